@@ -1,0 +1,261 @@
+"""ctypes bindings for oracle/liboracle.so and, where it has been built, for the
+unmodified reference library oracle/_ref/libstralg_ref.so.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+__all__ = [
+    "build", "sa_is", "sa_is_strict", "sa_naive", "bwt", "c_table", "o_table", "remap",
+    "check_sa", "last_levels", "synth", "have_ref", "ref",
+]
+
+
+def build(ref=True):
+    """Compile liboracle.so (and _ref/libstralg_ref.so when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    if ref and os.path.isdir("/root/reference/stralg"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        lib = C.CDLL(path)
+        P8, P32 = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+        lib.oracle_sa_is.argtypes = [P8, C.c_size_t, C.c_uint32, P32]
+        lib.oracle_sa_is.restype = C.c_int
+        lib.oracle_sa_is_strict.argtypes = [P8, C.c_size_t, C.c_uint32, P32]
+        lib.oracle_sa_is_strict.restype = C.c_int
+        lib.oracle_sa_naive.argtypes = [P8, C.c_size_t, P32]
+        lib.oracle_sa_naive.restype = C.c_int
+        lib.oracle_bwt.argtypes = [P8, P32, C.c_size_t, P8]
+        lib.oracle_bwt.restype = None
+        lib.oracle_c_table.argtypes = [P8, C.c_size_t, C.c_uint32, P32]
+        lib.oracle_c_table.restype = None
+        lib.oracle_o_table.argtypes = [P8, P32, C.c_size_t, C.c_uint32, P32]
+        lib.oracle_o_table.restype = None
+        lib.oracle_remap.argtypes = [P8, C.c_size_t, P8, C.POINTER(C.c_int16)]
+        lib.oracle_remap.restype = C.c_uint32
+        lib.oracle_check_sa.argtypes = [P8, C.c_size_t, P32]
+        lib.oracle_check_sa.restype = C.c_int
+        lib.oracle_last_levels.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+        lib.oracle_last_levels.restype = C.c_int
+        lib.oracle_synth.argtypes = [P8, C.c_size_t, C.c_uint32, C.c_uint64]
+        lib.oracle_synth.restype = None
+        _LIB = lib
+    return _LIB
+
+
+def _text(t):
+    """bytes / uint8 array of symbols (no terminator) -> contiguous array with a 0 appended."""
+    a = np.frombuffer(bytes(t), dtype=np.uint8) if isinstance(t, (bytes, bytearray)) else np.asarray(t, dtype=np.uint8)
+    buf = np.zeros(a.size + 1, dtype=np.uint8)
+    buf[: a.size] = a
+    return buf, a.size
+
+
+def sa_is(text, sigma):
+    """stralg/sa_is.c:466 sa_is_construction: suffix array (n+1 uint32) of text + sentinel."""
+    buf, n = _text(text)
+    out = np.empty(n + 1, dtype=np.uint32)
+    if _lib().oracle_sa_is(_u8(buf), n, sigma, _u32(out)) != 0:
+        raise MemoryError("oracle_sa_is")
+    return out
+
+
+def sa_is_strict(text, sigma):
+    buf, n = _text(text)
+    out = np.empty(n + 1, dtype=np.uint32)
+    if _lib().oracle_sa_is_strict(_u8(buf), n, sigma, _u32(out)) != 0:
+        raise MemoryError("oracle_sa_is_strict")
+    return out
+
+
+def sa_naive(text):
+    buf, n = _text(text)
+    out = np.empty(n + 1, dtype=np.uint32)
+    _lib().oracle_sa_naive(_u8(buf), n, _u32(out))
+    return out
+
+
+def bwt(text, sa):
+    buf, n = _text(text)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    out = np.empty(n + 1, dtype=np.uint8)
+    _lib().oracle_bwt(_u8(buf), _u32(sa), n + 1, _u8(out))
+    return out
+
+
+def c_table(text, sigma):
+    buf, n = _text(text)
+    out = np.empty(sigma, dtype=np.uint32)
+    _lib().oracle_c_table(_u8(buf), n + 1, sigma, _u32(out))
+    return out
+
+
+def o_table(text, sa, sigma):
+    """Position-major O table, shape (N+1, sigma)."""
+    buf, n = _text(text)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    out = np.empty((n + 2, sigma), dtype=np.uint32)
+    _lib().oracle_o_table(_u8(buf), _u32(sa), n + 1, sigma, _u32(out))
+    return out
+
+
+def remap(raw):
+    """stralg/remap.c: returns (remapped symbols without terminator, alphabet_size, table[256])."""
+    buf, n = _text(raw)
+    out = np.empty(n + 1, dtype=np.uint8)
+    table = np.empty(256, dtype=np.int16)
+    sigma = _lib().oracle_remap(_u8(buf), n, _u8(out), table.ctypes.data_as(C.POINTER(C.c_int16)))
+    return out[:n].copy(), int(sigma), table
+
+
+def check_sa(text, sa):
+    buf, n = _text(text)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    assert sa.size == n + 1
+    return bool(_lib().oracle_check_sa(_u8(buf), n, _u32(sa)))
+
+
+def last_levels():
+    ns = (C.c_uint64 * 64)()
+    ms = (C.c_uint64 * 64)()
+    k = _lib().oracle_last_levels(ns, ms, 64)
+    return [(int(ns[i]), int(ms[i])) for i in range(k)]
+
+
+def synth(n, sigma, seed):
+    out = np.empty(n, dtype=np.uint8)
+    _lib().oracle_synth(_u8(out), n, sigma, seed)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# The unmodified reference (build container only; never present on the GPU box)
+# ---------------------------------------------------------------------------
+
+class _RefSA(C.Structure):
+    # stralg/suffix_array.h:10-20
+    _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32),
+                ("array", C.POINTER(C.c_uint32)), ("inverse", C.POINTER(C.c_uint32)),
+                ("lcp", C.POINTER(C.c_uint32))]
+
+
+class _RefRemap(C.Structure):
+    # stralg/remap.h:9-19
+    _fields_ = [("alphabet_size", C.c_uint32), ("table", C.c_byte * 256),
+                ("rev_table", C.c_byte * 128)]
+
+
+class _RefBwt(C.Structure):
+    # stralg/bwt.h:36-44
+    _fields_ = [("remap_table", C.POINTER(_RefRemap)), ("sa", C.POINTER(_RefSA)),
+                ("c_table", C.POINTER(C.c_uint32)), ("o_table", C.POINTER(C.c_uint32)),
+                ("o_indices", C.POINTER(C.POINTER(C.c_uint32))),
+                ("ro_table", C.POINTER(C.c_uint32)),
+                ("ro_indices", C.POINTER(C.POINTER(C.c_uint32)))]
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libstralg_ref.so"))
+
+
+class _Ref:
+    """Thin driver around the reference's own entry points."""
+
+    def __init__(self):
+        lib = C.CDLL(os.path.join(_HERE, "_ref", "libstralg_ref.so"))
+        P8 = C.POINTER(C.c_uint8)
+        for name in ("sa_is_construction", "sa_is_mem_construction"):
+            f = getattr(lib, name)
+            f.argtypes = [P8, C.c_uint32]
+            f.restype = C.POINTER(_RefSA)
+        for name in ("skew_sa_construction", "qsort_sa_construction"):
+            f = getattr(lib, name)
+            f.argtypes = [P8]
+            f.restype = C.POINTER(_RefSA)
+        lib.free_suffix_array.argtypes = [C.POINTER(_RefSA)]
+        lib.free_suffix_array.restype = None
+        lib.remap_string.argtypes = [P8, P8]
+        lib.remap_string.restype = C.c_uint32
+        lib.build_complete_table.argtypes = [P8, C.c_bool]
+        lib.build_complete_table.restype = C.POINTER(_RefBwt)
+        lib.completely_free_bwt_table.argtypes = [C.POINTER(_RefBwt)]
+        lib.completely_free_bwt_table.restype = None
+        self.lib = lib
+
+    def _sa(self, fn, buf, *args):
+        sa = fn(_u8(buf), *args)
+        out = np.ctypeslib.as_array(sa.contents.array, shape=(sa.contents.length,)).copy()
+        self.lib.free_suffix_array(sa)
+        return out
+
+    def sa_is(self, text, sigma):
+        buf, _ = _text(text)
+        return self._sa(self.lib.sa_is_construction, buf, sigma)
+
+    def sa_is_mem(self, text, sigma):
+        buf, _ = _text(text)
+        return self._sa(self.lib.sa_is_mem_construction, buf, sigma)
+
+    def skew(self, text):
+        buf, _ = _text(text)
+        return self._sa(self.lib.skew_sa_construction, buf)
+
+    def qsort(self, text):
+        buf, _ = _text(text)
+        return self._sa(self.lib.qsort_sa_construction, buf)
+
+    def remap_string(self, raw):
+        buf, n = _text(raw)
+        out = np.zeros(n + 1, dtype=np.uint8)
+        sigma = self.lib.remap_string(_u8(out), _u8(buf))
+        return out[:n].copy(), int(sigma)
+
+    def build_complete_table(self, raw, include_reverse=True):
+        """Returns dict(sigma, remapped, sa, c, o[(N+1), sigma], ro or None)."""
+        buf, n = _text(raw)
+        t = self.lib.build_complete_table(_u8(buf), include_reverse)
+        bt = t.contents
+        sigma = int(bt.remap_table.contents.alphabet_size)
+        N = int(bt.sa.contents.length)
+        res = {
+            "sigma": sigma,
+            "remapped": np.ctypeslib.as_array(bt.sa.contents.string, shape=(N,)).copy()[:n],
+            "sa": np.ctypeslib.as_array(bt.sa.contents.array, shape=(N,)).copy(),
+            "c": np.ctypeslib.as_array(bt.c_table, shape=(sigma,)).copy(),
+            "o": np.ctypeslib.as_array(bt.o_table, shape=((N + 1) * sigma,)).copy().reshape(N + 1, sigma),
+            "ro": None,
+        }
+        if include_reverse:
+            res["ro"] = np.ctypeslib.as_array(bt.ro_table, shape=((N + 1) * sigma,)).copy().reshape(N + 1, sigma)
+        self.lib.completely_free_bwt_table(t)
+        return res
+
+
+def ref():
+    global _REF
+    if _REF is None:
+        _REF = _Ref()
+    return _REF
