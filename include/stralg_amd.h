@@ -1,0 +1,133 @@
+/*
+ * stralg_amd.h -- C-ABI of the MI355X suffix-array / BWT-table construction
+ * path (libstralg_amd.so).  Plain pointers and sizes only.
+ *
+ * These are the device-side entry points that stralg's own constructors bind
+ * (include/stralg_compat.h declares the reference-named wrappers on top):
+ *
+ *   sx_sa_build      replaces the body of  sa_is_construction      stralg/sa_is.c:466-509
+ *                                          sa_is_mem_construction  stralg/sa_is_mem.c:471-494
+ *                                          skew_sa_construction    stralg/skew.c:388-395
+ *   sx_bwt_tables    replaces the C/O/RO loops of init_bwt_table   stralg/bwt.c:35-88
+ *
+ * Every function returns 0 on success or a non-zero code (HIP error number,
+ * or one of SX_E_*); sx_last_error() gives the text.  There is no CPU
+ * fallback: without a usable GPU the calls fail.
+ */
+#ifndef STRALG_AMD_H
+#define STRALG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sx_ctx sx_ctx;
+
+enum {
+    SX_OK = 0,
+    SX_E_ARG = -1,     /* malformed argument (symbol >= alphabet_size, interior 0, n too large) */
+    SX_E_NOMEM = -2,   /* host allocation failed */
+    SX_E_INTERNAL = -3 /* a device-side invariant did not hold */
+};
+
+/* Kernel classes for the in-library HIP-event profiler (bench.py roofline). */
+enum {
+    SX_KC_CLASSIFY = 0,   /* S/L types, LMS flags, bucket histograms      sa_is.c:134-174 */
+    SX_KC_SAMPLES,        /* sample (LMS + cut) flags and compaction                       */
+    SX_KC_KEYS,           /* LMS-substring pieces -> 64-bit keys          sa_is.c:265-292 */
+    SX_KC_RADIX_HIST,     /* radix sort: per-tile digit histogram                          */
+    SX_KC_RADIX_SCATTER,  /* radix sort: stable scatter                                    */
+    SX_KC_SCAN,           /* device-wide scans / compactions                               */
+    SX_KC_NAMES,          /* names + reduced string                       sa_is.c:295-336 */
+    SX_KC_DOUBLING,       /* reduced-string suffix sort (elementwise steps)                */
+    SX_KC_INDUCE_GATHER,  /* induce: gather text[SA[i]-1] + per-tile bucket histogram      */
+    SX_KC_INDUCE_SCAN,    /* induce: per-bucket offsets                                    */
+    SX_KC_INDUCE_SCATTER, /* induce: stable scatter to bucket cursors     sa_is.c:220-263 */
+    SX_KC_BWT_GATHER,     /* bwt[i] = text[SA[i]-1] + per-tile symbol counts bwt.c:13-20  */
+    SX_KC_OTABLE,         /* O-table rows                                 bwt.c:47-65     */
+    SX_KC_MISC,
+    SX_KC_COUNT
+};
+
+typedef struct sx_kernel_stat {
+    uint64_t launches;
+    double ms;          /* sum of HIP-event durations */
+    uint64_t alg_bytes; /* sum of algorithmic bytes (per kernel) */
+} sx_kernel_stat;
+
+typedef struct sx_build_stats {
+    uint64_t n;              /* symbols without the sentinel */
+    uint64_t n_lms;          /* LMS positions incl. the sentinel */
+    uint64_t n_samples;      /* LMS positions + cut points = reduced string length */
+    uint64_t n_names;        /* distinct piece names */
+    uint32_t key_bits;       /* bits per symbol in a piece key */
+    uint32_t key_slots;      /* symbols per piece key */
+    uint32_t doubling_rounds;
+    uint32_t induce_rounds;  /* multisplit rounds over both passes */
+    uint32_t sort_passes;    /* radix passes, all sorts */
+    uint32_t reserved;
+    double ms_total;         /* wall time of the last build on the device stream */
+} sx_build_stats;
+
+/* ---- context ------------------------------------------------------------ */
+int sx_device_count(void);
+int sx_ctx_create(int device, sx_ctx **out);
+void sx_ctx_destroy(sx_ctx *ctx);
+const char *sx_last_error(const sx_ctx *ctx);
+/* drop cached workspace (it is otherwise kept between calls) */
+void sx_ctx_trim(sx_ctx *ctx);
+
+/* ---- suffix array -------------------------------------------------------- */
+/* Host buffers.  text[0..n) holds symbols in [1, alphabet_size), alphabet_size
+ * <= 256; sa_out receives n+1 entries (sa_out[0] == n, the sentinel suffix).
+ * Unlike sort_SA's shortcut (sa_is.c:423-428) the result is the true suffix
+ * array for any alphabet_size that bounds the symbols. */
+int sx_sa_build(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t alphabet_size,
+                uint32_t *sa_out);
+/* Device buffers (inputs resident in HBM); d_text has n bytes, d_sa_out n+1 entries. */
+int sx_sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t alphabet_size,
+                    uint32_t *d_sa_out);
+
+/* ---- BWT tables ------------------------------------------------------------ */
+/* text[0..N-1) symbols in [1, sigma) (N = n+1 counts the sentinel), sa[N].
+ * c_out[sigma]; o_out[(N+1)*sigma] position-major: o_out[i*sigma + a] = O(a,i).
+ * o_out may be NULL (C table only).  sigma <= 128 as in stralg/remap.h:14-18. */
+int sx_bwt_tables(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t N,
+                  uint32_t sigma, uint32_t *c_out, uint32_t *o_out);
+/* Device buffers; d_bwt_out (N bytes) is optional. */
+int sx_bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N,
+                      uint32_t sigma, uint32_t *d_c_out, uint32_t *d_o_out, uint8_t *d_bwt_out);
+
+/* ---- measurement ------------------------------------------------------------ */
+int sx_profile_enable(sx_ctx *ctx, int on);       /* bracket every launch with HIP events */
+int sx_profile_reset(sx_ctx *ctx);
+int sx_profile_read(sx_ctx *ctx, sx_kernel_stat *out /* SX_KC_COUNT entries */);
+const char *sx_kernel_class_name(int kclass);
+int sx_last_stats(const sx_ctx *ctx, sx_build_stats *out);
+
+/* Synthetic input on the device: symbol i = 1 + (splitmix64(seed, i) >> 33) % (sigma - 1)
+ * (same stream as oracle_synth / stralg_amd.synth). */
+int sx_synth_dev(sx_ctx *ctx, uint8_t *d_out, uint64_t n, uint32_t sigma, uint64_t seed);
+
+/* ---- primitives, exported for the kernel-level tests ---------------------- */
+/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit);
+ * all four device buffers hold n entries; *result_in_b tells where the output is. */
+int sx_prim_sort_pairs_dev(sx_ctx *ctx, uint64_t *d_keys_a, uint32_t *d_vals_a, uint64_t *d_keys_b,
+                           uint32_t *d_vals_b, uint64_t n, int begin_bit, int end_bit,
+                           int *result_in_b);
+/* exclusive prefix sum of n u32; d_total (optional) receives the grand total */
+int sx_prim_exclusive_sum_dev(sx_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
+                              uint32_t *d_total);
+/* S/L classification products: LMS flags as one byte per position (n+1) and the
+ * three per-symbol histograms (256 entries each): all symbols incl. sentinel,
+ * L-type symbols, LMS symbols. */
+int sx_prim_classify_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_lms_flags,
+                         uint32_t *d_hist_all, uint32_t *d_hist_l, uint32_t *d_hist_lms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

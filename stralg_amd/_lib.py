@@ -1,0 +1,78 @@
+"""ctypes binding of libstralg_amd.so (the C-ABI declared in include/stralg_amd.h).
+
+The product library is stralg_amd/libstralg_amd.so, built in-tree by
+stralg_amd/csrc/Makefile for gfx950.  There is no CPU fallback: if the library
+is missing, or no GPU is visible when a context is created, the call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "libstralg_amd.so")
+
+KC_NAMES = ["classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names", "doubling",
+            "induce_gather", "induce_scan", "induce_scatter", "bwt_gather", "otable", "misc"]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("alg_bytes", C.c_uint64)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_lms", C.c_uint64), ("n_samples", C.c_uint64),
+                ("n_names", C.c_uint64), ("key_bits", C.c_uint32), ("key_slots", C.c_uint32),
+                ("doubling_rounds", C.c_uint32), ("induce_rounds", C.c_uint32),
+                ("sort_passes", C.c_uint32), ("reserved", C.c_uint32), ("ms_total", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+def load(path=None):
+    """Load the shared library and declare every entry point of include/stralg_amd.h."""
+    path = path or PRODUCT_LIB
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `make -C stralg_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    sig = {
+        "sx_device_count": (C.c_int, []),
+        "sx_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "sx_ctx_destroy": (None, [vp]),
+        "sx_last_error": (C.c_char_p, [vp]),
+        "sx_ctx_trim": (None, [vp]),
+        "sx_sa_build": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, u32p]),
+        "sx_sa_build_dev": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, u32p]),
+        "sx_bwt_tables": (C.c_int, [vp, u8p, u32p, C.c_uint64, C.c_uint32, u32p, u32p]),
+        "sx_bwt_tables_dev": (C.c_int, [vp, u8p, u32p, C.c_uint64, C.c_uint32, u32p, u32p, u8p]),
+        "sx_profile_enable": (C.c_int, [vp, C.c_int]),
+        "sx_profile_reset": (C.c_int, [vp]),
+        "sx_profile_read": (C.c_int, [vp, C.POINTER(KernelStat)]),
+        "sx_kernel_class_name": (C.c_char_p, [C.c_int]),
+        "sx_last_stats": (C.c_int, [vp, C.POINTER(BuildStats)]),
+        "sx_synth_dev": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, C.c_uint64]),
+        "sx_prim_sort_pairs_dev": (C.c_int, [vp, u64p, u32p, u64p, u32p, C.c_uint64, C.c_int, C.c_int,
+                                             C.POINTER(C.c_int)]),
+        "sx_prim_exclusive_sum_dev": (C.c_int, [vp, u32p, u32p, C.c_uint64, u32p]),
+        "sx_prim_classify_dev": (C.c_int, [vp, u8p, C.c_uint64, u8p, u32p, u32p, u32p]),
+    }
+    missing = []
+    for name, (res, args) in sig.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise RuntimeError(f"{path} lacks symbols declared in include/stralg_amd.h: {missing}")
+    return lib
+
+
+EXPORTS = ["sx_device_count", "sx_ctx_create", "sx_ctx_destroy", "sx_last_error", "sx_ctx_trim",
+           "sx_sa_build", "sx_sa_build_dev", "sx_bwt_tables", "sx_bwt_tables_dev", "sx_profile_enable",
+           "sx_profile_reset", "sx_profile_read", "sx_kernel_class_name", "sx_last_stats",
+           "sx_synth_dev", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]

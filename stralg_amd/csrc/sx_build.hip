@@ -1,0 +1,207 @@
+// sx_build.hip -- suffix-array construction driver and its C-ABI entry points.
+//
+// Pipeline (each step cites the reference pass whose role it takes):
+//   1 classify            sa_is.c:134-174   types, LMS flags, bucket sizes
+//   2 samples + keys      sa_is.c:265-292   LMS-substring pieces as 64-bit keys
+//   3 radix sort, names   sa_is.c:295-336   sorted LMS substrings -> reduced string
+//   4 reduced suffix sort sa_is.c:370-387   (recursion) -> order of the LMS suffixes
+//   5 sorted LMS          sa_is.c:443-464   remap_LMS
+//   6 induce L, induce S  sa_is.c:220-263,397-398
+// The output is the unique suffix array, hence bit-identical to
+// sa_is_construction / sa_is_mem_construction / skew_sa_construction.
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_internal.hpp"
+
+#include <chrono>
+
+namespace sx {
+
+__global__ void write_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i)
+{
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void synth_kernel(uint8_t *__restrict__ out, uint64_t n, uint32_t span,
+                                                       uint64_t seed)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = (uint8_t)(1u + (uint32_t)((splitmix64_at(seed, i) >> 33) % span));
+}
+
+} // namespace sx
+
+using namespace sx;
+
+// bits per symbol, symbols per key, bits of the length field (tests/model.py key_layout)
+static void key_layout(uint32_t maxc, uint32_t &bits, uint32_t &slots, uint32_t &lenbits)
+{
+    bits = (uint32_t)sx_bitlen(maxc);
+    if (bits < 1) bits = 1;
+    slots = 2;
+    while ((slots + 1) * bits + (uint32_t)sx_bitlen(slots + 1) + 1 <= 64) ++slots;
+    lenbits = (uint32_t)sx_bitlen(slots);
+}
+
+static size_t reduce_bytes(uint64_t M, uint64_t m)
+{
+    const size_t a = 256;
+    size_t b = 0;
+    b += M * 4 + a;       // pos
+    b += M + a;           // is_lms
+    b += 2 * (M * 8 + a); // keys
+    b += 2 * (M * 4 + a); // vals
+    b += 3 * (M * 4 + a); // R, rank, sa_r
+    b += 2 * (M * 4 + a); // active positions
+    b += M * 4 + a;       // gid
+    b += 2 * (M + a);     // heads
+    b += m * 4 + a;       // sorted lms
+    b += 4096;
+    return b;
+}
+
+static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n = n;
+    if (sigma < 1 || sigma > 256) return sx_fail_msg(ctx, SX_E_ARG, "alphabet_size must be in [1, 256]");
+    if (n > 0xFFFFFFFEull) return sx_fail_msg(ctx, SX_E_ARG, "n must be at most 2^32 - 2");
+    if (n > 0 && sigma < 2) return sx_fail_msg(ctx, SX_E_ARG, "non-empty text needs alphabet_size >= 2");
+    if (n == 0) { // sa_is.c:413-417
+        sx_launch(ctx, SX_KC_MISC, 0, write_u32_kernel, dim3(1), dim3(1), d_sa, 0u);
+        return sx_sync(ctx);
+    }
+    const uint64_t N = n + 1;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, sx_text_scratch_bytes(n) + sx_induce_scratch_bytes(N, sigma)));
+    sx_arena an;
+    an.base = (char *)ctx->slab[SX_SLAB_N].p;
+    an.cap = ctx->slab[SX_SLAB_N].cap;
+    const uint64_t padded = (uint64_t)sx_div_up(N, kClsTile) * kClsTile + 64;
+    uint8_t *T = an.take<uint8_t>(padded);
+    if (!T) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: text");
+    // only the tail needs zeroing: sentinel + padding
+    SX_CHECK(hipMemcpyAsync(T, d_text, n, hipMemcpyDeviceToDevice, ctx->stream));
+    SX_CHECK(hipMemsetAsync(T + n, 0, padded - n, ctx->stream));
+
+    sx_text_info ti;
+    SX_TRY(sx_classify(ctx, T, n, an, ti));
+    if (ti.maxc >= sigma) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= alphabet_size");
+    ctx->stats.n_lms = ti.m;
+
+    const uint32_t *sorted_lms = nullptr;
+    if (ti.m <= 1) {
+        // only the sentinel is LMS: it alone seeds the induction
+        uint32_t *one = an.take<uint32_t>(1);
+        if (!one) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena");
+        sx_launch(ctx, SX_KC_MISC, 0, write_u32_kernel, dim3(1), dim3(1), one, (uint32_t)n);
+        sorted_lms = one;
+        ctx->stats.n_samples = 1;
+        ctx->stats.n_names = 1;
+    } else {
+        uint32_t bits, slots, lenbits;
+        key_layout(ti.maxc, bits, slots, lenbits);
+        ctx->stats.key_bits = bits;
+        ctx->stats.key_slots = slots;
+        SX_TRY(sx_sample_flags(ctx, ti, slots - 1));
+        const uint64_t M = ti.M;
+        ctx->stats.n_samples = M;
+        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, reduce_bytes(M, ti.m)));
+        sx_arena am;
+        am.base = (char *)ctx->slab[SX_SLAB_M].p;
+        am.cap = ctx->slab[SX_SLAB_M].cap;
+        uint32_t *pos = am.take<uint32_t>(M);
+        uint8_t *is_lms = am.take<uint8_t>(M);
+        sx_reduce_bufs rb;
+        rb.ka = am.take<uint64_t>(M);
+        rb.kb = am.take<uint64_t>(M);
+        rb.va = am.take<uint32_t>(M);
+        rb.vb = am.take<uint32_t>(M);
+        rb.R = am.take<uint32_t>(M);
+        rb.rank = am.take<uint32_t>(M);
+        rb.sa_r = am.take<uint32_t>(M);
+        rb.pos_a = am.take<uint32_t>(M);
+        rb.pos_b = am.take<uint32_t>(M);
+        rb.gid = am.take<uint32_t>(M);
+        rb.head_a = am.take<uint8_t>(M);
+        rb.head_b = am.take<uint8_t>(M);
+        uint32_t *slms = am.take<uint32_t>(ti.m);
+        rb.d_scalar = am.take<uint32_t>(16);
+        if (!pos || !is_lms || !rb.ka || !rb.kb || !rb.va || !rb.vb || !rb.R || !rb.rank || !rb.sa_r || !rb.pos_a ||
+            !rb.pos_b || !rb.gid || !rb.head_a || !rb.head_b || !slms || !rb.d_scalar)
+            return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: reduce buffers");
+
+        SX_TRY(sx_sample_write(ctx, ti, pos, is_lms));
+        SX_TRY(sx_piece_keys(ctx, ti, pos, is_lms, bits, slots, lenbits, rb.ka, rb.va));
+        const int used = (int)(slots * bits + lenbits + 1);
+        int in_b = 0;
+        SX_TRY(sx_sort_pairs(ctx, rb.ka, rb.va, rb.kb, rb.vb, M, 64 - used, 64, &in_b));
+        const uint64_t *ks = in_b ? rb.kb : rb.ka;
+        const uint32_t *vs = in_b ? rb.vb : rb.va;
+        uint64_t n_names = 0;
+        SX_TRY(sx_name_pieces(ctx, ks, vs, M, rb, &n_names));
+        ctx->stats.n_names = n_names;
+        const uint32_t *sa_r;
+        if (n_names == M) {
+            sa_r = vs; // every piece is unique: sorted pieces == sorted suffixes (sa_is.c:423-428)
+        } else {
+            SX_TRY(sx_reduced_suffix_sort(ctx, M, n_names, rb));
+            sa_r = rb.sa_r;
+        }
+        SX_TRY(sx_sorted_lms(ctx, sa_r, pos, is_lms, M, slms, rb.d_scalar));
+        uint32_t got = 0;
+        SX_TRY(sx_readback(ctx, rb.d_scalar, 1, &got));
+        if (got != ti.m) return sx_fail_msg(ctx, SX_E_INTERNAL, "sorted LMS count differs from the LMS count");
+        sorted_lms = slms;
+    }
+
+    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, d_sa, an));
+    SX_TRY(sx_sync(ctx));
+    ctx->stats.ms_total =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+extern "C" {
+
+int sx_sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t alphabet_size, uint32_t *d_sa_out)
+{
+    if (!ctx || !d_sa_out || (n && !d_text)) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    return sa_build_dev(ctx, d_text, n, alphabet_size, d_sa_out);
+}
+
+int sx_sa_build(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t alphabet_size, uint32_t *sa_out)
+{
+    if (!ctx || !sa_out || (n && !text)) return SX_E_ARG;
+    if (n > 0xFFFFFFFEull) return sx_fail_msg(ctx, SX_E_ARG, "n must be at most 2^32 - 2");
+    SX_CHECK(hipSetDevice(ctx->device));
+    const uint64_t N = n + 1;
+    const size_t text_bytes = (n + 255) & ~(size_t)255;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, text_bytes + N * sizeof(uint32_t) + 512));
+    uint8_t *d_text = (uint8_t *)ctx->slab[SX_SLAB_IO].p;
+    uint32_t *d_sa = (uint32_t *)((char *)ctx->slab[SX_SLAB_IO].p + text_bytes + 256);
+    if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
+    SX_TRY(sa_build_dev(ctx, d_text, n, alphabet_size, d_sa));
+    SX_CHECK(hipMemcpyAsync(sa_out, d_sa, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return sx_sync(ctx);
+}
+
+int sx_synth_dev(sx_ctx *ctx, uint8_t *d_out, uint64_t n, uint32_t sigma, uint64_t seed)
+{
+    if (!ctx || sigma < 2 || sigma > 256) return SX_E_ARG;
+    if (n == 0) return 0;
+    SX_CHECK(hipSetDevice(ctx->device));
+    uint32_t grid = sx_div_up(n, kBlock);
+    if (grid > 8192) grid = 8192;
+    sx_launch(ctx, SX_KC_MISC, n, synth_kernel, dim3(grid), dim3(kBlock), d_out, n, sigma - 1, seed);
+    return sx_sync(ctx);
+}
+
+} // extern "C"

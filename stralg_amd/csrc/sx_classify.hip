@@ -1,0 +1,442 @@
+// sx_classify.hip -- level-0 streaming passes over the text.
+//
+//   cls_first / cls_resolve / cls_types   S/L classification as a backward
+//        segmented scan (stralg/sa_is.c:134-153 classify_SL), LMS predicate
+//        (sa_is.c:155-162), and the three per-symbol histograms: bucket sizes
+//        (sa_is.c:164-174 compute_buckets), L-type counts, LMS counts.
+//   samp_flags / samp_write               sample positions = LMS positions plus a
+//        cut every W symbols inside LMS substrings longer than W, so that every
+//        piece fits one 64-bit sort key.
+//   piece_keys                            pieces -> keys (comparison semantics of
+//        sa_is.c:265-292 equal_LMS extended to an order).
+//
+// All passes are HBM streaming: 16 text bytes per thread as one dwordx4 load,
+// a workgroup owns 4096 consecutive positions, types are resolved with
+// 64-lane ballots inside a wave and a 4-entry LDS hand-off between waves.
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_scan.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void load_chunk(const uint8_t *__restrict__ T, uint64_t p0, uint32_t (&c)[17])
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(T + p0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    c[16] = T[p0 + 16];
+}
+
+// bit i of dmask: the type of position p0+i is decided by its right neighbour;
+// bit i of vmask: ... and it is S.  The sentinel position n is S by definition.
+__device__ __forceinline__ void decided_masks(const uint32_t (&c)[17], uint64_t p0, uint64_t n,
+                                              uint32_t &dmask, uint32_t &vmask)
+{
+    dmask = 0;
+    vmask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t pos = p0 + i;
+        bool dec, val;
+        if (pos < n) {
+            dec = c[i] != c[i + 1];
+            val = c[i] < c[i + 1];
+        } else {
+            dec = pos == n;
+            val = true;
+        }
+        dmask |= (dec ? 1u : 0u) << i;
+        vmask |= ((dec && val) ? 1u : 0u) << i;
+    }
+}
+
+// ---- pass 1: type of each tile's first position, if the tile decides it -------
+__global__ __launch_bounds__(kBlock) void cls_first_kernel(const uint8_t *__restrict__ T, uint64_t n,
+                                                           uint8_t *__restrict__ tile_first)
+{
+    __shared__ uint32_t best;
+    if (threadIdx.x == 0) best = kNone;
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)threadIdx.x * kClsPerThread;
+    uint32_t c[17], dmask, vmask;
+    load_chunk(T, p0, c);
+    decided_masks(c, p0, n, dmask, vmask);
+    if (dmask) {
+        const int i = __ffs(dmask) - 1;
+        atomicMin(&best, ((threadIdx.x * kClsPerThread + (uint32_t)i) << 1) | ((vmask >> i) & 1u));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_first[blockIdx.x] = best == kNone ? (uint8_t)2 : (uint8_t)(best & 1u);
+}
+
+// ---- pass 2: tiles made of one symbol whose run continues take the type of the
+// next tile to the right.  One workgroup, right to left, 4096 tiles a step.
+__global__ __launch_bounds__(kBlock) void cls_resolve_kernel(uint8_t *__restrict__ tile_first, uint32_t ntiles)
+{
+    __shared__ uint32_t whas[kWavesPerBlock], wval[kWavesPerBlock], carry_s;
+    const int lane = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) carry_s = 1;
+    __syncthreads();
+    // r = distance from the last tile; tile index = ntiles - 1 - r
+    for (uint64_t start = 0; start < ntiles; start += (uint64_t)kBlock * 16) {
+        const uint64_t r0 = start + (uint64_t)threadIdx.x * 16;
+        uint32_t v[16];
+        bool has = false;
+        uint32_t last = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t r = r0 + k;
+            v[k] = r < ntiles ? tile_first[ntiles - 1 - r] : 2u;
+            if (v[k] != 2u) {
+                has = true;
+                last = v[k];
+            }
+        }
+        const uint64_t hm = __ballot(has ? 1 : 0);
+        const uint64_t fm = __ballot((has && last) ? 1 : 0);
+        if (lane == 0) {
+            whas[w] = hm != 0;
+            wval[w] = hm ? (uint32_t)((fm >> (63 - __clzll((unsigned long long)hm))) & 1ull) : 0u;
+        }
+        __syncthreads();
+        uint32_t cin;
+        const uint64_t lower = hm & lanemask_lt();
+        if (lower) {
+            cin = (uint32_t)((fm >> (63 - __clzll((unsigned long long)lower))) & 1ull);
+        } else {
+            cin = carry_s;
+            for (int ww = 0; ww < w; ++ww)
+                if (whas[ww]) cin = wval[ww];
+        }
+        uint32_t cur = cin;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t r = r0 + k;
+            if (v[k] != 2u) cur = v[k];
+            if (r < ntiles) tile_first[ntiles - 1 - r] = (uint8_t)cur;
+        }
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = cur;
+        __syncthreads();
+    }
+}
+
+// Type of the first position to the right of this thread's chunk: the first
+// decided position of a later thread of the tile, else the next tile's first type.
+__device__ __forceinline__ uint32_t carry_from_right(bool has, uint32_t first_val, uint32_t tile_carry,
+                                                     uint32_t *lds /* 2 * kWavesPerBlock */)
+{
+    const int lane = lane_id(), w = wave_id();
+    const uint64_t hm = __ballot(has ? 1 : 0);
+    const uint64_t fm = __ballot((has && first_val) ? 1 : 0);
+    if (lane == 0) {
+        lds[w] = hm != 0;
+        lds[kWavesPerBlock + w] = hm ? (uint32_t)((fm >> (__ffsll((unsigned long long)hm) - 1)) & 1ull) : 0u;
+    }
+    __syncthreads();
+    const uint64_t higher = lane == 63 ? 0ull : ((hm >> (lane + 1)) << (lane + 1));
+    uint32_t cin;
+    if (higher) {
+        cin = (uint32_t)((fm >> (__ffsll((unsigned long long)higher) - 1)) & 1ull);
+    } else {
+        cin = tile_carry;
+        for (int ww = kWavesPerBlock - 1; ww > w; --ww)
+            if (lds[ww]) cin = lds[kWavesPerBlock + ww];
+    }
+    __syncthreads();
+    return cin;
+}
+
+// ---- pass 3: types, LMS bits, histograms ------------------------------------------
+__global__ __launch_bounds__(kBlock) void cls_types_kernel(
+    const uint8_t *__restrict__ T, uint64_t n, const uint8_t *__restrict__ tile_first, uint32_t ntiles,
+    uint16_t *__restrict__ lmsbits, uint32_t *__restrict__ tile_lms, uint32_t *__restrict__ tile_last,
+    uint32_t *__restrict__ g_hist /* 3 * 256 */)
+{
+    __shared__ uint32_t h[3][256];
+    __shared__ uint32_t lds[2 * kWavesPerBlock];
+    __shared__ uint32_t last_s[kBlock];
+    const int t = (int)threadIdx.x;
+    h[0][t] = 0;
+    h[1][t] = 0;
+    h[2][t] = 0;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kClsTile;
+    const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
+    uint32_t c[17], dmask, vmask;
+    load_chunk(T, p0, c);
+    decided_masks(c, p0, n, dmask, vmask);
+    const uint32_t tile_carry = blockIdx.x + 1 < ntiles ? tile_first[blockIdx.x + 1] : 1u;
+    const bool has = dmask != 0;
+    const uint32_t fv = has ? (vmask >> (__ffs(dmask) - 1)) & 1u : 0u;
+    uint32_t cur = carry_from_right(has, fv, tile_carry, lds); // includes barriers (h[] is zeroed)
+    uint32_t smask = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+        if ((dmask >> i) & 1u) cur = (vmask >> i) & 1u;
+        smask |= cur << i;
+    }
+    last_s[t] = (smask >> 15) & 1u;
+    __syncthreads();
+    uint32_t prev_s;
+    if (t > 0) {
+        prev_s = last_s[t - 1];
+    } else if (tile0 == 0) {
+        prev_s = 1; // position 0 is never LMS
+    } else {
+        const uint32_t a = T[tile0 - 1], b = c[0];
+        prev_s = a < b ? 1u : (a > b ? 0u : (smask & 1u));
+    }
+    // LMS: S-type whose left neighbour is L-type (sa_is.c:155-162)
+    uint32_t lmsmask = smask & ~((smask << 1) | prev_s);
+    uint32_t valid = 0xFFFFu;
+    if (p0 > n) valid = 0;
+    else if (n - p0 < 15) valid = (2u << (uint32_t)(n - p0)) - 1u; // positions p0 .. n
+    lmsmask &= valid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if ((valid >> i) & 1u) {
+            const uint32_t ch = (p0 + i == n) ? 0u : c[i];
+            atomicAdd(&h[0][ch], 1u);
+            if (!((smask >> i) & 1u)) atomicAdd(&h[1][ch], 1u);
+            if ((lmsmask >> i) & 1u) atomicAdd(&h[2][ch], 1u);
+        }
+    }
+    lmsbits[(uint64_t)blockIdx.x * kBlock + t] = (uint16_t)lmsmask;
+    const uint32_t cnt = (uint32_t)__popc(lmsmask);
+    const uint32_t lastp1 = lmsmask ? (uint32_t)(p0 + (31 - __clz(lmsmask))) + 1u : 0u;
+    uint32_t tot_cnt, tot_last;
+    (void)block_exclusive_scan<OpAdd>(cnt, lds, tot_cnt);
+    (void)block_exclusive_scan<OpMax>(lastp1, lds, tot_last);
+    if (t == 0) {
+        tile_lms[blockIdx.x] = tot_cnt;
+        tile_last[blockIdx.x] = tot_last;
+    }
+    // (the scans above end with a barrier: h[] is complete)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t v = h[k][t];
+        if (v) atomicAdd(&g_hist[k * 256 + t], v);
+    }
+}
+
+// ---- pass 4: sample flags ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void samp_flags_kernel(const uint16_t *__restrict__ lmsbits, uint64_t n,
+                                                            const uint32_t *__restrict__ tile_prev, uint32_t W,
+                                                            uint16_t *__restrict__ sampbits,
+                                                            uint32_t *__restrict__ tile_samp)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const int t = (int)threadIdx.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)t * kClsPerThread;
+    const uint32_t lmsmask = lmsbits[(uint64_t)blockIdx.x * kBlock + t];
+    const uint32_t lastp1 = lmsmask ? (uint32_t)(p0 + (31 - __clz(lmsmask))) + 1u : 0u;
+    uint32_t tot;
+    uint32_t prev = block_exclusive_scan<OpMax>(lastp1, lds, tot);
+    const uint32_t tp = tile_prev[blockIdx.x];
+    prev = prev > tp ? prev : tp; // position + 1 of the nearest LMS to the left, 0 = none
+    uint32_t smp = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t pos = p0 + i;
+        if (pos <= n) {
+            if ((lmsmask >> i) & 1u) {
+                prev = (uint32_t)pos + 1u;
+                smp |= 1u << i;
+            } else if (prev != 0 && pos < n && ((uint32_t)pos - (prev - 1u)) % W == 0) {
+                smp |= 1u << i;
+            }
+        }
+    }
+    sampbits[(uint64_t)blockIdx.x * kBlock + t] = (uint16_t)smp;
+    uint32_t tot_s;
+    (void)block_exclusive_scan<OpAdd>((uint32_t)__popc(smp), lds, tot_s);
+    if (t == 0) tile_samp[blockIdx.x] = tot_s;
+}
+
+// ---- pass 5: compaction of the sample positions -------------------------------------
+__global__ __launch_bounds__(kBlock) void samp_write_kernel(const uint16_t *__restrict__ sampbits,
+                                                            const uint16_t *__restrict__ lmsbits,
+                                                            const uint32_t *__restrict__ tile_off,
+                                                            uint32_t *__restrict__ pos_out,
+                                                            uint8_t *__restrict__ islms_out)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const int t = (int)threadIdx.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)t * kClsPerThread;
+    uint32_t smp = sampbits[(uint64_t)blockIdx.x * kBlock + t];
+    const uint32_t lmsmask = lmsbits[(uint64_t)blockIdx.x * kBlock + t];
+    uint32_t tot;
+    uint32_t dst = block_exclusive_scan<OpAdd>((uint32_t)__popc(smp), lds, tot) + tile_off[blockIdx.x];
+    while (smp) {
+        const int i = __ffs(smp) - 1;
+        smp &= smp - 1u;
+        pos_out[dst] = (uint32_t)(p0 + i);
+        islms_out[dst] = (uint8_t)((lmsmask >> i) & 1u);
+        ++dst;
+    }
+}
+
+// ---- piece keys ---------------------------------------------------------------------
+// Piece k covers text[pos[k] .. pos[k+1]] (both ends included, <= slots symbols).
+// Key, most significant first: the symbols (bits each) padded with all-ones,
+// then (slots - length) so that of two pieces with equal padded symbols the
+// longer is smaller, then 1 if the piece ends at an LMS position, 0 if it ends
+// at a cut.  The sentinel piece gets key 0.
+__global__ __launch_bounds__(kBlock) void piece_keys_kernel(const uint8_t *__restrict__ T,
+                                                            const uint32_t *__restrict__ pos,
+                                                            const uint8_t *__restrict__ is_lms, uint64_t M,
+                                                            uint32_t bits, uint32_t slots, uint32_t lenbits,
+                                                            uint64_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ vals)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= M) return;
+    uint64_t key = 0;
+    if (k + 1 < M) {
+        const uint32_t i = pos[k], e = pos[k + 1];
+        const uint32_t len = e - i + 1u;
+        const uint64_t ones = (1ull << bits) - 1ull;
+        uint64_t acc = 0;
+        for (uint32_t s = 0; s < slots; ++s) {
+            const uint64_t code = s < len ? (uint64_t)T[(uint64_t)i + s] : ones;
+            acc = (acc << bits) | code;
+        }
+        acc = (acc << lenbits) | (uint64_t)(slots - len);
+        acc = (acc << 1) | (uint64_t)is_lms[k + 1];
+        key = acc << (64u - (slots * bits + lenbits + 1u));
+    }
+    keys[k] = key;
+    vals[k] = (uint32_t)k;
+}
+
+__global__ __launch_bounds__(kBlock) void expand_bits_kernel(const uint16_t *__restrict__ bits, uint64_t N,
+                                                             uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < N) out[i] = (uint8_t)((bits[i >> 4] >> (i & 15)) & 1u);
+}
+
+struct InPlus1Max {
+    const uint32_t *p;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return p[i]; }
+};
+
+} // namespace sx
+
+using namespace sx;
+
+size_t sx_text_scratch_bytes(uint64_t n)
+{
+    const uint64_t N = n + 1;
+    const uint64_t ntiles = (N + kClsTile - 1) / kClsTile;
+    size_t b = 0;
+    b += ntiles * kClsTile + 256;         // padded text copy
+    b += 2 * (ntiles * kBlock * 2 + 256); // lmsbits, sampbits
+    b += 5 * ntiles * 4 + 256;            // tile_u32
+    b += ntiles + 256;                    // tile_first
+    b += 3 * 256 * 4 + 256 + 256;         // hist, scalars
+    return b + 4096;
+}
+
+int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti)
+{
+    ti.T = T;
+    ti.n = n;
+    ti.N = n + 1;
+    ti.ntiles = sx_div_up(ti.N, kClsTile);
+    ti.lmsbits = arena.take<uint16_t>((size_t)ti.ntiles * kBlock);
+    ti.sampbits = arena.take<uint16_t>((size_t)ti.ntiles * kBlock);
+    ti.tile_u32 = arena.take<uint32_t>((size_t)ti.ntiles * 5);
+    ti.tile_first = arena.take<uint8_t>(ti.ntiles);
+    ti.d_hist = arena.take<uint32_t>(3 * 256);
+    ti.d_scalar = arena.take<uint32_t>(16);
+    if (!ti.lmsbits || !ti.sampbits || !ti.tile_u32 || !ti.tile_first || !ti.d_hist || !ti.d_scalar)
+        return sx_fail_msg(ctx, SX_E_INTERNAL, "classify: arena too small");
+    uint32_t *tile_lms = ti.tile_u32, *tile_last = ti.tile_u32 + ti.ntiles;
+    SX_CHECK(hipMemsetAsync(ti.d_hist, 0, 3 * 256 * sizeof(uint32_t), ctx->stream));
+    const dim3 grid(ti.ntiles), block(kBlock);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N, cls_first_kernel, grid, block, T, n, ti.tile_first);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.ntiles, cls_resolve_kernel, dim3(1), block, ti.tile_first, ti.ntiles);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8, cls_types_kernel, grid, block, T, n,
+              (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms, tile_last, ti.d_hist);
+    // read the three histograms back: the host drives the bucket loop
+    uint32_t h[3 * 256];
+    SX_TRY(sx_readback(ctx, ti.d_hist, 3 * 256, h));
+    memcpy(ti.h_all, h, sizeof ti.h_all);
+    memcpy(ti.h_l, h + 256, sizeof ti.h_l);
+    memcpy(ti.h_lms, h + 512, sizeof ti.h_lms);
+    ti.maxc = 0;
+    ti.m = 0;
+    uint64_t total = 0;
+    for (int c = 0; c < 256; ++c) {
+        if (ti.h_all[c]) ti.maxc = (uint32_t)c;
+        ti.m += ti.h_lms[c];
+        total += ti.h_all[c];
+    }
+    if (total != ti.N) return sx_fail_msg(ctx, SX_E_INTERNAL, "classify: histogram does not add up to n+1");
+    if (ti.h_all[0] != 1) return sx_fail_msg(ctx, SX_E_ARG, "text contains the sentinel symbol 0");
+    ti.M = 0;
+    return 0;
+}
+
+int sx_sample_flags(sx_ctx *ctx, sx_text_info &ti, uint32_t W)
+{
+    uint32_t *tile_last = ti.tile_u32 + ti.ntiles, *tile_prev = ti.tile_u32 + 2 * (size_t)ti.ntiles,
+             *tile_samp = ti.tile_u32 + 3 * (size_t)ti.ntiles, *tile_off = ti.tile_u32 + 4 * (size_t)ti.ntiles;
+    // nearest LMS position (+1) in the tiles to the left of each tile
+    SX_TRY((device_scan<OpMax>(ctx, ti.ntiles, InU32{tile_last}, OutExclusive{tile_prev}, nullptr)));
+    sx_launch(ctx, SX_KC_SAMPLES, ti.N / 4, samp_flags_kernel, dim3(ti.ntiles), dim3(kBlock),
+              (const uint16_t *)ti.lmsbits, ti.n, (const uint32_t *)tile_prev, W, ti.sampbits, tile_samp);
+    SX_TRY((device_scan<OpAdd>(ctx, ti.ntiles, InU32{tile_samp}, OutExclusive{tile_off}, ti.d_scalar)));
+    uint32_t M32 = 0;
+    SX_TRY(sx_readback(ctx, ti.d_scalar, 1, &M32));
+    ti.M = M32;
+    if (ti.M < ti.m) return sx_fail_msg(ctx, SX_E_INTERNAL, "samples: fewer samples than LMS positions");
+    return 0;
+}
+
+int sx_sample_write(sx_ctx *ctx, const sx_text_info &ti, uint32_t *pos, uint8_t *is_lms)
+{
+    const uint32_t *tile_off = ti.tile_u32 + 4 * (size_t)ti.ntiles;
+    sx_launch(ctx, SX_KC_SAMPLES, ti.N / 4 + ti.M * 5, samp_write_kernel, dim3(ti.ntiles), dim3(kBlock),
+              (const uint16_t *)ti.sampbits, (const uint16_t *)ti.lmsbits, tile_off, pos, is_lms);
+    return 0;
+}
+
+int sx_piece_keys(sx_ctx *ctx, const sx_text_info &ti, const uint32_t *pos, const uint8_t *is_lms,
+                  uint32_t bits, uint32_t slots, uint32_t lenbits, uint64_t *keys, uint32_t *vals)
+{
+    if (ti.M == 0) return 0;
+    sx_launch(ctx, SX_KC_KEYS, ti.M * (4 + 1 + 12) + ti.N, piece_keys_kernel, dim3(sx_div_up(ti.M, kBlock)),
+              dim3(kBlock), ti.T, pos, is_lms, ti.M, bits, slots, lenbits, keys, vals);
+    return 0;
+}
+
+extern "C" int sx_prim_classify_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint8_t *d_lms_flags,
+                                    uint32_t *d_hist_all, uint32_t *d_hist_l, uint32_t *d_hist_lms)
+{
+    if (!ctx) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, sx_text_scratch_bytes(n)));
+    sx_arena arena;
+    arena.base = (char *)ctx->slab[SX_SLAB_N].p;
+    arena.cap = ctx->slab[SX_SLAB_N].cap;
+    const uint64_t N = n + 1;
+    const uint64_t padded = (uint64_t)sx_div_up(N, kClsTile) * kClsTile + 64;
+    uint8_t *T = arena.take<uint8_t>(padded);
+    if (!T) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena");
+    SX_CHECK(hipMemsetAsync(T, 0, padded, ctx->stream));
+    if (n) SX_CHECK(hipMemcpyAsync(T, d_text, n, hipMemcpyDeviceToDevice, ctx->stream));
+    sx_text_info ti;
+    SX_TRY(sx_classify(ctx, T, n, arena, ti));
+    sx_launch(ctx, SX_KC_MISC, 0, expand_bits_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock),
+              (const uint16_t *)ti.lmsbits, N, d_lms_flags);
+    SX_CHECK(hipMemcpyAsync(d_hist_all, ti.d_hist, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    SX_CHECK(hipMemcpyAsync(d_hist_l, ti.d_hist + 256, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    SX_CHECK(hipMemcpyAsync(d_hist_lms, ti.d_hist + 512, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return sx_sync(ctx);
+}

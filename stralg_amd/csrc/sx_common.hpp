@@ -1,0 +1,99 @@
+// sx_common.hpp -- context, workspace slabs, launch + profiling helpers.
+//
+// One sx_ctx per (host thread, GPU): it owns a HIP stream, grow-only device
+// slabs and a pinned read-back page.  Nothing here is process-global, so N
+// host threads can drive N GPUs concurrently (threading).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/stralg_amd.h"
+
+#define SX_CHECK(expr)                                                         \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) return sx_fail(ctx, (int)e_, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define SX_TRY(expr)                                                           \
+    do {                                                                       \
+        int rc_ = (expr);                                                      \
+        if (rc_ != 0) return rc_;                                              \
+    } while (0)
+
+struct sx_slab {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// bump allocator over one slab; offsets are 256-byte aligned
+struct sx_arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    template <class T> T *take(size_t count)
+    {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) return nullptr;
+        T *r = reinterpret_cast<T *>(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+struct sx_event_pair {
+    hipEvent_t a, b;
+    int kclass;
+};
+
+enum { SX_SLAB_N = 0, SX_SLAB_M = 1, SX_SLAB_TMP = 2, SX_SLAB_BWT = 3, SX_SLAB_SCAN = 4, SX_SLAB_SORT = 5, SX_SLAB_IO = 6, SX_NSLABS = 7 };
+
+struct sx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    sx_slab slab[SX_NSLABS];
+    uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB)
+    // profiling
+    int prof_on = 0;
+    std::vector<sx_event_pair> ev_used;
+    std::vector<sx_event_pair> ev_free;
+    sx_kernel_stat kstat[SX_KC_COUNT];
+    sx_build_stats stats;
+};
+
+int sx_fail(sx_ctx *ctx, int code, const char *what, const char *file, int line);
+int sx_fail_msg(sx_ctx *ctx, int code, const char *msg);
+int sx_slab_ensure(sx_ctx *ctx, int which, size_t bytes);
+int sx_sync(sx_ctx *ctx);
+// device -> pinned host copy of `count` u32 followed by a stream sync
+int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst);
+
+void sx_prof_begin(sx_ctx *ctx, int kclass);
+void sx_prof_end(sx_ctx *ctx, int kclass, uint64_t alg_bytes);
+
+// Launch with optional HIP-event bracketing on the context's stream.
+// alg_bytes = algorithmic bytes moved by this launch (per kernel).
+template <class... P, class... A>
+static inline void sx_launch(sx_ctx *ctx, int kclass, uint64_t alg_bytes, void (*kernel)(P...),
+                             dim3 grid, dim3 block, A... args)
+{
+    if (ctx->prof_on) sx_prof_begin(ctx, kclass);
+    hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+    if (ctx->prof_on) sx_prof_end(ctx, kclass, alg_bytes);
+}
+
+static inline uint32_t sx_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+static inline int sx_bitlen(uint64_t v)
+{
+    int b = 0;
+    while (v) {
+        ++b;
+        v >>= 1;
+    }
+    return b;
+}

@@ -1,0 +1,202 @@
+// sx_ctx.hip -- context lifetime, workspace slabs, HIP-event profiler.
+#include "sx_common.hpp"
+#include "sx_scan.hpp"
+
+#include <new>
+
+static const char *kClassNames[SX_KC_COUNT] = {
+    "classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names",
+    "doubling", "induce_gather", "induce_scan", "induce_scatter", "bwt_gather", "otable", "misc",
+};
+
+int sx_fail(sx_ctx *ctx, int code, const char *what, const char *file, int line)
+{
+    if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%d) at %s:%d", what,
+                      hipGetErrorString((hipError_t)code), code, file, line);
+    return code ? code : SX_E_INTERNAL;
+}
+
+int sx_fail_msg(sx_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", msg);
+    return code;
+}
+
+int sx_slab_ensure(sx_ctx *ctx, int which, size_t bytes)
+{
+    sx_slab &s = ctx->slab[which];
+    if (s.cap >= bytes) return 0;
+    if (s.p) {
+        SX_CHECK(hipStreamSynchronize(ctx->stream));
+        SX_CHECK(hipFree(s.p));
+        s.p = nullptr;
+        s.cap = 0;
+    }
+    // round up so that repeated calls with slowly growing inputs do not thrash
+    size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    SX_CHECK(hipMalloc(&s.p, want));
+    s.cap = want;
+    return 0;
+}
+
+uint32_t *sx::sx_scan_scratch(sx_ctx *ctx, uint32_t ntiles)
+{
+    // tile totals of the scan in flight; a slab of its own so that growing it
+    // never moves a caller's data
+    const size_t need = (size_t)ntiles * sizeof(uint32_t);
+    if (ctx->slab[SX_SLAB_SCAN].cap < need) {
+        if (sx_slab_ensure(ctx, SX_SLAB_SCAN, need) != 0) return nullptr;
+    }
+    return (uint32_t *)ctx->slab[SX_SLAB_SCAN].p;
+}
+
+int sx_sync(sx_ctx *ctx)
+{
+    SX_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst)
+{
+    if (count * sizeof(uint32_t) > 4096) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
+    SX_CHECK(hipMemcpyAsync(ctx->h_pin, d_src, count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SX_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(h_dst, ctx->h_pin, count * sizeof(uint32_t));
+    return 0;
+}
+
+void sx_prof_begin(sx_ctx *ctx, int kclass)
+{
+    sx_event_pair ep;
+    if (!ctx->ev_free.empty()) {
+        ep = ctx->ev_free.back();
+        ctx->ev_free.pop_back();
+    } else {
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
+    }
+    ep.kclass = kclass;
+    (void)hipEventRecord(ep.a, ctx->stream);
+    ctx->ev_used.push_back(ep);
+}
+
+void sx_prof_end(sx_ctx *ctx, int kclass, uint64_t alg_bytes)
+{
+    if (ctx->ev_used.empty()) return;
+    (void)hipEventRecord(ctx->ev_used.back().b, ctx->stream);
+    ctx->kstat[kclass].launches += 1;
+    ctx->kstat[kclass].alg_bytes += alg_bytes;
+}
+
+static void prof_drain(sx_ctx *ctx)
+{
+    if (ctx->ev_used.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (sx_event_pair &ep : ctx->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) ctx->kstat[ep.kclass].ms += ms;
+        ctx->ev_free.push_back(ep);
+    }
+    ctx->ev_used.clear();
+}
+
+extern "C" {
+
+int sx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sx_ctx_create(int device, sx_ctx **out)
+{
+    if (!out) return SX_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "stralg_amd: no usable HIP device (%s); this library has no CPU fallback\n",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return e != hipSuccess ? (int)e : SX_E_INTERNAL;
+    }
+    if (device < 0 || device >= ndev) return SX_E_ARG;
+    sx_ctx *ctx = new (std::nothrow) sx_ctx();
+    if (!ctx) return SX_E_NOMEM;
+    ctx->device = device;
+    memset(ctx->kstat, 0, sizeof ctx->kstat);
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_pin, 4096, hipHostMallocDefault) != hipSuccess) {
+        fprintf(stderr, "stralg_amd: cannot initialise device %d\n", device);
+        delete ctx;
+        return SX_E_INTERNAL;
+    }
+    *out = ctx;
+    return 0;
+}
+
+void sx_ctx_trim(sx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < SX_NSLABS; ++i) {
+        if (ctx->slab[i].p) (void)hipFree(ctx->slab[i].p);
+        ctx->slab[i].p = nullptr;
+        ctx->slab[i].cap = 0;
+    }
+}
+
+void sx_ctx_destroy(sx_ctx *ctx)
+{
+    if (!ctx) return;
+    sx_ctx_trim(ctx);
+    prof_drain(ctx);
+    for (sx_event_pair &ep : ctx->ev_free) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *sx_last_error(const sx_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+int sx_profile_enable(sx_ctx *ctx, int on)
+{
+    if (!ctx) return SX_E_ARG;
+    if (!on) prof_drain(ctx);
+    ctx->prof_on = on ? 1 : 0;
+    return 0;
+}
+
+int sx_profile_reset(sx_ctx *ctx)
+{
+    if (!ctx) return SX_E_ARG;
+    prof_drain(ctx);
+    memset(ctx->kstat, 0, sizeof ctx->kstat);
+    return 0;
+}
+
+int sx_profile_read(sx_ctx *ctx, sx_kernel_stat *out)
+{
+    if (!ctx || !out) return SX_E_ARG;
+    prof_drain(ctx);
+    memcpy(out, ctx->kstat, sizeof ctx->kstat);
+    return 0;
+}
+
+const char *sx_kernel_class_name(int kclass)
+{
+    return kclass >= 0 && kclass < SX_KC_COUNT ? kClassNames[kclass] : "?";
+}
+
+int sx_last_stats(const sx_ctx *ctx, sx_build_stats *out)
+{
+    if (!ctx || !out) return SX_E_ARG;
+    *out = ctx->stats;
+    return 0;
+}
+
+} // extern "C"

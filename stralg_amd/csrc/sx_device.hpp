@@ -1,0 +1,101 @@
+// sx_device.hpp -- wave64 / workgroup building blocks shared by the kernels.
+//
+// gfx950 wavefronts are 64 lanes wide; everything here is written for that
+// width (ballots are 64-bit, scans take 6 shuffle steps).  All collectives
+// must be reached by every lane of a wave: callers predicate, never branch
+// around them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sx {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256; // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+struct OpAdd {
+    __device__ __forceinline__ static uint32_t identity() { return 0u; }
+    __device__ __forceinline__ static uint32_t apply(uint32_t a, uint32_t b) { return a + b; }
+};
+struct OpMax {
+    __device__ __forceinline__ static uint32_t identity() { return 0u; }
+    __device__ __forceinline__ static uint32_t apply(uint32_t a, uint32_t b) { return a > b ? a : b; }
+};
+
+template <class Op> __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        uint32_t t = __shfl_up(v, (unsigned)d, kWave);
+        if (lane >= d) v = Op::apply(t, v);
+    }
+    return v;
+}
+
+// Exclusive scan over the kBlock threads of a workgroup.  `lds` needs
+// kWavesPerBlock entries; the function ends with a barrier so `lds` can be
+// reused by the caller straight away.
+template <class Op>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &total)
+{
+    const int lane = lane_id(), w = wave_id();
+    uint32_t inc = wave_inclusive_scan<Op>(v);
+    uint32_t prev = __shfl_up(inc, 1u, kWave);
+    uint32_t exc = lane == 0 ? Op::identity() : prev;
+    if (lane == kWave - 1) lds[w] = inc;
+    __syncthreads();
+    uint32_t base = Op::identity(), tot = Op::identity();
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) {
+        uint32_t x = lds[i];
+        if (i < w) base = Op::apply(base, x);
+        tot = Op::apply(tot, x);
+    }
+    __syncthreads();
+    total = tot;
+    return Op::apply(base, exc);
+}
+
+template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v, uint32_t *lds)
+{
+    uint32_t total;
+    (void)block_exclusive_scan<Op>(v, lds, total);
+    return total;
+}
+
+// Lanes of the wave holding the same BITS-bit digit (and valid) as this lane.
+template <int BITS> __device__ __forceinline__ uint64_t match_any(uint32_t digit, bool valid)
+{
+    uint64_t peers = __ballot(valid ? 1 : 0);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t m = __ballot(bit ? 1 : 0);
+        peers &= bit ? m : ~m;
+    }
+    return valid ? peers : 0ull;
+}
+
+// Stable ranking step shared by the radix scatter and the induce scatter:
+// items are presented wave by wave in (item k, lane) order; `counter` is this
+// wave's LDS counter row (one u32 per digit).  Returns the rank of the item
+// among the wave's items with the same digit seen so far.
+template <int BITS>
+__device__ __forceinline__ uint32_t wave_rank_step(uint32_t digit, bool valid, uint32_t *counter)
+{
+    const uint64_t peers = match_any<BITS>(digit, valid);
+    const uint32_t r = (uint32_t)__popcll(peers & lanemask_lt());
+    uint32_t old = 0;
+    if (valid && r == 0) old = atomicAdd(&counter[digit], (uint32_t)__popcll(peers));
+    const int leader = peers ? (__ffsll((unsigned long long)peers) - 1) : lane_id();
+    old = __shfl(old, leader, kWave);
+    return old + r;
+}
+
+} // namespace sx

@@ -1,0 +1,63 @@
+// sx_internal.hpp -- stage interfaces between the translation units.
+#pragma once
+#include "sx_common.hpp"
+
+// ---- sx_radix.hip
+int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
+                  int begin_bit, int end_bit, int *result_in_b);
+
+// ---- sx_classify.hip
+constexpr int kClsPerThread = 16;                     // text positions per thread
+constexpr int kClsTile = 256 * kClsPerThread;         // text positions per workgroup
+
+struct sx_text_info {
+    const uint8_t *T;   // device text: n symbols, T[n] == 0, zero padding to the tile end + 32
+    uint64_t n, N;      // N = n + 1 positions
+    uint32_t ntiles;    // classification tiles
+    uint16_t *lmsbits;  // one bit per position, 16 positions per entry
+    uint16_t *sampbits; // sample (LMS or cut) bits, same layout
+    uint32_t *tile_u32; // 5 * ntiles scratch: lms count, last lms(+1), prev lms(+1), sample count, sample offset
+    uint8_t *tile_first; // per tile: type of its first position (0 L, 1 S, 2 open)
+    uint32_t *d_hist;   // device: 3 * 256: all symbols, L-type symbols, LMS symbols
+    uint32_t *d_scalar; // device: a few u32 results (totals)
+    uint32_t h_all[256], h_l[256], h_lms[256];
+    uint32_t maxc;      // largest symbol present
+    uint64_t m;         // LMS positions incl. the sentinel
+    uint64_t M;         // samples
+};
+
+size_t sx_text_scratch_bytes(uint64_t n);
+// carve the per-text scratch out of `arena`, run classification, read the histograms back
+int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti);
+// sample flags for piece width W (symbols between consecutive samples <= W); sets ti.M
+int sx_sample_flags(sx_ctx *ctx, sx_text_info &ti, uint32_t W);
+// compaction of the sample positions; pos[M], is_lms[M]
+int sx_sample_write(sx_ctx *ctx, const sx_text_info &ti, uint32_t *pos, uint8_t *is_lms);
+int sx_piece_keys(sx_ctx *ctx, const sx_text_info &ti, const uint32_t *pos, const uint8_t *is_lms,
+                  uint32_t bits, uint32_t slots, uint32_t lenbits, uint64_t *keys, uint32_t *vals);
+
+// ---- sx_reduce.hip
+struct sx_reduce_bufs {
+    uint64_t *ka, *kb;      // M keys each
+    uint32_t *va, *vb;      // M values each
+    uint32_t *R;            // reduced string (names), M
+    uint32_t *rank;         // M
+    uint32_t *sa_r;         // suffix array of the reduced string, M
+    uint32_t *pos_a, *pos_b; // active positions, M each
+    uint32_t *gid;          // M
+    uint8_t *head_a, *head_b; // M each
+    uint32_t *d_scalar;     // >= 4 u32
+};
+// names from the sorted piece keys; n_names out.  keys/vals sorted in (ks, vs).
+int sx_name_pieces(sx_ctx *ctx, const uint64_t *ks, const uint32_t *vs, uint64_t M, sx_reduce_bufs &rb,
+                   uint64_t *n_names);
+// suffix array of R[0..M) (R[M-1] == 0 unique minimum) by prefix doubling -> rb.sa_r
+int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_bufs &rb);
+// sorted LMS suffix positions from the reduced suffix array
+int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms, uint64_t M,
+                  uint32_t *sorted_lms, uint32_t *d_total);
+
+// ---- sx_induce.hip
+size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);
+int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
+              uint32_t *SA, sx_arena &arena);

@@ -1,0 +1,167 @@
+// sx_radix.hip -- stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits a pass.
+//
+// Used for the LMS-substring piece sort (role of stralg/sa_is.c:295-336's
+// induced LMS-substring order; the pass structure is that of
+// stralg/skew.c:53-99: count, prefix sum, stable scatter) and for the
+// reduced-string suffix sort.
+//
+// Per pass, three launches:
+//   radix_hist     tile digit counts -> hist[digit][tile]           (reads keys)
+//   device_scan    exclusive sum over hist in digit-major order
+//   radix_scatter  wave-striped load, ballot-based stable ranking, tile
+//                  re-ordered in LDS so that each digit's run leaves the CU
+//                  as contiguous stores.
+// HBM-bound: 2 x (8 + 4) B per pair and pass for the scatter, 8 B for the
+// histogram read.  No MFMA (integer indexing).
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_scan.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+constexpr int kRadixItems = 8;
+constexpr int kRadixTile = kBlock * kRadixItems;
+
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
+                                                            int shift, uint32_t mask,
+                                                            uint32_t *__restrict__ hist, uint32_t ntiles)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kRadixTile;
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
+    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
+    uint32_t ntiles)
+{
+    __shared__ uint32_t wcount[kWavesPerBlock][256]; // per-wave digit counters, then wave bases
+    __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
+    __shared__ uint32_t goff[256];                   // global offset of the digit minus dbase
+    __shared__ uint32_t scan_lds[kWavesPerBlock];
+    __shared__ uint64_t skey[kRadixTile];
+    __shared__ uint32_t sval[kRadixTile];
+
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kRadixTile;
+    const uint64_t wave0 = tile0 + (uint64_t)w * (kWave * kRadixItems);
+    uint64_t key[kRadixItems];
+    uint32_t val[kRadixItems], rnk[kRadixItems];
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
+        const bool ok = i < n;
+        key[k] = ok ? kin[i] : ~0ull;
+        val[k] = ok ? vin[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
+        const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+        rnk[k] = wave_rank_step<8>(d, i < n, wcount[w]);
+    }
+    __syncthreads();
+    {
+        const int d = t; // kBlock == 256 digits
+        uint32_t s = 0;
+#pragma unroll
+        for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+            const uint32_t x = wcount[ww][d];
+            wcount[ww][d] = s;
+            s += x;
+        }
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan<OpAdd>(s, scan_lds, tot);
+        dbase[d] = ex;
+        goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+            const uint32_t pos = dbase[d] + wcount[w][d] + rnk[k];
+            skey[pos] = key[k];
+            sval[pos] = val[k];
+        }
+    }
+    __syncthreads();
+    const uint64_t left = n - tile0;
+    const uint32_t cnt = left < (uint64_t)kRadixTile ? (uint32_t)left : (uint32_t)kRadixTile;
+    for (uint32_t i = (uint32_t)t; i < cnt; i += kBlock) {
+        const uint64_t kk = skey[i];
+        const uint32_t d = (uint32_t)(kk >> shift) & mask;
+        const uint32_t dst = goff[d] + i;
+        kout[dst] = kk;
+        vout[dst] = sval[i];
+    }
+}
+
+} // namespace sx
+
+using namespace sx;
+
+int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
+                  int begin_bit, int end_bit, int *result_in_b)
+{
+    *result_in_b = 0;
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
+    const uint32_t ntiles = sx_div_up(n, kRadixTile);
+    const uint64_t hist_n = (uint64_t)256 * ntiles;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, hist_n * sizeof(uint32_t)));
+    uint32_t *hist = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
+    uint64_t *kin = ka, *kout = kb;
+    uint32_t *vin = va, *vout = vb;
+    int flips = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+        const uint32_t mask = (1u << bits) - 1u;
+        sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kBlock),
+                  (const uint64_t *)kin, n, shift, mask, hist, ntiles);
+        SX_TRY((device_scan<OpAdd>(ctx, hist_n, InU32{hist}, OutExclusive{hist}, nullptr, SX_KC_SCAN,
+                                   hist_n * 12)));
+        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(ntiles), dim3(kBlock),
+                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask,
+                  (const uint32_t *)hist, ntiles);
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+        ++flips;
+        ctx->stats.sort_passes++;
+    }
+    *result_in_b = flips & 1;
+    return 0;
+}
+
+extern "C" int sx_prim_sort_pairs_dev(sx_ctx *ctx, uint64_t *d_keys_a, uint32_t *d_vals_a, uint64_t *d_keys_b,
+                                      uint32_t *d_vals_b, uint64_t n, int begin_bit, int end_bit,
+                                      int *result_in_b)
+{
+    if (!ctx || !result_in_b || begin_bit < 0 || end_bit > 64) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(sx_sort_pairs(ctx, d_keys_a, d_vals_a, d_keys_b, d_vals_b, n, begin_bit, end_bit, result_in_b));
+    return sx_sync(ctx);
+}
+
+extern "C" int sx_prim_exclusive_sum_dev(sx_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
+                                         uint32_t *d_total)
+{
+    if (!ctx) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY((device_scan<OpAdd>(ctx, n, InU32{d_in}, OutExclusive{d_out}, d_total)));
+    return sx_sync(ctx);
+}
