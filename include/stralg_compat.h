@@ -1,0 +1,105 @@
+/*
+ * stralg_compat.h -- the reference-named entry points of the suffix-array /
+ * BWT-table construction path, exported by libstralg_amd.so with the exact
+ * signatures and struct layouts of mailund/stralg, so that the library can
+ * replace the reference's translation units for this path at link time
+ * (the reference has no plugin registry; its boundary is symbol replacement
+ * in libstralg, stralg/CMakeLists.txt:2-32 -- see INTEGRATION.md).
+ *
+ * Each declaration cites the reference declaration it replaces.
+ * Ownership and error behaviour follow the reference: arrays handed back are
+ * malloc/calloc memory that callers release with free(); sa->string is
+ * borrowed; constructors never return NULL (on a device error they print the
+ * reason to stderr and abort() -- there is no CPU fallback).
+ */
+#ifndef STRALG_COMPAT_H
+#define STRALG_COMPAT_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* stralg/suffix_array.h:10-20 (40 bytes on LP64) */
+struct suffix_array {
+    uint8_t *string;   /* borrowed, NUL-terminated */
+    uint32_t length;   /* strlen + 1 */
+    uint32_t *array;   /* length entries, malloc'd */
+    uint32_t *inverse; /* NULL after construction */
+    uint32_t *lcp;     /* NULL after construction */
+};
+
+/* stralg/remap.h:9-19 (388 bytes) */
+struct remap_table {
+    uint32_t alphabet_size;
+    signed char table[256];
+    signed char rev_table[128];
+};
+
+/* stralg/bwt.h:36-44 (56 bytes) */
+struct bwt_table {
+    struct remap_table *remap_table;
+    struct suffix_array *sa;
+    uint32_t *c_table;
+    uint32_t *o_table;     /* position-major: o_table[i * sigma + a] (bwt.c:50-57) */
+    uint32_t **o_indices;  /* o_indices[i] = o_table + sigma * i */
+    uint32_t *ro_table;
+    uint32_t **ro_indices;
+};
+
+/* stralg/suffix_array_internal.h:10 */
+struct suffix_array *allocate_sa_(uint8_t *string);
+
+/* stralg/suffix_array.h:31-35 (sa_is.c:466-509) */
+struct suffix_array *sa_is_construction(uint8_t *remapped_string, uint32_t alphabet_size);
+/* stralg/suffix_array.h:37-41 (sa_is_mem.c:471-494): same array, same device path */
+struct suffix_array *sa_is_mem_construction(uint8_t *remapped_string, uint32_t alphabet_size);
+/* stralg/suffix_array.h:26-29 (skew.c:388-395): any bytes 1..255, not remapped */
+struct suffix_array *skew_sa_construction(uint8_t *string);
+/* stralg/suffix_array.h:43-51 (suffix_array.c:12-24) */
+void free_suffix_array(struct suffix_array *sa);
+void free_complete_suffix_array(struct suffix_array *sa);
+
+/* stralg/remap.h:21-33,43-47,80-86 (remap.c:8-114,155-165) */
+struct remap_table *alloc_remap_table(const uint8_t *string);
+void init_remap_table(struct remap_table *table, const uint8_t *string);
+void dealloc_remap_table(struct remap_table *table);
+void free_remap_table(struct remap_table *table);
+uint8_t *remap(uint8_t *output, const uint8_t *input, struct remap_table *table);
+uint8_t *remap_between(uint8_t *output, const uint8_t *from, const uint8_t *to, struct remap_table *table);
+uint8_t *remap_between0(uint8_t *output, const uint8_t *from, const uint8_t *to, struct remap_table *table);
+uint32_t remap_string(uint8_t *output, uint8_t *input);
+
+/* stralg/bwt.h:73-76 (bwt.c:22-89) */
+void init_bwt_table(struct bwt_table *bwt_table, struct suffix_array *sa, struct suffix_array *rsa,
+                    struct remap_table *remap_table);
+/* stralg/bwt.h:98-100 (bwt.c:109-118) */
+struct bwt_table *alloc_bwt_table(struct suffix_array *sa, struct suffix_array *rsa,
+                                  struct remap_table *remap_table);
+/* stralg/bwt.h:110-139 (bwt.c:91-132) */
+void dealloc_bwt_table(struct bwt_table *bwt_table);
+void free_bwt_table(struct bwt_table *bwt_table);
+void completely_dealloc_bwt_table(struct bwt_table *bwt_table);
+void completely_free_bwt_table(struct bwt_table *bwt_table);
+/* stralg/bwt.h:156-160 (bwt.c:134-161) */
+struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse);
+
+/* ---- additions (not in the reference) --------------------------------------- */
+/* GPU used by the calling thread's constructors (default: $STRALG_AMD_DEVICE or 0).
+ * One context per host thread, so N threads can farm records over N GPUs
+ * (tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62 is the per-record loop). */
+int stralg_amd_set_device(int device);
+/* release the calling thread's context and its cached device memory */
+void stralg_amd_release(void);
+/* Build tables for `count` independent strings, string k on devices[k % n_devices],
+ * one host thread per device; out[k] receives build_complete_table(strings[k], ...). */
+int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
+                                  const int *devices, int n_devices, struct bwt_table **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

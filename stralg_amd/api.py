@@ -1,0 +1,259 @@
+"""Host-side mirror of stralg's interface for the suffix-array / BWT-table path.
+
+Names, argument meaning and results follow the reference declarations cited on
+each function; arrays come back as numpy arrays instead of malloc'd pointers.
+All work happens in libstralg_amd.so (include/stralg_amd.h); a missing library
+or GPU raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+
+
+class StralgAmdError(RuntimeError):
+    pass
+
+
+def _ptr(x):
+    """Raw address of a numpy array, a torch tensor, an int address or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError(f"cannot take the address of {type(x)!r}")
+
+
+class Context:
+    """One device context (sx_ctx): a HIP stream plus cached workspace on one GPU."""
+
+    def __init__(self, device=0, lib_path=None):
+        self.lib = _lib.load(lib_path)
+        self.device = device
+        h = C.c_void_p()
+        rc = self.lib.sx_ctx_create(device, C.byref(h))
+        if rc != 0 or not h:
+            raise StralgAmdError(
+                f"sx_ctx_create(device={device}) failed with code {rc}: no usable GPU "
+                "(stralg_amd has no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.sx_last_error(self.h)
+            raise StralgAmdError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+    # ---- host-buffer entry points ------------------------------------------------
+    def sa_build(self, text, alphabet_size):
+        """sx_sa_build: text = uint8 symbols in [1, alphabet_size) without terminator."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        out = np.empty(text.size + 1, dtype=np.uint32)
+        self._check(self.lib.sx_sa_build(self.h, _ptr(text), text.size, alphabet_size, _ptr(out)), "sx_sa_build")
+        return out
+
+    def bwt_tables(self, text, sa, sigma, want_o=True):
+        """sx_bwt_tables: returns (c_table[sigma], o_table[(N+1), sigma] or None)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        sa = np.ascontiguousarray(sa, dtype=np.uint32)
+        N = sa.size
+        if text.size != N - 1:
+            raise ValueError("sa must have len(text) + 1 entries")
+        c = np.zeros(sigma, dtype=np.uint32)
+        o = np.empty((N + 1, sigma), dtype=np.uint32) if want_o else None
+        self._check(self.lib.sx_bwt_tables(self.h, _ptr(text), _ptr(sa), N, sigma, _ptr(c), _ptr(o)), "sx_bwt_tables")
+        return c, o
+
+    # ---- device-buffer entry points (torch tensors or raw addresses) --------------
+    def sa_build_dev(self, d_text, n, alphabet_size, d_sa_out):
+        self._check(self.lib.sx_sa_build_dev(self.h, _ptr(d_text), n, alphabet_size, _ptr(d_sa_out)), "sx_sa_build_dev")
+
+    def bwt_tables_dev(self, d_text, d_sa, N, sigma, d_c_out, d_o_out=None, d_bwt_out=None):
+        self._check(self.lib.sx_bwt_tables_dev(self.h, _ptr(d_text), _ptr(d_sa), N, sigma, _ptr(d_c_out),
+                                               _ptr(d_o_out), _ptr(d_bwt_out)), "sx_bwt_tables_dev")
+
+    def synth_dev(self, d_out, n, sigma, seed):
+        self._check(self.lib.sx_synth_dev(self.h, _ptr(d_out), n, sigma, seed), "sx_synth_dev")
+
+    # ---- primitives (kernel-level tests) ------------------------------------------
+    def prim_sort_pairs_dev(self, ka, va, kb, vb, n, begin_bit, end_bit):
+        flag = C.c_int(0)
+        self._check(self.lib.sx_prim_sort_pairs_dev(self.h, _ptr(ka), _ptr(va), _ptr(kb), _ptr(vb), n, begin_bit,
+                                                    end_bit, C.byref(flag)), "sx_prim_sort_pairs_dev")
+        return bool(flag.value)
+
+    def prim_exclusive_sum_dev(self, d_in, d_out, n, d_total=None):
+        self._check(self.lib.sx_prim_exclusive_sum_dev(self.h, _ptr(d_in), _ptr(d_out), n, _ptr(d_total)),
+                    "sx_prim_exclusive_sum_dev")
+
+    def prim_classify_dev(self, d_text, n, d_flags, d_hist_all, d_hist_l, d_hist_lms):
+        self._check(self.lib.sx_prim_classify_dev(self.h, _ptr(d_text), n, _ptr(d_flags), _ptr(d_hist_all),
+                                                  _ptr(d_hist_l), _ptr(d_hist_lms)), "sx_prim_classify_dev")
+
+    # ---- measurement -----------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.sx_profile_enable(self.h, 1 if on else 0), "sx_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.sx_profile_reset(self.h), "sx_profile_reset")
+
+    def profile_read(self):
+        arr = (_lib.KernelStat * len(_lib.KC_NAMES))()
+        self._check(self.lib.sx_profile_read(self.h, arr), "sx_profile_read")
+        return {name: {"launches": int(arr[i].launches), "ms": float(arr[i].ms), "alg_bytes": int(arr[i].alg_bytes)}
+                for i, name in enumerate(_lib.KC_NAMES)}
+
+    def last_stats(self):
+        st = _lib.BuildStats()
+        self._check(self.lib.sx_last_stats(self.h, C.byref(st)), "sx_last_stats")
+        return st.as_dict()
+
+    def trim(self):
+        self.lib.sx_ctx_trim(self.h)
+
+
+_tls = threading.local()
+
+
+def default_context(device=None):
+    """The calling thread's context (created on first use, like the C host layer's)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None or (device is not None and ctx.device != device):
+        ctx = Context(device or 0)
+        _tls.ctx = ctx
+    return ctx
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped results
+# ---------------------------------------------------------------------------
+
+class SuffixArray:
+    """stralg/suffix_array.h:10-20: string (borrowed, with terminator), length, array."""
+
+    def __init__(self, string, array):
+        self.string = string
+        self.length = int(array.size)
+        self.array = array
+        self.inverse = None
+        self.lcp = None
+
+
+class RemapTable:
+    """stralg/remap.h:9-19."""
+
+    def __init__(self, alphabet_size, table, rev_table):
+        self.alphabet_size = alphabet_size
+        self.table = table
+        self.rev_table = rev_table
+
+
+class BwtTable:
+    """stralg/bwt.h:36-44; o_table / ro_table are (N+1, sigma) arrays: O(a, i) = o_table[i, a]."""
+
+    def __init__(self, remap_table, sa, c_table, o_table, ro_table):
+        self.remap_table = remap_table
+        self.sa = sa
+        self.c_table = c_table
+        self.o_table = o_table
+        self.ro_table = ro_table
+
+
+def _symbols(x):
+    """bytes-like or array without terminator -> uint8 array; stops at the first 0 like strlen."""
+    a = np.frombuffer(bytes(x), dtype=np.uint8) if isinstance(x, (bytes, bytearray, memoryview)) else np.asarray(x, dtype=np.uint8)
+    zero = np.flatnonzero(a == 0)
+    return a[: zero[0]] if zero.size else a
+
+
+def _with_terminator(a):
+    out = np.zeros(a.size + 1, dtype=np.uint8)
+    out[: a.size] = a
+    return out
+
+
+def sa_is_construction(remapped_string, alphabet_size, ctx=None):
+    """stralg/suffix_array.h:31-35 (sa_is.c:466-509)."""
+    ctx = ctx or default_context()
+    text = _symbols(remapped_string)
+    return SuffixArray(_with_terminator(text), ctx.sa_build(text, alphabet_size))
+
+
+def sa_is_mem_construction(remapped_string, alphabet_size, ctx=None):
+    """stralg/suffix_array.h:37-41 (sa_is_mem.c:471-494): same array, same device path."""
+    return sa_is_construction(remapped_string, alphabet_size, ctx)
+
+
+def skew_sa_construction(string, ctx=None):
+    """stralg/suffix_array.h:26-29 (skew.c:388-395): raw bytes 1..255, alphabet fixed at 256."""
+    return sa_is_construction(string, 256, ctx)
+
+
+def alloc_remap_table(string):
+    """stralg/remap.c:8-41: order-preserving dense codes, 0 reserved for the sentinel."""
+    s = _symbols(string)
+    present = np.zeros(256, dtype=bool)
+    present[s] = True
+    present[0] = False
+    table = np.full(256, -1, dtype=np.int16)
+    rev = np.full(128, -1, dtype=np.int16)
+    table[0] = 0
+    rev[0] = 0
+    letters = np.flatnonzero(present)
+    if letters.size > 127:
+        raise StralgAmdError("more than 127 distinct letters: stralg's remap table cannot hold them (remap.h:14-18)")
+    table[letters] = np.arange(1, letters.size + 1)
+    rev[1: letters.size + 1] = letters
+    return RemapTable(int(letters.size + 1), table, rev)
+
+
+def remap(string, table):
+    """stralg/remap.c:102-114; raises where the reference returns NULL (letter not in the table)."""
+    s = _symbols(string)
+    out = table.table[s]
+    if (out < 0).any():
+        raise StralgAmdError("remap: the string holds a letter that is not in the table")
+    return out.astype(np.uint8)
+
+
+def remap_string(string):
+    """stralg/remap.c:155-165: returns (remapped symbols, alphabet_size)."""
+    t = alloc_remap_table(string)
+    return remap(string, t), t.alphabet_size
+
+
+def init_bwt_table(sa, rsa, remap_table, ctx=None):
+    """stralg/bwt.h:73-76 (bwt.c:22-89): C, O and (when rsa is given) RO tables."""
+    ctx = ctx or default_context()
+    sigma = remap_table.alphabet_size
+    c, o = ctx.bwt_tables(sa.string[:-1], sa.array, sigma)
+    ro = None
+    if rsa is not None:
+        _, ro = ctx.bwt_tables(rsa.string[:-1], rsa.array, sigma)
+    return BwtTable(remap_table, sa, c, o, ro)
+
+
+def build_complete_table(string, include_reverse=True, ctx=None):
+    """stralg/bwt.h:156-160 (bwt.c:134-161): remap -> SA-IS -> [reverse, SA-IS] -> tables."""
+    ctx = ctx or default_context()
+    table = alloc_remap_table(string)
+    remapped = remap(string, table)
+    sa = sa_is_construction(remapped, table.alphabet_size, ctx)
+    rsa = sa_is_construction(remapped[::-1].copy(), table.alphabet_size, ctx) if include_reverse else None
+    return init_bwt_table(sa, rsa, table, ctx)

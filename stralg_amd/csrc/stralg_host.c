@@ -1,0 +1,317 @@
+/*
+ * stralg_host.c -- host side of the drop-in: stralg's own entry points for the
+ * suffix-array / BWT-table construction path (include/stralg_compat.h), in C,
+ * on top of the C-ABI shim (include/stralg_amd.h).  Plain host glue only:
+ * allocation with malloc/calloc (callers free() these arrays), the byte remap,
+ * string reversal and the o_indices pointer tables stay on the CPU, exactly
+ * the parts SURVEY.md section 2 marks as host glue.
+ */
+#include "stralg_compat.h"
+#include "stralg_amd.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- per-thread device context --------------------------------------------- */
+
+static __thread sx_ctx *tls_ctx = NULL;
+static __thread int tls_device = -1;
+
+static void die(const char *what, int rc, const sx_ctx *ctx)
+{
+    fprintf(stderr, "stralg_amd: %s failed (code %d): %s\n", what, rc, ctx ? sx_last_error(ctx) : "");
+    fprintf(stderr, "stralg_amd: the reference entry points cannot report errors and there is no CPU "
+                    "fallback; aborting\n");
+    abort();
+}
+
+static sx_ctx *thread_ctx(void)
+{
+    if (tls_ctx) return tls_ctx;
+    if (tls_device < 0) {
+        const char *env = getenv("STRALG_AMD_DEVICE");
+        tls_device = env ? atoi(env) : 0;
+    }
+    int rc = sx_ctx_create(tls_device, &tls_ctx);
+    if (rc != 0) die("sx_ctx_create", rc, NULL);
+    return tls_ctx;
+}
+
+int stralg_amd_set_device(int device)
+{
+    if (device < 0 || device >= sx_device_count()) return -1;
+    if (tls_ctx && tls_device != device) {
+        sx_ctx_destroy(tls_ctx);
+        tls_ctx = NULL;
+    }
+    tls_device = device;
+    return 0;
+}
+
+void stralg_amd_release(void)
+{
+    if (tls_ctx) sx_ctx_destroy(tls_ctx);
+    tls_ctx = NULL;
+}
+
+/* ---- suffix arrays (stralg/suffix_array_internal.c:7-19, suffix_array.c:12-24) ---- */
+
+struct suffix_array *allocate_sa_(uint8_t *string)
+{
+    struct suffix_array *sa = malloc(sizeof *sa);
+    size_t len = strlen((const char *)string) + 1;
+    sa->string = string;
+    sa->length = (uint32_t)len;
+    sa->array = malloc(len * sizeof *sa->array);
+    sa->inverse = NULL;
+    sa->lcp = NULL;
+    return sa;
+}
+
+static struct suffix_array *construct_on_device(uint8_t *string, uint32_t alphabet_size, const char *who)
+{
+    struct suffix_array *sa = allocate_sa_(string);
+    sx_ctx *ctx = thread_ctx();
+    int rc = sx_sa_build(ctx, string, (uint64_t)sa->length - 1, alphabet_size, sa->array);
+    if (rc != 0) die(who, rc, ctx);
+    return sa;
+}
+
+struct suffix_array *sa_is_construction(uint8_t *remapped_string, uint32_t alphabet_size)
+{
+    return construct_on_device(remapped_string, alphabet_size, "sa_is_construction");
+}
+
+struct suffix_array *sa_is_mem_construction(uint8_t *remapped_string, uint32_t alphabet_size)
+{
+    return construct_on_device(remapped_string, alphabet_size, "sa_is_mem_construction");
+}
+
+struct suffix_array *skew_sa_construction(uint8_t *string)
+{
+    /* skew.c:375 works on raw bytes with a fixed alphabet of 256 */
+    return construct_on_device(string, 256, "skew_sa_construction");
+}
+
+void free_suffix_array(struct suffix_array *sa)
+{
+    free(sa->array);
+    free(sa->inverse);
+    free(sa->lcp);
+    free(sa);
+}
+
+void free_complete_suffix_array(struct suffix_array *sa)
+{
+    free(sa->string);
+    free_suffix_array(sa);
+}
+
+/* ---- remap (stralg/remap.c:8-114,155-165) ----------------------------------------- */
+
+void init_remap_table(struct remap_table *table, const uint8_t *string)
+{
+    bool present[256] = {false};
+    for (const uint8_t *p = string; *p; ++p) present[*p] = true;
+    memset(table->table, -1, sizeof table->table);
+    memset(table->rev_table, -1, sizeof table->rev_table);
+    table->table[0] = 0; /* the sentinel maps to itself */
+    table->rev_table[0] = 0;
+    uint32_t next = 1;
+    for (int c = 1; c < 256; ++c) {
+        if (!present[c]) continue;
+        /* more than 127 letters do not fit signed char codes (remap.h:14-18) */
+        table->table[c] = (signed char)next;
+        if (next < 128) table->rev_table[next] = (signed char)c;
+        ++next;
+    }
+    table->alphabet_size = next;
+}
+
+struct remap_table *alloc_remap_table(const uint8_t *string)
+{
+    struct remap_table *table = malloc(sizeof *table);
+    init_remap_table(table, string);
+    return table;
+}
+
+void dealloc_remap_table(struct remap_table *table) { (void)table; }
+
+void free_remap_table(struct remap_table *table) { free(table); }
+
+uint8_t *remap_between(uint8_t *output, const uint8_t *from, const uint8_t *to, struct remap_table *table)
+{
+    for (; from != to; ++from, ++output) {
+        signed char code = table->table[*from];
+        *output = (uint8_t)code;
+        if (code < 0) return NULL; /* letter not in the table */
+    }
+    return output;
+}
+
+uint8_t *remap_between0(uint8_t *output, const uint8_t *from, const uint8_t *to, struct remap_table *table)
+{
+    uint8_t *end = remap_between(output, from, to, table);
+    if (!end) return NULL;
+    *end = 0;
+    return end + 1;
+}
+
+uint8_t *remap(uint8_t *output, const uint8_t *input, struct remap_table *table)
+{
+    /* the terminator is mapped too (0 -> 0), as in remap.c:102-114 */
+    return remap_between(output, input, input + strlen((const char *)input) + 1, table);
+}
+
+uint32_t remap_string(uint8_t *output, uint8_t *input)
+{
+    struct remap_table table;
+    init_remap_table(&table, input);
+    remap(output, input, &table);
+    return table.alphabet_size;
+}
+
+/* ---- BWT tables (stralg/bwt.c:22-161) ------------------------------------------------ */
+
+static uint32_t **row_pointers(uint32_t *table, size_t rows, uint32_t sigma)
+{
+    uint32_t **idx = malloc(rows * sizeof *idx);
+    for (size_t i = 0; i < rows; ++i) idx[i] = table + (size_t)sigma * i;
+    return idx;
+}
+
+void init_bwt_table(struct bwt_table *bwt_table, struct suffix_array *sa, struct suffix_array *rsa,
+                    struct remap_table *remap_table)
+{
+    const uint32_t sigma = remap_table->alphabet_size;
+    const size_t N = sa->length;
+    /* size_t, unlike bwt.c:50-51 whose uint32_t o_size wraps beyond ~204.8 Mi symbols */
+    const size_t o_words = (size_t)sigma * (N + 1);
+    sx_ctx *ctx = thread_ctx();
+
+    bwt_table->remap_table = remap_table;
+    bwt_table->sa = sa;
+    bwt_table->c_table = calloc(sigma, sizeof *bwt_table->c_table);
+    bwt_table->o_table = malloc(o_words * sizeof *bwt_table->o_table);
+    int rc = sx_bwt_tables(ctx, sa->string, sa->array, N, sigma, bwt_table->c_table, bwt_table->o_table);
+    if (rc != 0) die("init_bwt_table", rc, ctx);
+    bwt_table->o_indices = row_pointers(bwt_table->o_table, N + 1, sigma);
+
+    if (rsa) {
+        uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
+        bwt_table->ro_table = malloc(o_words * sizeof *bwt_table->ro_table);
+        rc = sx_bwt_tables(ctx, rsa->string, rsa->array, rsa->length, sigma, c_tmp, bwt_table->ro_table);
+        if (rc != 0) die("init_bwt_table (reverse)", rc, ctx);
+        free(c_tmp);
+        bwt_table->ro_indices = row_pointers(bwt_table->ro_table, N + 1, sigma);
+    } else {
+        bwt_table->ro_table = NULL;
+        bwt_table->ro_indices = NULL;
+    }
+}
+
+struct bwt_table *alloc_bwt_table(struct suffix_array *sa, struct suffix_array *rsa,
+                                  struct remap_table *remap_table)
+{
+    struct bwt_table *table = malloc(sizeof *table);
+    init_bwt_table(table, sa, rsa, remap_table);
+    return table;
+}
+
+void dealloc_bwt_table(struct bwt_table *bwt_table)
+{
+    free(bwt_table->c_table);
+    free(bwt_table->o_table);
+    free(bwt_table->o_indices);
+    free(bwt_table->ro_table);
+    free(bwt_table->ro_indices);
+}
+
+void free_bwt_table(struct bwt_table *bwt_table)
+{
+    dealloc_bwt_table(bwt_table);
+    free(bwt_table);
+}
+
+void completely_dealloc_bwt_table(struct bwt_table *bwt_table)
+{
+    free_complete_suffix_array(bwt_table->sa);
+    free_remap_table(bwt_table->remap_table);
+    dealloc_bwt_table(bwt_table);
+}
+
+void completely_free_bwt_table(struct bwt_table *bwt_table)
+{
+    completely_dealloc_bwt_table(bwt_table);
+    free(bwt_table);
+}
+
+struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse)
+{
+    const size_t n = strlen((const char *)string);
+    struct remap_table *remap_table = alloc_remap_table(string);
+    if (remap_table->alphabet_size > 128) {
+        fprintf(stderr, "stralg_amd: build_complete_table: %u distinct letters; stralg's remap table holds "
+                        "at most 127 (stralg/remap.h:14-18)\n", remap_table->alphabet_size - 1);
+        abort();
+    }
+    uint8_t *remapped = malloc(n + 1);
+    remap(remapped, string, remap_table);
+    /* ownership of `remapped` moves into sa->string (bwt.c:139-143) */
+    struct suffix_array *sa = sa_is_construction(remapped, remap_table->alphabet_size);
+
+    struct suffix_array *rsa = NULL;
+    if (include_reverse) {
+        uint8_t *rev = malloc(n + 1);
+        for (size_t i = 0; i < n; ++i) rev[i] = remapped[n - 1 - i];
+        rev[n] = 0;
+        rsa = sa_is_construction(rev, remap_table->alphabet_size);
+    }
+    struct bwt_table *table = malloc(sizeof *table);
+    init_bwt_table(table, sa, rsa, remap_table);
+    if (rsa) free_complete_suffix_array(rsa); /* bwt.c:158: rsa and the reversed copy are temporary */
+    return table;
+}
+
+/* ---- batch farm: independent records, one host thread per GPU ------------------------ */
+
+struct farm_job {
+    const uint8_t *const *strings;
+    struct bwt_table **out;
+    size_t count;
+    bool include_reverse;
+    int device, lane, lanes;
+};
+
+static void *farm_worker(void *arg)
+{
+    struct farm_job *job = arg;
+    stralg_amd_set_device(job->device);
+    for (size_t k = (size_t)job->lane; k < job->count; k += (size_t)job->lanes)
+        job->out[k] = build_complete_table(job->strings[k], job->include_reverse);
+    stralg_amd_release();
+    return NULL;
+}
+
+int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
+                                  const int *devices, int n_devices, struct bwt_table **out)
+{
+    if (!strings || !out || n_devices <= 0 || !devices) return -1;
+    pthread_t *threads = malloc((size_t)n_devices * sizeof *threads);
+    struct farm_job *jobs = malloc((size_t)n_devices * sizeof *jobs);
+    if (!threads || !jobs) {
+        free(threads);
+        free(jobs);
+        return -2;
+    }
+    for (int d = 0; d < n_devices; ++d) {
+        jobs[d] = (struct farm_job){strings, out, count, include_reverse, devices[d], d, n_devices};
+        pthread_create(&threads[d], NULL, farm_worker, &jobs[d]);
+    }
+    for (int d = 0; d < n_devices; ++d) pthread_join(threads[d], NULL);
+    free(jobs);
+    free(threads);
+    return 0;
+}

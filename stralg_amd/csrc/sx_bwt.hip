@@ -1,0 +1,235 @@
+// sx_bwt.hip -- BWT symbols, C table and O table (stralg/bwt.c:13-65).
+//
+//   bwt[i]  = SA[i] == 0 ? 0 : text[SA[i] - 1]                 bwt.c:13-20
+//   C[a]    = #{symbols of text + sentinel that are < a}        bwt.c:35-45
+//   O(a, i) = #{k < i : bwt[k] == a},  i = 0 .. N               bwt.c:47-65
+//             stored position-major: o[i * sigma + a]           bwt.c:50-57
+//
+// The reference loops letter-outer / position-inner (sigma strided sweeps and
+// sigma gathers of every bwt symbol).  Here each bwt symbol is gathered once
+// (the only random access), tiles of rows get their starting counts from a
+// per-symbol prefix over tile histograms, and every tile of O rows is
+// assembled in LDS and leaves the CU as contiguous stores: the kernel is
+// bound by the 4*sigma output bytes per position.
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+constexpr int kSmallSigma = 8;      // register-vector O kernel for sigma <= 8
+constexpr int kSmallRowsPerThread = 4;
+constexpr int kSmallTile = kBlock * kSmallRowsPerThread; // 1024 rows, 32 KiB of LDS at sigma 8
+constexpr int kWideTile = 64;       // rows per workgroup of the wide-alphabet O kernel
+constexpr int kMaxSigmaO = 128;     // stralg/remap.h:14-18
+
+// bwt symbols + per-tile symbol counts.  tile_rows rows per workgroup; row N
+// (the last O row) has no symbol of its own.
+__global__ __launch_bounds__(kBlock) void bwt_gather_kernel(const uint8_t *__restrict__ T,
+                                                            const uint32_t *__restrict__ SA, uint64_t N,
+                                                            uint32_t tile_rows, uint32_t sigma,
+                                                            uint8_t *__restrict__ bwt,
+                                                            uint32_t *__restrict__ tilehist, uint32_t ntiles)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t tile0 = (uint64_t)blockIdx.x * tile_rows;
+    for (uint32_t r = threadIdx.x; r < tile_rows; r += kBlock) {
+        const uint64_t i = tile0 + r;
+        if (i < N) {
+            const uint32_t p = SA[i];
+            // an entry outside [0, n] (a malformed sa) must not fault: count it as symbol 255
+            const uint32_t b = p == 0 ? 0u : ((uint64_t)p < N ? (uint32_t)T[p - 1u] : 255u);
+            bwt[i] = (uint8_t)b;
+            atomicAdd(&h[b], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// per symbol: exclusive prefix of the tile counts (in place) and the symbol total
+__global__ __launch_bounds__(kBlock) void bwt_offsets_kernel(uint32_t *__restrict__ tilehist, uint32_t ntiles,
+                                                             uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const uint32_t tot = block_scan_row_inplace(tilehist + (uint64_t)blockIdx.x * ntiles, ntiles, lds);
+    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+__global__ void c_table_kernel(const uint32_t *__restrict__ totals, uint32_t sigma, uint32_t *__restrict__ c_out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t a = 0; a < sigma; ++a) {
+            c_out[a] = acc;
+            acc += totals[a];
+        }
+    }
+}
+
+// O rows for sigma <= 8: every thread owns 4 consecutive rows and keeps the
+// running counts of all symbols in registers.
+template <int SIG>
+__global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
+                                                              uint32_t sigma,
+                                                              const uint32_t *__restrict__ tilepre,
+                                                              uint32_t ntiles, uint32_t *__restrict__ o_out)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    __shared__ uint32_t rows[kSmallTile * SIG];
+    const int t = (int)threadIdx.x;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kSmallTile;
+    const uint64_t r0 = tile0 + (uint64_t)t * kSmallRowsPerThread;
+    uint32_t sym[kSmallRowsPerThread];
+    uint32_t cnt[SIG];
+#pragma unroll
+    for (int a = 0; a < SIG; ++a) cnt[a] = 0;
+#pragma unroll
+    for (int k = 0; k < kSmallRowsPerThread; ++k) {
+        const uint64_t i = r0 + k;
+        sym[k] = i < N ? (uint32_t)bwt[i] : 0xFFu;
+#pragma unroll
+        for (int a = 0; a < SIG; ++a) cnt[a] += sym[k] == (uint32_t)a ? 1u : 0u;
+    }
+    uint32_t run[SIG];
+#pragma unroll
+    for (int a = 0; a < SIG; ++a) {
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan<OpAdd>(cnt[a], lds, tot);
+        run[a] = ex + ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallRowsPerThread; ++k) {
+        const uint32_t lr = (uint32_t)t * kSmallRowsPerThread + k;
+#pragma unroll
+        for (int a = 0; a < SIG; ++a) {
+            if ((uint32_t)a < sigma) rows[lr * sigma + a] = run[a];
+            run[a] += sym[k] == (uint32_t)a ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    // rows tile0 .. min(tile0 + tile, N + 1) leave as one contiguous block
+    const uint64_t rows_left = N + 1 - tile0;
+    const uint32_t nrows = rows_left < (uint64_t)kSmallTile ? (uint32_t)rows_left : (uint32_t)kSmallTile;
+    const uint32_t nwords = nrows * sigma;
+    uint32_t *dst = o_out + tile0 * sigma;
+    for (uint32_t i = (uint32_t)t; i < nwords; i += kBlock) dst[i] = rows[i];
+}
+
+// O rows for 8 < sigma <= 128: 64 rows per workgroup; symbols mark a +1 in the
+// row after them, one thread per symbol column then accumulates down the rows.
+__global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
+                                                             uint32_t sigma,
+                                                             const uint32_t *__restrict__ tilepre,
+                                                             uint32_t ntiles, uint32_t *__restrict__ o_out)
+{
+    __shared__ uint32_t rows[kWideTile * kMaxSigmaO];
+    const int t = (int)threadIdx.x;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kWideTile;
+    for (uint32_t i = (uint32_t)t; i < (uint32_t)kWideTile * sigma; i += kBlock) rows[i] = 0;
+    __syncthreads();
+    if (t + 1 < kWideTile) {
+        const uint64_t i = tile0 + t;
+        if (i < N) rows[(uint32_t)(t + 1) * sigma + bwt[i]] = 1; // one writer per row
+    }
+    __syncthreads();
+    if ((uint32_t)t < sigma) {
+        uint32_t run = tilepre[(uint64_t)t * ntiles + blockIdx.x];
+        for (int r = 0; r < kWideTile; ++r) {
+            run += rows[(uint32_t)r * sigma + t];
+            rows[(uint32_t)r * sigma + t] = run;
+        }
+    }
+    __syncthreads();
+    const uint64_t rows_left = N + 1 - tile0;
+    const uint32_t nrows = rows_left < (uint64_t)kWideTile ? (uint32_t)rows_left : (uint32_t)kWideTile;
+    const uint32_t nwords = nrows * sigma;
+    uint32_t *dst = o_out + tile0 * sigma;
+    for (uint32_t i = (uint32_t)t; i < nwords; i += kBlock) dst[i] = rows[i];
+}
+
+} // namespace sx
+
+using namespace sx;
+
+static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t sigma,
+                          uint32_t *d_c, uint32_t *d_o, uint8_t *d_bwt)
+{
+    if (N == 0 || N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "N must be in [1, 2^32 - 1]");
+    if (sigma < 1 || sigma > 256) return sx_fail_msg(ctx, SX_E_ARG, "sigma must be in [1, 256]");
+    if (d_o && sigma > kMaxSigmaO)
+        return sx_fail_msg(ctx, SX_E_ARG, "the O table is defined for sigma <= 128 (stralg/remap.h:14-18)");
+    const bool small = sigma <= kSmallSigma;
+    const uint32_t tile_rows = small ? kSmallTile : kWideTile;
+    const uint32_t ntiles = sx_div_up(N + 1, tile_rows);
+    const size_t need = (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 1024 + 4096;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, need));
+    sx_arena ar;
+    ar.base = (char *)ctx->slab[SX_SLAB_BWT].p;
+    ar.cap = ctx->slab[SX_SLAB_BWT].cap;
+    uint8_t *bwt = d_bwt ? d_bwt : ar.take<uint8_t>(N);
+    uint32_t *tilehist = ar.take<uint32_t>((size_t)sigma * ntiles);
+    uint32_t *totals = ar.take<uint32_t>(256);
+    if (!bwt || !tilehist || !totals) return sx_fail_msg(ctx, SX_E_INTERNAL, "bwt: arena too small");
+
+    sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_gather_kernel, dim3(ntiles), dim3(kBlock), d_text, d_sa, N,
+              tile_rows, sigma, bwt, tilehist, ntiles);
+    sx_launch(ctx, SX_KC_SCAN, (uint64_t)sigma * ntiles * 8, bwt_offsets_kernel, dim3(sigma), dim3(kBlock),
+              tilehist, ntiles, totals);
+    sx_launch(ctx, SX_KC_MISC, 0, c_table_kernel, dim3(1), dim3(64), (const uint32_t *)totals, sigma, d_c);
+    // every bwt symbol must be < sigma (the O kernels index rows by symbol)
+    uint32_t h_tot[256];
+    SX_TRY(sx_readback(ctx, totals, sigma, h_tot));
+    uint64_t sum = 0;
+    for (uint32_t a = 0; a < sigma; ++a) sum += h_tot[a];
+    if (sum != N) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= sigma, or sa is not over this text");
+    if (d_o) {
+        const uint64_t out_bytes = (N + 1) * (uint64_t)sigma * 4 + N;
+        if (small)
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<kSmallSigma>, dim3(ntiles), dim3(kBlock),
+                      (const uint8_t *)bwt, N, sigma, (const uint32_t *)tilehist, ntiles, d_o);
+        else
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_wide_kernel, dim3(ntiles), dim3(kBlock),
+                      (const uint8_t *)bwt, N, sigma, (const uint32_t *)tilehist, ntiles, d_o);
+    }
+    return 0;
+}
+
+extern "C" {
+
+int sx_bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t sigma,
+                      uint32_t *d_c_out, uint32_t *d_o_out, uint8_t *d_bwt_out)
+{
+    if (!ctx || !d_sa || !d_c_out || (N > 1 && !d_text)) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, N, sigma, d_c_out, d_o_out, d_bwt_out));
+    return sx_sync(ctx);
+}
+
+int sx_bwt_tables(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t N, uint32_t sigma,
+                  uint32_t *c_out, uint32_t *o_out)
+{
+    if (!ctx || !sa || !c_out || (N > 1 && !text)) return SX_E_ARG;
+    if (N == 0 || N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "N must be in [1, 2^32 - 1]");
+    if (sigma < 1 || sigma > 256) return sx_fail_msg(ctx, SX_E_ARG, "sigma must be in [1, 256]");
+    SX_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n = N - 1;
+    const size_t text_b = (n + 255) & ~(size_t)255, sa_b = (N * 4 + 255) & ~(size_t)255;
+    const size_t o_b = o_out ? (((N + 1) * (size_t)sigma * 4 + 255) & ~(size_t)255) : 0;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, text_b + sa_b + o_b + 1024 + 1024));
+    char *base = (char *)ctx->slab[SX_SLAB_IO].p;
+    uint8_t *d_text = (uint8_t *)base;
+    uint32_t *d_sa = (uint32_t *)(base + text_b + 256);
+    uint32_t *d_c = (uint32_t *)(base + text_b + 256 + sa_b);
+    uint32_t *d_o = o_out ? (uint32_t *)(base + text_b + 256 + sa_b + 1024) : nullptr;
+    if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
+    SX_CHECK(hipMemcpyAsync(d_sa, sa, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, N, sigma, d_c, d_o, nullptr));
+    SX_CHECK(hipMemcpyAsync(c_out, d_c, (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (o_out) SX_CHECK(hipMemcpyAsync(o_out, d_o, (N + 1) * (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sx_sync(ctx);
+}
+
+} // extern "C"

@@ -98,4 +98,30 @@ __device__ __forceinline__ uint32_t wave_rank_step(uint32_t digit, bool valid, u
     return old + r;
 }
 
+// In-place exclusive prefix sum of row[0..count) by one workgroup; returns the total.
+__device__ __forceinline__ uint32_t block_scan_row_inplace(uint32_t *__restrict__ row, uint64_t count,
+                                                           uint32_t *lds)
+{
+    constexpr int kPer = 8;
+    uint32_t carry = 0;
+    for (uint64_t start = 0; start < count; start += (uint64_t)kBlock * kPer) { // uniform trip count
+        const uint64_t i0 = start + (uint64_t)threadIdx.x * kPer;
+        uint32_t v[kPer], acc = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            v[k] = i0 + k < count ? row[i0 + k] : 0u;
+            acc += v[k];
+        }
+        uint32_t tot;
+        uint32_t run = carry + block_exclusive_scan<OpAdd>(acc, lds, tot);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (i0 + k < count) row[i0 + k] = run;
+            run += v[k];
+        }
+        carry += tot;
+    }
+    return carry;
+}
+
 } // namespace sx

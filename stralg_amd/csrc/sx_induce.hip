@@ -87,26 +87,7 @@ __global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__rest
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     const uint32_t key = blockIdx.x;
-    uint32_t *row = hist + (uint64_t)key * ntiles;
-    constexpr int kPer = 8;
-    uint32_t carry = 0;
-    for (uint64_t start = 0; start < ntiles; start += (uint64_t)kBlock * kPer) {
-        const uint64_t i0 = start + (uint64_t)threadIdx.x * kPer;
-        uint32_t v[kPer], acc = 0;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            v[k] = i0 + k < ntiles ? row[i0 + k] : 0u;
-            acc += v[k];
-        }
-        uint32_t tot;
-        uint32_t run = carry + block_exclusive_scan<OpAdd>(acc, lds, tot);
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            if (i0 + k < ntiles) row[i0 + k] = run;
-            run += v[k];
-        }
-        carry += tot;
-    }
+    const uint32_t carry = block_scan_row_inplace(hist + (uint64_t)key * ntiles, ntiles, lds);
     if (threadIdx.x == 0) {
         const uint32_t cur = cursor[key];
         base[key] = cur;

@@ -1,0 +1,55 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libstralg_amd_emu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def golden_cases():
+    """name -> dict(sym, sigma, sa[, raw, c, o, ro]) from tests/golden/golden.npz."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+    cases = {}
+    for key in z.files:
+        name, field = key.rsplit("/", 1)
+        cases.setdefault(name, {})[field] = z[key]
+    for c in cases.values():
+        c["sigma"] = int(c["sigma"][0])
+    return cases
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return golden_cases()
+
+
+@pytest.fixture(scope="session")
+def emu_ctx():
+    """Context on the CPU execution harness build of the kernel sources (tests/emu).
+    Test infrastructure: it exercises kernel logic without a GPU and is never what
+    the product loads."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "stralg_amd", "csrc"), "emu"])
+    from stralg_amd.api import Context
+    ctx = Context(0, lib_path=EMU_LIB)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from stralg_amd.api import Context
+    ctx = Context(0)
+    yield ctx
+    ctx.close()

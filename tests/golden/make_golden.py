@@ -1,0 +1,114 @@
+"""Generates tests/golden/golden.npz by running the UNMODIFIED reference
+(oracle/_ref/libstralg_ref.so, built from /root/reference by oracle/Makefile) in
+the build container.  The fixture holds inputs and the reference's outputs only.
+
+    python tests/golden/make_golden.py
+
+Cases:
+  * the strings of the reference's own tests for this path
+    (tests/stralg/suffix_array_test.c:11-32, bwt_test.c:16-70,
+     match_test.c:682-696, serialise_test.c:15, test-data/*.txt, bioinf ref.fa)
+  * seeded random strings, sigma in {2,3,5,21,128,256}, n up to 64 Ki
+  * structured strings (runs, periodic, Fibonacci, monotone)
+For every case: remapped symbols, alphabet_size, SA (sa_is_construction; checked
+equal to sa_is_mem / skew / qsort inside this script), and for sigma <= 128 and
+n <= 4096 the C, O and RO tables of build_complete_table.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+REF_TESTS = "/root/reference/tests"
+
+
+def main():
+    oracle.build(ref=True)
+    ref = oracle.ref()
+    cases = {}
+
+    def add(name, raw, tables=True, pre_remapped_sigma=None):
+        raw = np.frombuffer(bytes(raw), dtype=np.uint8) if isinstance(raw, (bytes, bytearray)) else np.asarray(raw, np.uint8)
+        if pre_remapped_sigma is None:
+            sym, sigma = ref.remap_string(raw)
+        else:
+            sym, sigma = raw, pre_remapped_sigma
+        sa = ref.sa_is(sym, sigma)
+        assert (ref.sa_is_mem(sym, sigma) == sa).all(), name
+        if sym.size and sigma > 2:
+            assert (ref.skew(sym) == sa).all(), name
+        if sym.size <= 5000:
+            assert (ref.qsort(sym) == sa).all(), name
+        cases[name + "/sym"] = sym
+        cases[name + "/sigma"] = np.array([sigma], np.uint32)
+        cases[name + "/sa"] = sa
+        if tables and pre_remapped_sigma is None and sigma <= 128 and 0 < raw.size <= 4096:
+            t = ref.build_complete_table(raw, True)
+            assert (t["sa"] == sa).all() and t["sigma"] == sigma
+            cases[name + "/raw"] = raw
+            cases[name + "/c"] = t["c"]
+            cases[name + "/o"] = t["o"]
+            cases[name + "/ro"] = t["ro"]
+
+    # the reference's own test strings
+    add("ref/ababacabac", b"ababacabac")
+    add("ref/mississippi", b"mississippi")
+    add("ref/serialise", b"acgtadtadadfasdfing")
+    for i, s in enumerate([b"acacacg", b"gacacacag", b"acacacag", b"acagcaca", b"acatgaca", b"acgc", b"ccgc",
+                           b"aaaaaaaaa"]):
+        add(f"ref/match{i}", s)
+    add("ref/modest-proposal", open(f"{REF_TESTS}/stralg/test-data/modest-proposal.txt", "rb").read().replace(b"\0", b""))
+    add("ref/repetitive", open(f"{REF_TESTS}/stralg/test-data/repetitive-string.txt", "rb").read().strip())
+    seqs, cur = [], []
+    for line in open(f"{REF_TESTS}/bioinf/test-data/ref.fa", "rb").read().splitlines():
+        if line.startswith(b">"):
+            if cur:
+                seqs.append(b"".join(cur))
+            cur = []
+        elif line.strip():
+            cur.append(line.strip())
+    if cur:
+        seqs.append(b"".join(cur))
+    for i, s in enumerate(seqs):
+        add(f"ref/fasta{i}", s)
+
+    # seeded random strings, already in remapped form (symbols 1..sigma-1)
+    rng = np.random.default_rng(20261003)
+    for sigma in (2, 3, 5, 21, 128, 256):
+        for n in (0, 1, 2, 3, 10, 1000):
+            if sigma == n + 1:
+                continue  # sort_SA's shortcut needs distinct symbols
+            add(f"rand/s{sigma}/n{n}", rng.integers(1, sigma, size=n, dtype=np.uint8), pre_remapped_sigma=sigma)
+    for sigma in (5, 256):
+        add(f"rand/s{sigma}/n65536", oracle.synth(65536, sigma, 42), pre_remapped_sigma=sigma)
+
+    # structured strings
+    add("struct/all-a", np.full(3000, ord("a"), np.uint8))
+    add("struct/ab", np.tile(np.frombuffer(b"ab", np.uint8), 2000))
+    add("struct/aab", np.tile(np.frombuffer(b"aab", np.uint8), 1300))
+    add("struct/runs", np.repeat(rng.integers(97, 101, size=120, dtype=np.uint8), 31))
+    add("struct/akb-akb", np.frombuffer(b"a" * 1500 + b"b" + b"a" * 1500 + b"b", np.uint8))
+    add("struct/b-ak", np.frombuffer(b"b" + b"a" * 3000, np.uint8))
+    add("struct/increasing", np.arange(1, 121, dtype=np.uint8))
+    add("struct/decreasing", np.arange(120, 0, -1, dtype=np.uint8))
+    a, b = b"a", b"ab"
+    while len(b) < 4000:
+        a, b = b, b + a
+    add("struct/fibonacci", np.frombuffer(b, np.uint8))
+    add("struct/periodic", np.tile(rng.integers(97, 101, size=50, dtype=np.uint8), 80))
+    add("struct/tile-runs", np.concatenate([np.full(4096, 2, np.uint8), np.full(4100, 2, np.uint8), [1],
+                                            np.full(8200, 3, np.uint8), [4]]).astype(np.uint8),
+        pre_remapped_sigma=5)
+
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz")
+    np.savez_compressed(out, **cases)
+    names = sorted({k.rsplit("/", 1)[0] for k in cases})
+    print(f"{len(names)} cases -> {out} ({os.path.getsize(out)} bytes)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""The HIP kernel sources, executed by the CPU harness of tests/emu, against the
+oracle and the golden vectors.  This checks kernel logic (ballot ranking, tile
+carries, scans) where there is no GPU; the `-m gpu` tests repeat the parity checks
+on hardware through the product library."""
+import numpy as np
+
+import oracle
+
+
+def _sa(ctx, x, sigma):
+    return ctx.sa_build(np.asarray(x, dtype=np.uint8), sigma)
+
+
+def test_tiny_and_edges(emu_ctx):
+    assert _sa(emu_ctx, [], 5).tolist() == [0]
+    assert _sa(emu_ctx, [3], 5).tolist() == [1, 0]
+    for x in ([1, 1], [1, 2], [2, 1], [1, 2, 1], [2, 2, 1, 2], [1, 1, 2, 3]):
+        assert (_sa(emu_ctx, x, 5) == oracle.sa_is_strict(np.array(x, np.uint8), 5)).all(), x
+    # loose alphabet_size: the true suffix array, not sort_SA's shortcut (quirk 3)
+    assert _sa(emu_ctx, [1, 1, 2, 3], 5).tolist() == [4, 0, 1, 2, 3]
+
+
+def test_golden_small(emu_ctx, golden):
+    for name, c in golden.items():
+        n = c["sym"].size
+        if n > 4200 or c["sigma"] > 21 or c["sigma"] == n + 1:
+            continue
+        assert (_sa(emu_ctx, c["sym"], c["sigma"]) == c["sa"]).all(), name
+
+
+def test_random_and_tile_boundaries(emu_ctx):
+    rng = np.random.default_rng(3)
+    for n in (4095, 4096, 4097, 9000):
+        x = rng.integers(1, 5, size=n, dtype=np.uint8)
+        assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all(), n
+    x = rng.integers(1, 256, size=600, dtype=np.uint8)
+    assert (_sa(emu_ctx, x, 256) == oracle.sa_is(x, 256)).all()
+
+
+def test_bwt_tables(emu_ctx, golden):
+    for name in ("ref/mississippi", "ref/serialise", "struct/periodic", "ref/fasta0"):
+        c = golden[name]
+        ct, ot = emu_ctx.bwt_tables(c["sym"], c["sa"], c["sigma"])
+        assert (ct == c["c"]).all() and (ot == c["o"]).all(), name
+    # wide-alphabet O kernel (8 < sigma <= 128) and the last row across a tile edge
+    rng = np.random.default_rng(9)
+    for sigma, n in ((21, 700), (128, 300), (5, 1023), (5, 1024), (5, 2049)):
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        sa = oracle.sa_is(x, sigma)
+        ct, ot = emu_ctx.bwt_tables(x, sa, sigma)
+        assert (ct == oracle.c_table(x, sigma)).all(), (sigma, n)
+        assert (ot == oracle.o_table(x, sa, sigma)).all(), (sigma, n)
+
+
+def test_primitives(emu_ctx):
+    rng = np.random.default_rng(1)
+    n = 5000
+    keys = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+    keys[::7] = keys[3]  # duplicates: stability matters
+    vals = np.arange(n, dtype=np.uint32)
+    ka, va, kb, vb = keys.copy(), vals.copy(), np.zeros_like(keys), np.zeros_like(vals)
+    in_b = emu_ctx.prim_sort_pairs_dev(ka, va, kb, vb, n, 0, 64)
+    ks, vs = (kb, vb) if in_b else (ka, va)
+    order = np.argsort(keys, kind="stable")
+    assert (ks == keys[order]).all() and (vs == order).all()
+    x = rng.integers(0, 1000, size=70000, dtype=np.uint32)
+    out, tot = np.zeros_like(x), np.zeros(1, np.uint32)
+    emu_ctx.prim_exclusive_sum_dev(x, out, x.size, tot)
+    ref = np.concatenate(([0], np.cumsum(x, dtype=np.uint64)[:-1])).astype(np.uint32)
+    assert (out == ref).all() and tot[0] == x.sum()

@@ -1,0 +1,269 @@
+"""Parity on hardware, through the C-ABI of the product library: the HIP path
+against the oracle, the golden vectors and size-independent properties.
+Everything here is bit-exact (integer / index work)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from stralg_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _loaded_product_lib():
+    with open("/proc/self/maps") as f:
+        return any("stralg_amd/libstralg_amd.so" in line for line in f)
+
+
+def test_native_library_is_loaded(gpu_ctx):
+    assert _loaded_product_lib()
+    assert gpu_ctx.lib.sx_device_count() >= 1
+
+
+# ---- kernel-level ------------------------------------------------------------------
+
+def test_radix_sort_pairs(gpu_ctx):
+    import torch
+    rng = np.random.default_rng(1)
+    for n, lo, hi in ((1, 0, 64), (5, 0, 64), (2048, 0, 64), (2049, 3, 61), (1_000_003, 0, 64), (300_000, 8, 24)):
+        keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        if n > 10:
+            keys[::7] = keys[3]
+        vals = np.arange(n, dtype=np.uint32)
+        ka = torch.from_numpy(keys.view(np.int64)).cuda()
+        va = torch.from_numpy(vals.view(np.int32)).cuda()
+        kb, vb = torch.empty_like(ka), torch.empty_like(va)
+        in_b = gpu_ctx.prim_sort_pairs_dev(ka, va, kb, vb, n, lo, hi)
+        ks = (kb if in_b else ka).cpu().numpy().view(np.uint64)
+        vs = (vb if in_b else va).cpu().numpy().view(np.uint32)
+        mask = np.uint64(((1 << hi) - 1) ^ ((1 << lo) - 1)) if hi < 64 else np.uint64(~np.uint64((1 << lo) - 1))
+        order = np.argsort(keys & mask, kind="stable")
+        assert (vs == order).all(), (n, lo, hi)
+        assert (ks == keys[order]).all(), (n, lo, hi)
+
+
+def test_exclusive_sum(gpu_ctx):
+    import torch
+    rng = np.random.default_rng(2)
+    for n in (1, 2047, 2048, 2049, 5_000_000):
+        x = rng.integers(0, 800, size=n, dtype=np.uint32)
+        d = torch.from_numpy(x.view(np.int32)).cuda()
+        out, tot = torch.empty_like(d), torch.zeros(1, dtype=torch.int32, device="cuda")
+        gpu_ctx.prim_exclusive_sum_dev(d, out, n, tot)
+        ref = np.concatenate(([0], np.cumsum(x, dtype=np.uint64)[:-1])).astype(np.uint32)
+        assert (out.cpu().numpy().view(np.uint32) == ref).all(), n
+        assert int(tot.cpu().numpy().view(np.uint32)[0]) == int(x.sum()), n
+
+
+def test_classify_against_model(gpu_ctx):
+    import torch
+    import model
+    rng = np.random.default_rng(3)
+    inputs = [rng.integers(1, 5, size=100_000, dtype=np.uint8), rng.integers(1, 256, size=70_000, dtype=np.uint8),
+              np.concatenate([np.full(9000, 2, np.uint8), [1], np.full(5000, 3, np.uint8), [4]]).astype(np.uint8),
+              np.full(20_000, 7, np.uint8)]
+    for x in inputs:
+        n = x.size
+        T = np.concatenate((x, np.zeros(1, np.uint8)))
+        is_s, lms = model.types_and_lms(T)
+        d = torch.from_numpy(x).cuda()
+        flags = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+        h = [torch.zeros(256, dtype=torch.int32, device="cuda") for _ in range(3)]
+        gpu_ctx.prim_classify_dev(d, n, flags, *h)
+        assert (flags.cpu().numpy().astype(bool) == lms).all()
+        assert (h[0].cpu().numpy() == np.bincount(T, minlength=256)).all()
+        assert (h[1].cpu().numpy() == np.bincount(T[~is_s], minlength=256)).all()
+        assert (h[2].cpu().numpy() == np.bincount(T[lms], minlength=256)).all()
+
+
+# ---- golden vectors and oracle ---------------------------------------------------------
+
+def test_golden_suffix_arrays(gpu_ctx, golden):
+    for name, c in golden.items():
+        if c["sigma"] == c["sym"].size + 1:
+            continue
+        assert (gpu_ctx.sa_build(c["sym"], c["sigma"]) == c["sa"]).all(), name
+
+
+def test_golden_tables(gpu_ctx, golden):
+    import stralg_amd
+    checked = 0
+    for name, c in golden.items():
+        if "o" not in c:
+            continue
+        t = stralg_amd.build_complete_table(bytes(c["raw"]), True, gpu_ctx)
+        assert t.remap_table.alphabet_size == c["sigma"], name
+        assert (t.sa.array == c["sa"]).all(), name
+        assert (t.c_table == c["c"]).all(), name
+        assert (t.o_table == c["o"]).all(), name      # all (N+1) rows, incl. the last (quirk 7)
+        assert (t.ro_table == c["ro"]).all(), name
+        checked += 1
+    assert checked > 20
+
+
+def test_edges_and_errors(gpu_ctx):
+    from stralg_amd.api import StralgAmdError
+    assert gpu_ctx.sa_build(np.zeros(0, np.uint8), 5).tolist() == [0]
+    assert gpu_ctx.sa_build(np.array([3], np.uint8), 5).tolist() == [1, 0]
+    assert gpu_ctx.sa_build(np.array([1, 1, 2, 3], np.uint8), 5).tolist() == [4, 0, 1, 2, 3]  # quirk 3
+    assert gpu_ctx.sa_build(np.array([1, 2, 3, 4], np.uint8), 5).tolist() == [4, 0, 1, 2, 3]  # distinct symbols
+    with pytest.raises(StralgAmdError):
+        gpu_ctx.sa_build(np.array([1, 7, 2], np.uint8), 5)        # symbol >= alphabet_size
+    with pytest.raises(StralgAmdError):
+        gpu_ctx.sa_build(np.array([1, 0, 2], np.uint8), 5)        # interior sentinel
+    x = np.array([1, 2, 1], np.uint8)
+    assert (gpu_ctx.sa_build(x, 256) == oracle.sa_is_strict(x, 256)).all()    # loose alphabet
+
+
+def test_random_against_oracle(gpu_ctx):
+    rng = np.random.default_rng(4)
+    for sigma in (2, 3, 5, 21, 128, 256):
+        for n in (7, 300, 4096, 4097, 70_001):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), (sigma, n)
+
+
+def test_structured_against_oracle(gpu_ctx):
+    rng = np.random.default_rng(5)
+    cases = {
+        "all-equal": np.full(3000, 1, np.uint8),
+        "runs": np.repeat(rng.integers(1, 5, size=3000, dtype=np.uint8), 23),
+        "tile-runs": np.concatenate([rng.integers(1, 5, size=4090, dtype=np.uint8), np.full(9000, 3, np.uint8),
+                                     rng.integers(1, 5, size=4000, dtype=np.uint8)]),
+        "periodic": np.tile(rng.integers(1, 5, size=97, dtype=np.uint8), 3000),
+        "two-long-lms": np.concatenate([np.full(20000, 1, np.uint8), [2], np.full(20000, 1, np.uint8), [2]]).astype(np.uint8),
+        "long-pieces": np.tile(np.concatenate([np.full(100, 2, np.uint8), [1]]).astype(np.uint8), 500),
+    }
+    for name, x in cases.items():
+        sigma = int(x.max()) + 1
+        assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), name
+
+
+@pytest.mark.parametrize("sigma,n", [(5, 1 << 24), (256, 1 << 22)])
+def test_benchmark_shaped_against_oracle(gpu_ctx, sigma, n):
+    x = synth(n, sigma, 42)
+    got = gpu_ctx.sa_build(x, sigma)
+    want = oracle.sa_is(x, sigma)
+    assert (got == want).all()
+    if sigma <= 128:
+        c, o = gpu_ctx.bwt_tables(x[: 1 << 20], oracle.sa_is(x[: 1 << 20], sigma), sigma)
+        assert (c == oracle.c_table(x[: 1 << 20], sigma)).all()
+        assert (o == oracle.o_table(x[: 1 << 20], oracle.sa_is(x[: 1 << 20], sigma), sigma)).all()
+
+
+def test_wide_alphabet_tables(gpu_ctx):
+    rng = np.random.default_rng(6)
+    for sigma, n in ((9, 5000), (21, 70_000), (128, 30_000)):
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        sa = oracle.sa_is(x, sigma)
+        c, o = gpu_ctx.bwt_tables(x, sa, sigma)
+        assert (c == oracle.c_table(x, sigma)).all() and (o == oracle.o_table(x, sa, sigma)).all(), (sigma, n)
+
+
+# ---- the reference-named C entry points (include/stralg_compat.h) ------------------------
+
+def test_reference_named_c_api(gpu_ctx, golden):
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class RT(C.Structure):
+        _fields_ = [("alphabet_size", C.c_uint32), ("table", C.c_byte * 256), ("rev_table", C.c_byte * 128)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.POINTER(RT)), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.POINTER(C.POINTER(C.c_uint32))),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.POINTER(C.POINTER(C.c_uint32)))]
+
+    lib = gpu_ctx.lib
+    lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
+    lib.build_complete_table.restype = C.POINTER(BT)
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    for name in ("ref/mississippi", "ref/serialise", "ref/fasta2", "struct/fibonacci"):
+        c = golden[name]
+        t = lib.build_complete_table(bytes(c["raw"]), True).contents
+        N, sigma = t.sa.contents.length, t.remap_table.contents.alphabet_size
+        assert sigma == c["sigma"] and N == c["sa"].size
+        assert (np.ctypeslib.as_array(t.sa.contents.array, shape=(N,)) == c["sa"]).all()
+        assert (np.ctypeslib.as_array(t.c_table, shape=(sigma,)) == c["c"]).all()
+        assert (np.ctypeslib.as_array(t.o_table, shape=(N + 1, sigma)) == c["o"]).all()
+        assert (np.ctypeslib.as_array(t.ro_table, shape=(N + 1, sigma)) == c["ro"]).all()
+        # the O(a, i) macro of bwt.h:49 goes through the row pointers
+        for i in (0, N // 2, N):
+            assert [t.o_indices[i][a] for a in range(sigma)] == c["o"][i].tolist()
+        lib.completely_free_bwt_table(t)
+    # the three constructors share one result (match_test.c:479,517,539)
+    lib.sa_is_construction.argtypes = [C.c_char_p, C.c_uint32]
+    lib.sa_is_construction.restype = C.POINTER(SA)
+    lib.skew_sa_construction.argtypes = [C.c_char_p]
+    lib.skew_sa_construction.restype = C.POINTER(SA)
+    lib.free_suffix_array.argtypes = [C.POINTER(SA)]
+    lib.free_suffix_array.restype = None
+    c = golden["ref/ababacabac"]
+    buf = C.create_string_buffer(bytes(c["sym"]))
+    a = lib.sa_is_construction(buf, c["sigma"])
+    b = lib.skew_sa_construction(buf)
+    assert np.ctypeslib.as_array(a.contents.array, shape=(11,)).tolist() == [10, 0, 6, 2, 8, 4, 1, 7, 3, 9, 5]
+    assert np.ctypeslib.as_array(b.contents.array, shape=(11,)).tolist() == [10, 0, 6, 2, 8, 4, 1, 7, 3, 9, 5]
+    lib.free_suffix_array(a)
+    lib.free_suffix_array(b)
+
+
+# ---- BASELINE.json's full sizes: size-independent properties -------------------------------
+
+def _verify_sa_on_device(text_u8, sa_i32, n):
+    """permutation + strictly increasing suffixes, O(n) on the GPU with torch."""
+    import torch
+    N = n + 1
+    assert int(sa_i32[0]) == n
+    sa = sa_i32.long()
+    rank = torch.full((N + 1,), -1, dtype=torch.int32, device=sa.device)
+    rank[sa] = torch.arange(N, dtype=torch.int32, device=sa.device)
+    assert bool((rank[:N] >= 0).all()), "not a permutation"
+    T = torch.zeros(N + 1, dtype=torch.uint8, device=sa.device)
+    T[:n] = text_u8
+    a, b = sa[1:-1], sa[2:]
+    ca, cb = T[a], T[b]
+    ra, rb = rank[a + 1], rank[b + 1]
+    ok = (ca < cb) | ((ca == cb) & (ra < rb))
+    assert bool(ok.all()), "suffixes out of order"
+
+
+@pytest.mark.parametrize("log2n,sigma", [(28, 5), (30, 5), (28, 256)])
+def test_full_size_properties(gpu_ctx, log2n, sigma):
+    import torch
+    n = 1 << log2n
+    text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.synth_dev(text, n, sigma, 42)
+    head = text[: 1 << 16].cpu().numpy()
+    assert (head == synth(1 << 16, sigma, 42)).all()
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    gpu_ctx.sa_build_dev(text, n, sigma, sa)
+    _verify_sa_on_device(text, sa, n)
+    if sigma <= 128 and log2n <= 28:
+        N = n + 1
+        c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
+        o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
+        bw = torch.empty(N, dtype=torch.uint8, device="cuda")
+        gpu_ctx.bwt_tables_dev(text, sa, N, sigma, c, o, bw)
+        counts = torch.bincount(text.long(), minlength=sigma)
+        counts[0] += 1
+        want_c = torch.cumsum(counts, 0) - counts
+        assert bool((c.long() == want_c).all())
+        o = o.view(N + 1, sigma)
+        assert bool((o[0] == 0).all()) and bool((o[N].long() == counts).all())
+        step = 1 << 24
+        for s in range(0, N, step):
+            e = min(N, s + step)
+            d = (o[s + 1: e + 1] - o[s: e])
+            onehot = torch.nn.functional.one_hot(bw[s:e].long(), sigma).to(torch.int32)
+            assert bool((d == onehot).all())
+        # bwt symbols themselves: text[sa - 1]
+        idx = (sa.long() - 1).clamp(min=0)
+        want_b = torch.where(sa == 0, torch.zeros_like(bw), text[idx.clamp(max=n - 1)])
+        assert bool((bw == want_b).all())

@@ -1,0 +1,86 @@
+"""The oracle (oracle/oracle.c) against the golden vectors and, where the
+unmodified reference has been built (build container only), against the
+reference itself.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from stralg_amd.synth import synth
+
+
+def test_known_answers():
+    # tests/stralg/suffix_array_test.c:19-32
+    sym, sigma, _ = oracle.remap(b"ababacabac")
+    assert oracle.sa_is(sym, sigma).tolist() == [10, 0, 6, 2, 8, 4, 1, 7, 3, 9, 5]
+    # tests/stralg/bwt_test.c:16-19 and SURVEY.md 8c
+    sym, sigma, _ = oracle.remap(b"mississippi")
+    sa = oracle.sa_is(sym, sigma)
+    assert sa.tolist() == [11, 10, 7, 4, 1, 0, 9, 8, 6, 3, 5, 2]
+    assert oracle.c_table(sym, sigma).tolist() == [0, 1, 5, 6, 8]
+    assert oracle.bwt(sym, sa).tolist() == [1, 3, 4, 4, 2, 0, 3, 1, 4, 4, 1, 1]
+    # bwt_test.c:32-38 (letter-major literal, transposed here)
+    o = oracle.o_table(sym, sa, sigma)
+    expected = np.array([
+        [0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1],
+        [0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 4],
+        [0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1],
+        [0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2],
+        [0, 0, 0, 1, 2, 2, 2, 2, 2, 3, 4, 4, 4]], dtype=np.uint32)
+    assert (o.T == expected).all()
+
+
+def test_golden_vectors(golden):
+    for name, c in golden.items():
+        sa = oracle.sa_is(c["sym"], c["sigma"])
+        assert (sa == c["sa"]).all(), name
+        assert oracle.check_sa(c["sym"], sa), name
+        if "o" in c:
+            sym, sigma, _ = oracle.remap(c["raw"])
+            assert sigma == c["sigma"] and (sym == c["sym"]).all(), name
+            assert (oracle.c_table(sym, sigma) == c["c"]).all(), name
+            assert (oracle.o_table(sym, sa, sigma) == c["o"]).all(), name
+            rsym = sym[::-1].copy()
+            rsa = oracle.sa_is(rsym, sigma)
+            assert (oracle.o_table(rsym, rsa, sigma) == c["ro"]).all(), name
+
+
+def test_naive_agrees():
+    rng = np.random.default_rng(5)
+    for sigma in (2, 4, 17):
+        for n in (0, 1, 5, 64, 700):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            assert (oracle.sa_naive(x) == oracle.sa_is_strict(x, sigma)).all()
+
+
+def test_shortcut_quirk():
+    # alphabet_size == n + 1 with repeated symbols
+    x = np.array([1, 1, 2, 3], dtype=np.uint8)
+    got = oracle.sa_is(x, 5)                                        # what sa_is.c:423-428 yields:
+    assert got[:4].tolist() == [4, 1, 2, 3]                         # SA[x[i]] = i, last slot never written
+    assert not oracle.check_sa(x, got)
+    assert oracle.sa_is_strict(x, 5).tolist() == [4, 0, 1, 2, 3]   # the suffix array
+
+
+def test_synth_streams_agree():
+    for sigma in (5, 256):
+        assert (oracle.synth(10000, sigma, 42) == synth(10000, sigma, 42)).all()
+    assert (synth(100, 5, 7, start=50) == synth(150, 5, 7)[50:]).all()
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference library not built here")
+def test_against_reference_build():
+    ref = oracle.ref()
+    rng = np.random.default_rng(11)
+    for sigma in (2, 5, 20, 128, 256):
+        for n in (1, 2, 7, 100, 5000):
+            if sigma == n + 1:
+                continue
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            assert (ref.sa_is(x, sigma) == oracle.sa_is(x, sigma)).all()
+    raw = rng.integers(97, 103, size=3000, dtype=np.uint8)
+    t = ref.build_complete_table(raw, True)
+    sym, sigma, _ = oracle.remap(raw)
+    sa = oracle.sa_is(sym, sigma)
+    assert (sa == t["sa"]).all()
+    assert (oracle.c_table(sym, sigma) == t["c"]).all()
+    assert (oracle.o_table(sym, sa, sigma) == t["o"]).all()
