@@ -31,6 +31,13 @@ class BuildStats(C.Structure):
 def load(path=None):
     """Load the shared library and declare every entry point of include/stralg_amd.h."""
     path = path or PRODUCT_LIB
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever
+    # is loaded first serves the whole process, and a second copy cannot open the GPU,
+    # so torch -- the process's owner of device memory and streams -- must come first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `make -C stralg_amd/csrc` "

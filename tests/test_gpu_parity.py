@@ -184,7 +184,7 @@ def test_reference_named_c_api(gpu_ctx, golden):
     lib.build_complete_table.restype = C.POINTER(BT)
     lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
     lib.completely_free_bwt_table.restype = None
-    for name in ("ref/mississippi", "ref/serialise", "ref/fasta2", "struct/fibonacci"):
+    for name in ("ref/mississippi", "ref/serialise", "ref/fasta2", "struct/periodic"):
         c = golden[name]
         t = lib.build_complete_table(bytes(c["raw"]), True).contents
         N, sigma = t.sa.contents.length, t.remap_table.contents.alphabet_size
