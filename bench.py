@@ -99,33 +99,21 @@ def main():
         if tables:
             ctx.bwt_tables_dev(text, sa, N, sigma, c_tab, o_tab)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    from stralg_amd import farm
     for _ in range(args.warmup):
         step()
     ctx.profile_reset()
     ctx.profile_enable(True)   # HIP events on the library's own stream, inside the timed region
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps
+    elapsed = farm.timed(step, args.steps, 0, cuda=True)
     ctx.profile_enable(False)
     prof = ctx.profile_read()
     stats = ctx.last_stats()
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # max time over ranks, total suffixes over ranks (the only collectives; none on the data path)
+    elapsed, total_units = farm.reduce_scalars(elapsed, args.steps * N, device=dev)
 
     if rank == 0:
-        value = world * args.steps * N / elapsed / 1e6
+        value = total_units / elapsed / 1e6
         # dominant kernel class by summed HIP-event time
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
