@@ -68,7 +68,7 @@ typedef struct sx_build_stats {
     uint32_t doubling_rounds;
     uint32_t induce_rounds;  /* multisplit rounds over both passes */
     uint32_t sort_passes;    /* radix passes, all sorts */
-    uint32_t reserved;
+    uint32_t lms_path;       /* 1: prefix-key LMS sort resolved everything, 2: general path */
     double ms_total;         /* wall time of the last build on the device stream */
 } sx_build_stats;
 
@@ -79,6 +79,11 @@ void sx_ctx_destroy(sx_ctx *ctx);
 const char *sx_last_error(const sx_ctx *ctx);
 /* drop cached workspace (it is otherwise kept between calls) */
 void sx_ctx_trim(sx_ctx *ctx);
+/* behaviour switches (testing / measurement) */
+enum {
+    SX_FLAG_FORCE_GENERAL_PATH = 1 /* skip the prefix-key LMS sort: always pieces + names + prefix doubling */
+};
+int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 
 /* ---- suffix array -------------------------------------------------------- */
 /* Host buffers.  text[0..n) holds symbols in [1, alphabet_size), alphabet_size

@@ -22,7 +22,7 @@ class BuildStats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_lms", C.c_uint64), ("n_samples", C.c_uint64),
                 ("n_names", C.c_uint64), ("key_bits", C.c_uint32), ("key_slots", C.c_uint32),
                 ("doubling_rounds", C.c_uint32), ("induce_rounds", C.c_uint32),
-                ("sort_passes", C.c_uint32), ("reserved", C.c_uint32), ("ms_total", C.c_double)]
+                ("sort_passes", C.c_uint32), ("lms_path", C.c_uint32), ("ms_total", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -50,6 +50,7 @@ def load(path=None):
         "sx_ctx_destroy": (None, [vp]),
         "sx_last_error": (C.c_char_p, [vp]),
         "sx_ctx_trim": (None, [vp]),
+        "sx_ctx_set_flag": (C.c_int, [vp, C.c_int, C.c_int]),
         "sx_sa_build": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, u32p]),
         "sx_sa_build_dev": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, u32p]),
         "sx_bwt_tables": (C.c_int, [vp, u8p, u32p, C.c_uint64, C.c_uint32, u32p, u32p]),
@@ -79,7 +80,7 @@ def load(path=None):
     return lib
 
 
-EXPORTS = ["sx_device_count", "sx_ctx_create", "sx_ctx_destroy", "sx_last_error", "sx_ctx_trim",
+EXPORTS = ["sx_device_count", "sx_ctx_create", "sx_ctx_destroy", "sx_last_error", "sx_ctx_trim", "sx_ctx_set_flag",
            "sx_sa_build", "sx_sa_build_dev", "sx_bwt_tables", "sx_bwt_tables_dev", "sx_profile_enable",
            "sx_profile_reset", "sx_profile_read", "sx_kernel_class_name", "sx_last_stats",
            "sx_synth_dev", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]

@@ -124,6 +124,10 @@ class Context:
         self._check(self.lib.sx_last_stats(self.h, C.byref(st)), "sx_last_stats")
         return st.as_dict()
 
+    def force_general_path(self, on=True):
+        """SX_FLAG_FORCE_GENERAL_PATH: pieces + names + prefix doubling even where the prefix-key sort would do."""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 1, 1 if on else 0), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

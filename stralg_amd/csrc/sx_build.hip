@@ -83,7 +83,7 @@ static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t
     sx_arena an;
     an.base = (char *)ctx->slab[SX_SLAB_N].p;
     an.cap = ctx->slab[SX_SLAB_N].cap;
-    const uint64_t padded = (uint64_t)sx_div_up(N, kClsTile) * kClsTile + 64;
+    const uint64_t padded = (uint64_t)sx_div_up(N, kClsTile) * kClsTile + 128;
     uint8_t *T = an.take<uint8_t>(padded);
     if (!T) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: text");
     // only the tail needs zeroing: sentinel + padding
@@ -104,7 +104,31 @@ static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t
         sorted_lms = one;
         ctx->stats.n_samples = 1;
         ctx->stats.n_names = 1;
-    } else {
+    }
+    if (ti.m > 1 && !ctx->force_general) {
+        // fast path: radix sort of the LMS suffixes by their first 64/b symbols (sx_lmssort.hip)
+        SX_TRY(sx_sample_flags(ctx, ti, 0xFFFFFFFFu)); // no cut points: samples == LMS positions
+        if (ti.M != ti.m) return sx_fail_msg(ctx, SX_E_INTERNAL, "LMS compaction count differs from the histogram");
+        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(ti.m) + ti.m * 5 + 1024));
+        sx_arena am;
+        am.base = (char *)ctx->slab[SX_SLAB_M].p;
+        am.cap = ctx->slab[SX_SLAB_M].cap;
+        uint32_t *pos = am.take<uint32_t>(ti.m);
+        uint8_t *is_lms = am.take<uint8_t>(ti.m);
+        if (!pos || !is_lms) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS positions");
+        SX_TRY(sx_sample_write(ctx, ti, pos, is_lms));
+        int resolved = 0;
+        SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, pos, &sorted_lms, &resolved));
+        if (resolved) {
+            ctx->stats.lms_path = 1;
+            ctx->stats.n_samples = ti.m;
+        } else {
+            sorted_lms = nullptr;
+        }
+    }
+    if (ti.m > 1 && !sorted_lms) {
+        ctx->stats.lms_path = 2;
+        ctx->stats.doubling_rounds = 0;
         uint32_t bits, slots, lenbits;
         key_layout(ti.maxc, bits, slots, lenbits);
         ctx->stats.key_bits = bits;
@@ -154,7 +178,7 @@ static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t
             SX_TRY(sx_reduced_suffix_sort(ctx, M, n_names, rb));
             sa_r = rb.sa_r;
         }
-        SX_TRY(sx_sorted_lms(ctx, sa_r, pos, is_lms, M, slms, rb.d_scalar));
+        SX_TRY(sx_sorted_lms(ctx, sa_r, pos, is_lms, M, ti.m, slms, rb.d_scalar));
         uint32_t got = 0;
         SX_TRY(sx_readback(ctx, rb.d_scalar, 1, &got));
         if (got != ti.m) return sx_fail_msg(ctx, SX_E_INTERNAL, "sorted LMS count differs from the LMS count");

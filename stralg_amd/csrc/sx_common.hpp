@@ -59,6 +59,7 @@ struct sx_ctx {
     sx_slab slab[SX_NSLABS];
     uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB)
     // profiling
+    int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int prof_on = 0;
     std::vector<sx_event_pair> ev_used;
     std::vector<sx_event_pair> ev_free;

@@ -161,6 +161,16 @@ void sx_ctx_destroy(sx_ctx *ctx)
     delete ctx;
 }
 
+int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
+{
+    if (!ctx) return SX_E_ARG;
+    if (flag == SX_FLAG_FORCE_GENERAL_PATH) {
+        ctx->force_general = value ? 1 : 0;
+        return 0;
+    }
+    return SX_E_ARG;
+}
+
 const char *sx_last_error(const sx_ctx *ctx) { return ctx ? ctx->err : "no context"; }
 
 int sx_profile_enable(sx_ctx *ctx, int on)

@@ -55,7 +55,12 @@ int sx_name_pieces(sx_ctx *ctx, const uint64_t *ks, const uint32_t *vs, uint64_t
 int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_bufs &rb);
 // sorted LMS suffix positions from the reduced suffix array
 int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms, uint64_t M,
-                  uint32_t *sorted_lms, uint32_t *d_total);
+                  uint64_t m, uint32_t *sorted_lms, uint32_t *d_total);
+
+// ---- sx_lmssort.hip
+size_t sx_lms_prefix_bytes(uint64_t m);
+int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t *pos,
+                          const uint32_t **out, int *resolved);
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);

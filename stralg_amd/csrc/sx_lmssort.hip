@@ -1,0 +1,260 @@
+// sx_lmssort.hip -- LMS-suffix sort by fixed-length text prefixes (the fast path).
+//
+// Role of stralg/sa_is.c:340-387 (place_LMS + first induce round + reduce_SA +
+// recursion): produce the LMS suffixes in sorted order.  On inputs whose LMS
+// suffixes are told apart by their first few dozen symbols -- random DNA and
+// byte strings are: the expected longest repeat is ~2 log_sigma n symbols --
+// that order is simply a radix sort of (prefix key, position) pairs:
+//
+//   key(p)  = the first C symbols of suffix p, b = bitlen(max symbol) bits each,
+//             C = 64 / b (21 for DNA, 8 for bytes); past the end the text reads
+//             0, the unique smallest symbol, so no key containing the sentinel
+//             can tie with another.
+//   sort    one 64-bit LSD radix sort (sx_radix.hip) of all m LMS suffixes
+//   ties    groups of equal keys are refined by the next C symbols, a few
+//             rounds, on the tied elements only.
+//
+// If too many ties remain (repetitive text) the caller falls back to the
+// general path (pieces + names + prefix doubling, sx_reduce.hip), which is
+// O(n log n) whatever the input.  Either way the order is the unique one.
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_scan.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+// C symbols starting at text position p, packed most-significant first.
+// Reads three aligned 16-byte chunks when C <= 32, byte loads otherwise.
+__device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, uint32_t b,
+                                               uint32_t C)
+{
+    uint64_t acc = 0;
+    if (C <= 32) {
+        const uint64_t base = p & ~(uint64_t)15;
+        const uint32_t sh = (uint32_t)(p & 15);
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(T + base);
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(T + base + 16);
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(T + base + 32);
+        const uint32_t w[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        for (uint32_t s = 0; s < C; ++s) {
+            const uint32_t o = sh + s;
+            const uint32_t ch = (w[o >> 2] >> (8 * (o & 3))) & 0xFFu;
+            acc = (acc << b) | ch;
+        }
+    } else {
+        for (uint32_t s = 0; s < C; ++s) acc = (acc << b) | (uint64_t)T[p + s];
+    }
+    return acc << (64u - b * C);
+}
+
+__global__ __launch_bounds__(kBlock) void lms_prefix_keys_kernel(const uint8_t *__restrict__ T,
+                                                                 const uint32_t *__restrict__ pos, uint64_t m,
+                                                                 uint32_t b, uint32_t C, uint64_t *__restrict__ keys,
+                                                                 uint32_t *__restrict__ vals)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t p = pos[k];
+    keys[k] = prefix_key(T, p, b, C);
+    vals[k] = p;
+}
+
+// members of groups of equal keys: (index in the sorted order, text position, group head index)
+struct InTied {
+    const uint64_t *ks;
+    uint64_t m;
+    __device__ __forceinline__ uint32_t operator()(uint64_t j) const
+    {
+        const uint64_t k = ks[j];
+        const bool eq_prev = j > 0 && ks[j - 1] == k;
+        const bool eq_next = j + 1 < m && ks[j + 1] == k;
+        return (eq_prev || eq_next) ? 1u : 0u;
+    }
+};
+struct OutTied {
+    const uint64_t *ks;
+    const uint32_t *vs;
+    uint32_t *apos, *ap;
+    uint8_t *ahead;
+    uint32_t cap;
+    __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const
+    {
+        if (!v || excl >= cap) return;
+        apos[excl] = (uint32_t)j;
+        ap[excl] = vs[j];
+        ahead[excl] = (j == 0 || ks[j - 1] != ks[j]) ? 1 : 0;
+    }
+};
+
+// group id of an active element = index (in the active list) of its group's first member
+struct InActHead {
+    const uint8_t *ahead;
+    __device__ __forceinline__ uint32_t operator()(uint64_t t) const { return ahead[t] ? (uint32_t)t + 1u : 0u; }
+};
+struct OutActKey {
+    const uint8_t *T;
+    const uint32_t *ap;
+    uint64_t n, skip;
+    uint32_t b, C;
+    uint32_t *agid;
+    uint64_t *key_keep, *key_sort;
+    uint32_t *order;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const
+    {
+        agid[t] = (excl > v ? excl : v) - 1u;
+        const uint64_t q = (uint64_t)ap[t] + skip;
+        // q > n cannot happen inside a tie (a key holding the sentinel is unique); stay in bounds anyway
+        const uint64_t k = q <= n ? prefix_key(T, q, b, C) : 0ull;
+        key_keep[t] = k;
+        key_sort[t] = k;
+        order[t] = (uint32_t)t;
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void gid_keys_kernel(const uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ agid, uint64_t A,
+                                                          uint64_t *__restrict__ keys)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < A) keys[t] = agid[order[t]];
+}
+
+// after ordering by (group, next key): write the refined order back, find the new boundaries
+__global__ __launch_bounds__(kBlock) void refine_write_kernel(const uint32_t *__restrict__ order,
+                                                              const uint32_t *__restrict__ ap,
+                                                              const uint32_t *__restrict__ apos,
+                                                              const uint32_t *__restrict__ agid,
+                                                              const uint64_t *__restrict__ key_keep, uint64_t A,
+                                                              uint32_t *__restrict__ vals_sorted,
+                                                              uint32_t *__restrict__ ap_new,
+                                                              uint8_t *__restrict__ head_new)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= A) return;
+    const uint32_t o = order[t];
+    const uint32_t p = ap[o];
+    vals_sorted[apos[t]] = p; // slot t of the active list keeps its place in the sorted order
+    ap_new[t] = p;
+    bool head = true;
+    if (t > 0) {
+        const uint32_t o1 = order[t - 1];
+        head = agid[o1] != agid[o] || key_keep[o1] != key_keep[o];
+    }
+    head_new[t] = head ? 1 : 0;
+}
+
+struct InStillTied {
+    const uint8_t *head;
+    uint64_t A;
+    __device__ __forceinline__ uint32_t operator()(uint64_t t) const
+    {
+        const bool single = head[t] && (t + 1 == A || head[t + 1]);
+        return single ? 0u : 1u;
+    }
+};
+struct OutStillTied {
+    const uint32_t *apos, *ap;
+    const uint8_t *head;
+    uint32_t *apos2, *ap2;
+    uint8_t *head2;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const
+    {
+        if (!v) return;
+        apos2[excl] = apos[t];
+        ap2[excl] = ap[t];
+        head2[excl] = head[t];
+    }
+};
+
+} // namespace sx
+
+using namespace sx;
+
+size_t sx_lms_prefix_bytes(uint64_t m)
+{
+    const size_t a = 256;
+    const uint64_t cap = m / 8 + 1024;
+    size_t b = 0;
+    b += 2 * (m * 8 + a);   // keys
+    b += 2 * (m * 4 + a);   // values
+    b += 3 * (cap * 8 + a); // refinement keys: kept copy + sort ping-pong
+    b += 8 * (cap * 4 + a); // apos x2, ap x2, ap_new, agid, order x2
+    b += 3 * (cap + a);     // heads
+    return b + 4096;
+}
+
+// Returns 0 and *resolved = 1 with *out = device array of the m LMS suffix positions in
+// suffix order; *resolved = 0 when the caller must use the general path.
+int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t *pos,
+                          const uint32_t **out, int *resolved)
+{
+    *resolved = 0;
+    const uint64_t m = ti.m;
+    uint32_t b = (uint32_t)sx_bitlen(ti.maxc);
+    if (b < 1) b = 1;
+    const uint32_t C = 64 / b;
+    const uint32_t cap = (uint32_t)(m / 8 + 1024);
+    uint64_t *ka = am.take<uint64_t>(m), *kb = am.take<uint64_t>(m);
+    uint32_t *va = am.take<uint32_t>(m), *vb = am.take<uint32_t>(m);
+    uint64_t *key_keep = am.take<uint64_t>(cap), *rk_a = am.take<uint64_t>(cap), *rk_b = am.take<uint64_t>(cap);
+    uint32_t *apos = am.take<uint32_t>(cap), *apos2 = am.take<uint32_t>(cap);
+    uint32_t *ap = am.take<uint32_t>(cap), *ap2 = am.take<uint32_t>(cap), *ap_new = am.take<uint32_t>(cap);
+    uint32_t *agid = am.take<uint32_t>(cap), *ord_a = am.take<uint32_t>(cap), *ord_b = am.take<uint32_t>(cap);
+    uint8_t *head = am.take<uint8_t>(cap), *head2 = am.take<uint8_t>(cap), *head_new = am.take<uint8_t>(cap);
+    uint32_t *d_scalar = am.take<uint32_t>(16);
+    if (!ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
+        !agid || !ord_a || !ord_b || !head || !head2 || !head_new || !d_scalar)
+        return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
+    const dim3 block(kBlock);
+
+    sx_launch(ctx, SX_KC_KEYS, m * (4 + 12) + ti.N, lms_prefix_keys_kernel, dim3(sx_div_up(m, kBlock)), block,
+              ti.T, pos, m, b, C, ka, va);
+    int in_b = 0;
+    SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, (int)(64 - b * C), 64, &in_b));
+    const uint64_t *ks = in_b ? kb : ka;
+    uint32_t *vs = in_b ? vb : va;
+
+    // members of groups with equal keys
+    SX_TRY((device_scan<OpAdd>(ctx, m, InTied{ks, m}, OutTied{ks, vs, apos, ap, head, cap}, d_scalar,
+                               SX_KC_NAMES, m * 16)));
+    uint32_t A = 0;
+    SX_TRY(sx_readback(ctx, d_scalar, 1, &A));
+    ctx->stats.n_names = m - A; // suffixes told apart by the first sort
+    if (A > cap - 1024) return 0; // repetitive text: general path
+
+    for (int round = 1; A > 0; ++round) {
+        if (round > 3) return 0; // still tied after 4C symbols: general path
+        ctx->stats.doubling_rounds++;
+        const uint32_t gbits = (uint32_t)(sx_bitlen(A) > 0 ? sx_bitlen(A) : 1);
+        // group ids and the next C symbols of every tied suffix
+        SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head},
+                                   OutActKey{ti.T, ap, ti.n, (uint64_t)C * round, b, C, agid, key_keep, rk_a, ord_a},
+                                   nullptr, SX_KC_DOUBLING, (uint64_t)A * 32)));
+        // order by (group, next key), LSD: stable sort by next key, then stable sort by group
+        int f = 0;
+        SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A, (int)(64 - b * C), 64, &f));
+        uint32_t *ord1 = f ? ord_b : ord_a, *ord1_other = f ? ord_a : ord_b;
+        uint64_t *k1 = f ? rk_a : rk_b, *k1_other = f ? rk_b : rk_a; // k1: free to overwrite
+        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 16, gid_keys_kernel, dim3(sx_div_up(A, kBlock)), block,
+                  (const uint32_t *)ord1, (const uint32_t *)agid, (uint64_t)A, k1);
+        SX_TRY(sx_sort_pairs(ctx, k1, ord1, k1_other, ord1_other, A, 0, (int)gbits, &f));
+        const uint32_t *order = f ? ord1_other : ord1;
+        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 40, refine_write_kernel, dim3(sx_div_up(A, kBlock)), block, order,
+                  (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid, (const uint64_t *)key_keep,
+                  (uint64_t)A, vs, ap_new, head_new);
+        // keep what is still tied
+        SX_TRY((device_scan<OpAdd>(ctx, A, InStillTied{head_new, A},
+                                   OutStillTied{apos, ap_new, head_new, apos2, ap2, head2}, d_scalar, SX_KC_DOUBLING,
+                                   (uint64_t)A * 20)));
+        uint32_t A2 = 0;
+        SX_TRY(sx_readback(ctx, d_scalar, 1, &A2));
+        uint32_t *tp = apos; apos = apos2; apos2 = tp;
+        tp = ap; ap = ap2; ap2 = tp;
+        uint8_t *th = head; head = head2; head2 = th;
+        A = A2;
+    }
+    *out = vs;
+    *resolved = 1;
+    return 0;
+}

@@ -131,6 +131,15 @@ struct OutLmsPos {
     }
 };
 
+__global__ __launch_bounds__(kBlock) void gather_pos_kernel(const uint32_t *__restrict__ sa_r,
+                                                            const uint32_t *__restrict__ pos, uint64_t M,
+                                                            uint32_t *__restrict__ out, uint32_t *__restrict__ d_total)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < M) out[j] = pos[sa_r[j]];
+    if (j == 0) *d_total = (uint32_t)M;
+}
+
 } // namespace sx
 
 using namespace sx;
@@ -203,8 +212,14 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
 }
 
 int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms, uint64_t M,
-                  uint32_t *sorted_lms, uint32_t *d_total)
+                  uint64_t m, uint32_t *sorted_lms, uint32_t *d_total)
 {
+    if (M == m) {
+        // no cut points: every sample is an LMS position, one gather does it
+        sx_launch(ctx, SX_KC_DOUBLING, M * 12, gather_pos_kernel, dim3(sx_div_up(M, kBlock)), dim3(kBlock), sa_r, pos,
+                  M, sorted_lms, d_total);
+        return 0;
+    }
     return device_scan<OpAdd>(ctx, M, InIsLms{sa_r, is_lms}, OutLmsPos{sa_r, pos, sorted_lms}, d_total,
                               SX_KC_DOUBLING, M * (2 * (4 + 1) + 8));
 }

@@ -37,6 +37,25 @@ def test_random_and_tile_boundaries(emu_ctx):
     assert (_sa(emu_ctx, x, 256) == oracle.sa_is(x, 256)).all()
 
 
+def test_both_lms_paths(emu_ctx):
+    """prefix-key LMS sort (with tie refinement rounds) and the general path agree with the oracle"""
+    base = oracle.synth(6000, 5, 9)
+    seen = set()
+    for L in (0, 25, 70, 100):
+        x = base.copy()
+        if L:
+            x[3000:3000 + L] = x[100:100 + L]
+            x[4500:4500 + L] = x[100:100 + L]
+        want = oracle.sa_is(x, 5)
+        for force in (False, True):
+            emu_ctx.force_general_path(force)
+            assert (_sa(emu_ctx, x, 5) == want).all(), (L, force)
+            st = emu_ctx.last_stats()
+            seen.add((st["lms_path"], st["doubling_rounds"] > 0))
+    emu_ctx.force_general_path(False)
+    assert (1, False) in seen and (1, True) in seen and any(p == 2 for p, _ in seen)
+
+
 def test_bwt_tables(emu_ctx, golden):
     for name in ("ref/mississippi", "ref/serialise", "struct/periodic", "ref/fasta0"):
         c = golden[name]

@@ -127,6 +127,34 @@ def test_random_against_oracle(gpu_ctx):
             assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), (sigma, n)
 
 
+def test_general_path_against_oracle(gpu_ctx):
+    """SX_FLAG_FORCE_GENERAL_PATH: pieces + names + prefix doubling on inputs the fast path would take"""
+    rng = np.random.default_rng(14)
+    gpu_ctx.force_general_path(True)
+    try:
+        for sigma, n in ((5, 1 << 20), (256, 300_000), (2, 100_000), (21, 4097)):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), (sigma, n)
+            assert gpu_ctx.last_stats()["lms_path"] == 2
+    finally:
+        gpu_ctx.force_general_path(False)
+
+
+def test_tie_refinement_rounds(gpu_ctx):
+    """planted repeats longer than one prefix key: refinement rounds, then fallback"""
+    base = synth(1 << 20, 5, 9)
+    paths = []
+    for L in (0, 30, 70, 200, 5000):
+        x = base.copy()
+        for k in range(1, 40):
+            if L:
+                x[k * 20000: k * 20000 + L] = x[100: 100 + L]
+        assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all(), L
+        st = gpu_ctx.last_stats()
+        paths.append((L, st["lms_path"], st["doubling_rounds"]))
+    assert paths[0][1] == 1 and paths[1][1] == 1 and paths[1][2] >= 1 and paths[-1][1] == 2, paths
+
+
 def test_structured_against_oracle(gpu_ctx):
     rng = np.random.default_rng(5)
     cases = {
