@@ -132,7 +132,7 @@ def test_general_path_against_oracle(gpu_ctx):
     rng = np.random.default_rng(14)
     gpu_ctx.force_general_path(True)
     try:
-        for sigma, n in ((5, 1 << 20), (256, 300_000), (2, 100_000), (21, 4097)):
+        for sigma, n in ((5, 1 << 20), (256, 300_000), (3, 100_000), (21, 4097)):
             x = rng.integers(1, sigma, size=n, dtype=np.uint8)
             assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), (sigma, n)
             assert gpu_ctx.last_stats()["lms_path"] == 2
