@@ -93,11 +93,16 @@ def main():
     sa = torch.empty(N, dtype=torch.int32, device=dev)
     c_tab = torch.zeros(sigma, dtype=torch.int32, device=dev)
     o_tab = torch.empty((N + 1) * sigma, dtype=torch.int32, device=dev) if tables else None
+    bwt = torch.empty(N, dtype=torch.uint8, device=dev) if tables else None
 
     def step():
-        ctx.sa_build_dev(text, n, sigma, sa)
+        # build_complete_table's device work (stralg/bwt.c:143,154): suffix array, then C and O.
+        # The induced-sort passes hand the BWT over with the suffix array (sx_sa_bwt_build_dev).
         if tables:
-            ctx.bwt_tables_dev(text, sa, N, sigma, c_tab, o_tab)
+            ctx.sa_bwt_build_dev(text, n, sigma, sa, bwt)
+            ctx.bwt_tables_from_bwt_dev(bwt, N, sigma, c_tab, o_tab)
+        else:
+            ctx.sa_build_dev(text, n, sigma, sa)
 
     from stralg_amd import farm
     for _ in range(args.warmup):

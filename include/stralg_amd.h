@@ -96,6 +96,11 @@ int sx_sa_build(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t alphabet_
 int sx_sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t alphabet_size,
                     uint32_t *d_sa_out);
 
+/* Suffix array and BWT in one build: the induced-sort passes carry text[SA[i]-1]
+ * with every entry, so the BWT costs no extra gather.  d_bwt_out has n+1 bytes. */
+int sx_sa_bwt_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t alphabet_size,
+                        uint32_t *d_sa_out, uint8_t *d_bwt_out);
+
 /* ---- BWT tables ------------------------------------------------------------ */
 /* text[0..N-1) symbols in [1, sigma) (N = n+1 counts the sentinel), sa[N].
  * c_out[sigma]; o_out[(N+1)*sigma] position-major: o_out[i*sigma + a] = O(a,i).
@@ -105,6 +110,14 @@ int sx_bwt_tables(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t
 /* Device buffers; d_bwt_out (N bytes) is optional. */
 int sx_bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N,
                       uint32_t sigma, uint32_t *d_c_out, uint32_t *d_o_out, uint8_t *d_bwt_out);
+
+/* C/O tables from a BWT already on the device (pairs with sx_sa_bwt_build_dev). */
+int sx_bwt_tables_from_bwt_dev(sx_ctx *ctx, const uint8_t *d_bwt, uint64_t N, uint32_t sigma,
+                               uint32_t *d_c_out, uint32_t *d_o_out);
+/* build_complete_table's device work in one call (stralg/bwt.c:134-161): host text ->
+ * suffix array (sa_out, n+1 entries, may be NULL), C table, O table (may be NULL). */
+int sx_build_tables(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma, uint32_t *sa_out,
+                    uint32_t *c_out, uint32_t *o_out);
 
 /* ---- measurement ------------------------------------------------------------ */
 int sx_profile_enable(sx_ctx *ctx, int on);       /* bracket every launch with HIP events */

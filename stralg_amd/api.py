@@ -80,9 +80,28 @@ class Context:
         self._check(self.lib.sx_bwt_tables(self.h, _ptr(text), _ptr(sa), N, sigma, _ptr(c), _ptr(o)), "sx_bwt_tables")
         return c, o
 
+    def build_tables(self, text, sigma, want_sa=True, want_o=True):
+        """sx_build_tables: (sa or None, c_table, o_table or None) with one text upload."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        N = text.size + 1
+        sa = np.empty(N, dtype=np.uint32) if want_sa else None
+        c = np.zeros(sigma, dtype=np.uint32)
+        o = np.empty((N + 1, sigma), dtype=np.uint32) if want_o else None
+        self._check(self.lib.sx_build_tables(self.h, _ptr(text), text.size, sigma, _ptr(sa), _ptr(c), _ptr(o)),
+                    "sx_build_tables")
+        return sa, c, o
+
     # ---- device-buffer entry points (torch tensors or raw addresses) --------------
     def sa_build_dev(self, d_text, n, alphabet_size, d_sa_out):
         self._check(self.lib.sx_sa_build_dev(self.h, _ptr(d_text), n, alphabet_size, _ptr(d_sa_out)), "sx_sa_build_dev")
+
+    def sa_bwt_build_dev(self, d_text, n, alphabet_size, d_sa_out, d_bwt_out):
+        self._check(self.lib.sx_sa_bwt_build_dev(self.h, _ptr(d_text), n, alphabet_size, _ptr(d_sa_out),
+                                                 _ptr(d_bwt_out)), "sx_sa_bwt_build_dev")
+
+    def bwt_tables_from_bwt_dev(self, d_bwt, N, sigma, d_c_out, d_o_out=None):
+        self._check(self.lib.sx_bwt_tables_from_bwt_dev(self.h, _ptr(d_bwt), N, sigma, _ptr(d_c_out), _ptr(d_o_out)),
+                    "sx_bwt_tables_from_bwt_dev")
 
     def bwt_tables_dev(self, d_text, d_sa, N, sigma, d_c_out, d_o_out=None, d_bwt_out=None):
         self._check(self.lib.sx_bwt_tables_dev(self.h, _ptr(d_text), _ptr(d_sa), N, sigma, _ptr(d_c_out),
@@ -258,6 +277,11 @@ def build_complete_table(string, include_reverse=True, ctx=None):
     ctx = ctx or default_context()
     table = alloc_remap_table(string)
     remapped = remap(string, table)
-    sa = sa_is_construction(remapped, table.alphabet_size, ctx)
-    rsa = sa_is_construction(remapped[::-1].copy(), table.alphabet_size, ctx) if include_reverse else None
-    return init_bwt_table(sa, rsa, table, ctx)
+    sigma = table.alphabet_size
+    # one device pass per direction: the induced sort hands over the BWT with the suffix array
+    sa_arr, c, o = ctx.build_tables(remapped, sigma)
+    ro = None
+    if include_reverse:
+        _, _, ro = ctx.build_tables(remapped[::-1].copy(), sigma, want_sa=False)
+    sa = SuffixArray(_with_terminator(remapped), sa_arr)
+    return BwtTable(table, sa, c, o, ro)

@@ -259,19 +259,39 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
     }
     uint8_t *remapped = malloc(n + 1);
     remap(remapped, string, remap_table);
-    /* ownership of `remapped` moves into sa->string (bwt.c:139-143) */
-    struct suffix_array *sa = sa_is_construction(remapped, remap_table->alphabet_size);
+    const uint32_t sigma = remap_table->alphabet_size;
+    const size_t N = n + 1;
+    const size_t o_words = (size_t)sigma * (N + 1);
+    sx_ctx *ctx = thread_ctx();
 
-    struct suffix_array *rsa = NULL;
+    /* One device pass per direction (sx_build_tables): the induced sort hands the BWT over with
+     * the suffix array, so init_bwt_table's gather of text[SA[i]-1] is not repeated.  The
+     * results are what sa_is_construction + init_bwt_table produce (bwt.c:143-154). */
+    struct suffix_array *sa = allocate_sa_(remapped); /* ownership of `remapped` moves into sa->string */
+    struct bwt_table *table = malloc(sizeof *table);
+    table->remap_table = remap_table;
+    table->sa = sa;
+    table->c_table = calloc(sigma, sizeof *table->c_table);
+    table->o_table = malloc(o_words * sizeof *table->o_table);
+    int rc = sx_build_tables(ctx, remapped, n, sigma, sa->array, table->c_table, table->o_table);
+    if (rc != 0) die("build_complete_table", rc, ctx);
+    table->o_indices = row_pointers(table->o_table, N + 1, sigma);
+
+    table->ro_table = NULL;
+    table->ro_indices = NULL;
     if (include_reverse) {
+        /* the reverse suffix array and the reversed copy are temporary (bwt.c:147-158) */
         uint8_t *rev = malloc(n + 1);
         for (size_t i = 0; i < n; ++i) rev[i] = remapped[n - 1 - i];
         rev[n] = 0;
-        rsa = sa_is_construction(rev, remap_table->alphabet_size);
+        uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
+        table->ro_table = malloc(o_words * sizeof *table->ro_table);
+        rc = sx_build_tables(ctx, rev, n, sigma, NULL, c_tmp, table->ro_table);
+        if (rc != 0) die("build_complete_table (reverse)", rc, ctx);
+        free(c_tmp);
+        free(rev);
+        table->ro_indices = row_pointers(table->ro_table, N + 1, sigma);
     }
-    struct bwt_table *table = malloc(sizeof *table);
-    init_bwt_table(table, sa, rsa, remap_table);
-    if (rsa) free_complete_suffix_array(rsa); /* bwt.c:158: rsa and the reversed copy are temporary */
     return table;
 }
 

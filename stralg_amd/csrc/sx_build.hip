@@ -66,7 +66,7 @@ static size_t reduce_bytes(uint64_t M, uint64_t m)
     return b;
 }
 
-static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa)
+int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa, uint8_t *d_bwt)
 {
     const auto t0 = std::chrono::steady_clock::now();
     memset(&ctx->stats, 0, sizeof ctx->stats);
@@ -76,6 +76,7 @@ static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t
     if (n > 0 && sigma < 2) return sx_fail_msg(ctx, SX_E_ARG, "non-empty text needs alphabet_size >= 2");
     if (n == 0) { // sa_is.c:413-417
         sx_launch(ctx, SX_KC_MISC, 0, write_u32_kernel, dim3(1), dim3(1), d_sa, 0u);
+        if (d_bwt) SX_CHECK(hipMemsetAsync(d_bwt, 0, 1, ctx->stream));
         return sx_sync(ctx);
     }
     const uint64_t N = n + 1;
@@ -185,7 +186,7 @@ static int sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t
         sorted_lms = slms;
     }
 
-    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, d_sa, an));
+    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, d_sa, d_bwt, an));
     SX_TRY(sx_sync(ctx));
     ctx->stats.ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -198,7 +199,15 @@ int sx_sa_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t alp
 {
     if (!ctx || !d_sa_out || (n && !d_text)) return SX_E_ARG;
     SX_CHECK(hipSetDevice(ctx->device));
-    return sa_build_dev(ctx, d_text, n, alphabet_size, d_sa_out);
+    return sx_sa_build_impl(ctx, d_text, n, alphabet_size, d_sa_out, nullptr);
+}
+
+int sx_sa_bwt_build_dev(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t alphabet_size, uint32_t *d_sa_out,
+                        uint8_t *d_bwt_out)
+{
+    if (!ctx || !d_sa_out || (n && !d_text)) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    return sx_sa_build_impl(ctx, d_text, n, alphabet_size, d_sa_out, d_bwt_out);
 }
 
 int sx_sa_build(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t alphabet_size, uint32_t *sa_out)
@@ -212,8 +221,34 @@ int sx_sa_build(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t alphabet_
     uint8_t *d_text = (uint8_t *)ctx->slab[SX_SLAB_IO].p;
     uint32_t *d_sa = (uint32_t *)((char *)ctx->slab[SX_SLAB_IO].p + text_bytes + 256);
     if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
-    SX_TRY(sa_build_dev(ctx, d_text, n, alphabet_size, d_sa));
+    SX_TRY(sx_sa_build_impl(ctx, d_text, n, alphabet_size, d_sa, nullptr));
     SX_CHECK(hipMemcpyAsync(sa_out, d_sa, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return sx_sync(ctx);
+}
+
+int sx_build_tables(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma, uint32_t *sa_out, uint32_t *c_out,
+                    uint32_t *o_out)
+{
+    if (!ctx || (n && !text) || !c_out) return SX_E_ARG;
+    if (n > 0xFFFFFFFEull) return sx_fail_msg(ctx, SX_E_ARG, "n must be at most 2^32 - 2");
+    if (sigma < 1 || sigma > 256) return sx_fail_msg(ctx, SX_E_ARG, "sigma must be in [1, 256]");
+    SX_CHECK(hipSetDevice(ctx->device));
+    const uint64_t N = n + 1;
+    const size_t text_b = (n + 255) & ~(size_t)255, sa_b = (N * 4 + 255) & ~(size_t)255, bwt_b = (N + 255) & ~(size_t)255;
+    const size_t o_b = o_out ? (((N + 1) * (size_t)sigma * 4 + 255) & ~(size_t)255) : 0;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, text_b + sa_b + bwt_b + o_b + 4096));
+    char *base = (char *)ctx->slab[SX_SLAB_IO].p;
+    uint8_t *d_text = (uint8_t *)base;
+    uint32_t *d_sa = (uint32_t *)(base + text_b + 256);
+    uint8_t *d_bwt = (uint8_t *)(base + text_b + 256 + sa_b);
+    uint32_t *d_c = (uint32_t *)(base + text_b + 256 + sa_b + bwt_b);
+    uint32_t *d_o = o_out ? (uint32_t *)(base + text_b + 256 + sa_b + bwt_b + 1024) : nullptr;
+    if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
+    SX_TRY(sx_sa_build_impl(ctx, d_text, n, sigma, d_sa, d_bwt));
+    SX_TRY(sx_tables_from_bwt_impl(ctx, d_bwt, N, sigma, d_c, d_o));
+    if (sa_out) SX_CHECK(hipMemcpyAsync(sa_out, d_sa, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SX_CHECK(hipMemcpyAsync(c_out, d_c, (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (o_out) SX_CHECK(hipMemcpyAsync(o_out, d_o, (N + 1) * (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
     return sx_sync(ctx);
 }
 

@@ -49,6 +49,23 @@ __global__ __launch_bounds__(kBlock) void bwt_gather_kernel(const uint8_t *__res
     if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+// per-tile symbol counts of a BWT that is already in memory (fused SA+BWT build)
+__global__ __launch_bounds__(kBlock) void bwt_count_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
+                                                           uint32_t tile_rows, uint32_t sigma,
+                                                           uint32_t *__restrict__ tilehist, uint32_t ntiles)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t tile0 = (uint64_t)blockIdx.x * tile_rows;
+    for (uint32_t r = threadIdx.x; r < tile_rows; r += kBlock) {
+        const uint64_t i = tile0 + r;
+        if (i < N) atomicAdd(&h[bwt[i]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
 // per symbol: exclusive prefix of the tile counts (in place) and the symbol total
 __global__ __launch_bounds__(kBlock) void bwt_offsets_kernel(uint32_t *__restrict__ tilehist, uint32_t ntiles,
                                                              uint32_t *__restrict__ totals)
@@ -154,8 +171,9 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
 
 using namespace sx;
 
-static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t sigma,
-                          uint32_t *d_c, uint32_t *d_o, uint8_t *d_bwt)
+// tables from (text, sa) or from a ready BWT (d_bwt_in != NULL)
+static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, const uint8_t *d_bwt_in,
+                          uint64_t N, uint32_t sigma, uint32_t *d_c, uint32_t *d_o, uint8_t *d_bwt_out)
 {
     if (N == 0 || N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "N must be in [1, 2^32 - 1]");
     if (sigma < 1 || sigma > 256) return sx_fail_msg(ctx, SX_E_ARG, "sigma must be in [1, 256]");
@@ -169,13 +187,18 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     sx_arena ar;
     ar.base = (char *)ctx->slab[SX_SLAB_BWT].p;
     ar.cap = ctx->slab[SX_SLAB_BWT].cap;
-    uint8_t *bwt = d_bwt ? d_bwt : ar.take<uint8_t>(N);
+    uint8_t *bwt_own = d_bwt_in ? nullptr : (d_bwt_out ? d_bwt_out : ar.take<uint8_t>(N));
+    const uint8_t *bwt = d_bwt_in ? d_bwt_in : bwt_own;
     uint32_t *tilehist = ar.take<uint32_t>((size_t)sigma * ntiles);
     uint32_t *totals = ar.take<uint32_t>(256);
     if (!bwt || !tilehist || !totals) return sx_fail_msg(ctx, SX_E_INTERNAL, "bwt: arena too small");
 
-    sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_gather_kernel, dim3(ntiles), dim3(kBlock), d_text, d_sa, N,
-              tile_rows, sigma, bwt, tilehist, ntiles);
+    if (d_bwt_in)
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(ntiles), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
+                  tilehist, ntiles);
+    else
+        sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_gather_kernel, dim3(ntiles), dim3(kBlock), d_text, d_sa, N,
+                  tile_rows, sigma, bwt_own, tilehist, ntiles);
     sx_launch(ctx, SX_KC_SCAN, (uint64_t)sigma * ntiles * 8, bwt_offsets_kernel, dim3(sigma), dim3(kBlock),
               tilehist, ntiles, totals);
     sx_launch(ctx, SX_KC_MISC, 0, c_table_kernel, dim3(1), dim3(64), (const uint32_t *)totals, sigma, d_c);
@@ -188,13 +211,18 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     if (d_o) {
         const uint64_t out_bytes = (N + 1) * (uint64_t)sigma * 4 + N;
         if (small)
-            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<kSmallSigma>, dim3(ntiles), dim3(kBlock),
-                      (const uint8_t *)bwt, N, sigma, (const uint32_t *)tilehist, ntiles, d_o);
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<kSmallSigma>, dim3(ntiles), dim3(kBlock), bwt, N,
+                      sigma, (const uint32_t *)tilehist, ntiles, d_o);
         else
-            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_wide_kernel, dim3(ntiles), dim3(kBlock),
-                      (const uint8_t *)bwt, N, sigma, (const uint32_t *)tilehist, ntiles, d_o);
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_wide_kernel, dim3(ntiles), dim3(kBlock), bwt, N, sigma,
+                      (const uint32_t *)tilehist, ntiles, d_o);
     }
     return 0;
+}
+
+int sx_tables_from_bwt_impl(sx_ctx *ctx, const uint8_t *d_bwt, uint64_t N, uint32_t sigma, uint32_t *d_c, uint32_t *d_o)
+{
+    return bwt_tables_dev(ctx, nullptr, nullptr, d_bwt, N, sigma, d_c, d_o, nullptr);
 }
 
 extern "C" {
@@ -204,7 +232,16 @@ int sx_bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, 
 {
     if (!ctx || !d_sa || !d_c_out || (N > 1 && !d_text)) return SX_E_ARG;
     SX_CHECK(hipSetDevice(ctx->device));
-    SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, N, sigma, d_c_out, d_o_out, d_bwt_out));
+    SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, nullptr, N, sigma, d_c_out, d_o_out, d_bwt_out));
+    return sx_sync(ctx);
+}
+
+int sx_bwt_tables_from_bwt_dev(sx_ctx *ctx, const uint8_t *d_bwt, uint64_t N, uint32_t sigma, uint32_t *d_c_out,
+                               uint32_t *d_o_out)
+{
+    if (!ctx || !d_bwt || !d_c_out) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(bwt_tables_dev(ctx, nullptr, nullptr, d_bwt, N, sigma, d_c_out, d_o_out, nullptr));
     return sx_sync(ctx);
 }
 
@@ -226,7 +263,7 @@ int sx_bwt_tables(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t
     uint32_t *d_o = o_out ? (uint32_t *)(base + text_b + 256 + sa_b + 1024) : nullptr;
     if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
     SX_CHECK(hipMemcpyAsync(d_sa, sa, N * 4, hipMemcpyHostToDevice, ctx->stream));
-    SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, N, sigma, d_c, d_o, nullptr));
+    SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, nullptr, N, sigma, d_c, d_o, nullptr));
     SX_CHECK(hipMemcpyAsync(c_out, d_c, (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (o_out) SX_CHECK(hipMemcpyAsync(o_out, d_o, (N + 1) * (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
     return sx_sync(ctx);

@@ -19,8 +19,10 @@
 // L-type iff text[p-1] >= c; for an S-type entry, p-1 is S-type iff
 // text[p-1] <= c (equal symbols share the type of their right neighbour).
 //
-// Cost: one random byte gather per scanned entry (the HBM-latency-bound part)
-// and a 4-byte write per induced entry into <= sigma sequential streams.
+// Cost: streaming.  Every entry carries a window of the symbols to its left
+// (filled from the text once per LMS seed and again only when it runs dry), so
+// a round reads (entry, window) pairs and writes them to <= sigma sequential
+// streams; after the S pass the windows' first symbols are the BWT.
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
@@ -43,36 +45,72 @@ __device__ __forceinline__ bool induce_accept(uint32_t ch, uint32_t c, int mode)
     }
 }
 
-// logical item i of a round -> entry of the source range (reversed for the S pass)
-__device__ __forceinline__ uint32_t round_item(const uint32_t *__restrict__ src, uint32_t len, bool rev,
-                                               uint32_t i)
+// ---- symbol windows ---------------------------------------------------------------
+// Every suffix-array entry p travels with a window word holding the symbols to
+// its left, text[p-1], text[p-2], ... (codes = symbol - 1, B bits each, the
+// nearest one in the lowest field) and, in the low 4 bits, how many are valid.
+// Inducing p-1 from p pops one symbol; the text is touched again only when a
+// window runs dry.
+constexpr int kCntBits = 4;
+struct wnd_cfg {
+    uint32_t B;    // bits per symbol code
+    uint32_t CW;   // symbols per window (<= 15)
+    uint32_t mask; // (1 << B) - 1
+};
+
+template <class WT> __device__ __forceinline__ uint32_t wnd_count(WT w) { return (uint32_t)(w & (WT)15); }
+template <class WT> __device__ __forceinline__ uint32_t wnd_first(WT w, const wnd_cfg &c)
 {
-    return src[rev ? len - 1u - i : i];
+    return (uint32_t)((w >> kCntBits) & (WT)c.mask) + 1u;
+}
+template <class WT> __device__ __forceinline__ WT wnd_pop(WT w, const wnd_cfg &c)
+{
+    const WT cnt = w & (WT)15;
+    return (((w >> kCntBits) >> c.B) << kCntBits) | (cnt - 1);
+}
+// window of position p, read from the text (p >= 1)
+template <class WT>
+__device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p, const wnd_cfg &c)
+{
+    const uint32_t cnt = p < c.CW ? p : c.CW;
+    WT acc = 0;
+    for (uint32_t k = cnt; k-- > 0;) acc = (acc << c.B) | (WT)(T[p - 1u - k] - 1u);
+    return (acc << kCntBits) | (WT)cnt;
 }
 
-// gather text[p-1], remember it, count accepted entries per destination bucket
-__global__ __launch_bounds__(kBlock) void induce_gather_kernel(const uint32_t *__restrict__ src, uint32_t len,
-                                                               int rev, const uint8_t *__restrict__ T, int mode,
-                                                               uint32_t c, uint8_t *__restrict__ tmpch,
-                                                               uint32_t *__restrict__ hist, uint32_t ntiles,
-                                                               uint32_t nkeys)
+template <class WT>
+__global__ __launch_bounds__(kBlock) void fill_windows_kernel(const uint8_t *__restrict__ T,
+                                                              const uint32_t *__restrict__ pos, uint64_t count,
+                                                              wnd_cfg cfg, WT *__restrict__ out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t p = pos[k];
+    out[k] = p ? wnd_fill<WT>(T, p, cfg) : (WT)0;
+}
+
+// count accepted entries per destination bucket (no text access: the symbol is in the window)
+template <class WT>
+__global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__restrict__ srcP,
+                                                              const WT *__restrict__ srcW, uint32_t len, int rev,
+                                                              int mode, uint32_t c, wnd_cfg cfg,
+                                                              uint32_t *__restrict__ hist, uint32_t ntiles,
+                                                              uint32_t nkeys)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    // a symbol the accept test of this mode rejects (p == 0 has no predecessor)
-    const uint32_t reject = mode == MODE_L_FROM_L ? 0u : 255u;
     const uint32_t tile0 = blockIdx.x * (uint32_t)kIndTile;
 #pragma unroll
     for (int k = 0; k < kIndItems; ++k) {
         const uint32_t i = tile0 + (uint32_t)k * kBlock + threadIdx.x;
         if (i < len) {
-            const uint32_t p = round_item(src, len, rev != 0, i);
-            uint32_t ch = reject;
-            if (p != 0) ch = T[p - 1u];
-            const bool ok = p != 0 && induce_accept(ch, c, mode);
-            tmpch[i] = (uint8_t)(ok ? ch : reject);
-            if (ok) atomicAdd(&h[ch], 1u);
+            const uint32_t idx = rev ? len - 1u - i : i;
+            const uint32_t p = srcP[idx];
+            if (p != 0) {
+                const uint32_t ch = wnd_first<WT>(srcW[idx], cfg);
+                if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+            }
         }
     }
     __syncthreads();
@@ -96,13 +134,12 @@ __global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__rest
     }
 }
 
-template <int BITS>
-__global__ __launch_bounds__(kBlock) void induce_scatter_kernel(const uint32_t *__restrict__ src, uint32_t len,
-                                                                int rev, const uint8_t *__restrict__ tmpch,
-                                                                int mode, uint32_t c,
-                                                                const uint32_t *__restrict__ offs, uint32_t ntiles,
-                                                                const uint32_t *__restrict__ base, int dir,
-                                                                uint32_t *__restrict__ SA, uint32_t nkeys)
+// stable scatter of p-1 (with its popped window) to the bucket cursors
+template <class WT, int BITS>
+__global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, uint32_t len, int rev, int mode, uint32_t c,
+    wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs, uint32_t ntiles,
+    const uint32_t *__restrict__ base, int dir, uint32_t *__restrict__ SA, WT *__restrict__ WN, uint32_t nkeys)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gpos[256]; // first destination index of the tile for each bucket
@@ -112,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(const uint32_t *
     const uint32_t tile0 = blockIdx.x * (uint32_t)kIndTile;
     const uint32_t wave0 = tile0 + (uint32_t)w * (kWave * kIndItems);
     uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
+    WT wnd[kIndItems];
     bool ok[kIndItems];
 #pragma unroll
     for (int k = 0; k < kIndItems; ++k) {
@@ -119,12 +157,18 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(const uint32_t *
         ok[k] = false;
         dig[k] = 0;
         val[k] = 0;
+        wnd[k] = 0;
         if (i < len) {
-            const uint32_t p = round_item(src, len, rev != 0, i);
-            const uint32_t ch = tmpch[i];
-            ok[k] = p != 0 && induce_accept(ch, c, mode);
-            dig[k] = ch;
-            val[k] = p - 1u;
+            const uint32_t idx = rev ? len - 1u - i : i;
+            const uint32_t p = srcP[idx];
+            if (p != 0) {
+                const WT ww = srcW[idx];
+                const uint32_t ch = wnd_first<WT>(ww, cfg);
+                ok[k] = induce_accept(ch, c, mode);
+                dig[k] = ch;
+                val[k] = p - 1u;
+                wnd[k] = wnd_pop<WT>(ww, cfg);
+            }
         }
     }
 #pragma unroll
@@ -148,12 +192,29 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(const uint32_t *
             const uint32_t d = dig[k];
             const uint32_t r = gpos[d] + wcount[w][d] + rnk[k];
             const uint32_t dst = dir > 0 ? base[d] + r : base[d] - 1u - r;
-            SA[dst] = val[k];
+            const uint32_t j = val[k];
+            WT nw = wnd[k];
+            if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
+            SA[dst] = j;
+            WN[dst] = nw;
         }
     }
 }
 
-__global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
+template <class WT>
+__global__ __launch_bounds__(kBlock) void bwt_from_windows_kernel(const uint32_t *__restrict__ SA,
+                                                                  const WT *__restrict__ WN, uint64_t N, wnd_cfg cfg,
+                                                                  uint8_t *__restrict__ bwt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < N) bwt[i] = SA[i] == 0 ? (uint8_t)0 : (uint8_t)wnd_first<WT>(WN[i], cfg);
+}
+
+template <class WT> __global__ void set_entry_kernel(uint32_t *SA, WT *WN, uint32_t p, const uint8_t *T, wnd_cfg cfg)
+{
+    SA[0] = p;
+    WN[0] = p ? wnd_fill<WT>(T, p, cfg) : (WT)0;
+}
 
 } // namespace sx
 
@@ -162,64 +223,69 @@ using namespace sx;
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 {
     const uint64_t ntiles = (N + kIndTile - 1) / kIndTile;
-    return (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 3 * 1024 + 4096;
+    // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + tile histograms
+    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)sigma * ntiles * 4 + 256 + 3 * 1024 + 4096;
 }
 
 namespace {
-struct induce_state {
+template <class WT> struct induce_state {
     sx_ctx *ctx;
     const uint8_t *T;
     uint32_t *SA;
-    uint8_t *tmpch;
+    WT *WN;
     uint32_t *hist, *cursor, *base, *ctl;
-    uint32_t sigma;
+    uint32_t nk;
     int small_alphabet;
+    wnd_cfg cfg;
 };
 
-// one stable multi-way split; returns the number of entries appended to bucket c
-int induce_round(induce_state &st, const uint32_t *src, uint32_t len, int rev, int mode, uint32_t c, int dir,
-                 uint32_t *added_c)
+// one stable multi-way split; *added_c = number of entries appended to bucket c
+template <class WT>
+int induce_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, uint32_t len, int rev, int mode,
+                 uint32_t c, int dir, uint32_t *added_c)
 {
     sx_ctx *ctx = st.ctx;
     const uint32_t ntiles = sx_div_up(len, kIndTile);
-    sx_launch(ctx, SX_KC_INDUCE_GATHER, (uint64_t)len * 6, induce_gather_kernel, dim3(ntiles), dim3(kBlock), src,
-              len, rev, st.T, mode, c, st.tmpch, st.hist, ntiles, st.sigma);
-    sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)ntiles * st.sigma * 8, induce_offsets_kernel, dim3(st.sigma),
-              dim3(kBlock), st.hist, ntiles, st.cursor, st.base, dir, c, st.ctl);
+    const uint64_t eb = 4 + sizeof(WT);
+    sx_launch(ctx, SX_KC_INDUCE_GATHER, (uint64_t)len * eb, induce_count_kernel<WT>, dim3(ntiles), dim3(kBlock), srcP,
+              srcW, len, rev, mode, c, st.cfg, st.hist, ntiles, st.nk);
+    sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)ntiles * st.nk * 8, induce_offsets_kernel, dim3(st.nk), dim3(kBlock),
+              st.hist, ntiles, st.cursor, st.base, dir, c, st.ctl);
     if (st.small_alphabet)
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, (uint64_t)len * 9, induce_scatter_kernel<3>, dim3(ntiles),
-                  dim3(kBlock), src, len, rev, (const uint8_t *)st.tmpch, mode, c, (const uint32_t *)st.hist,
-                  ntiles, (const uint32_t *)st.base, dir, st.SA, st.sigma);
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, (uint64_t)len * eb * 2, induce_scatter_kernel<WT, 3>, dim3(ntiles),
+                  dim3(kBlock), srcP, srcW, len, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, ntiles,
+                  (const uint32_t *)st.base, dir, st.SA, st.WN, st.nk);
     else
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, (uint64_t)len * 9, induce_scatter_kernel<8>, dim3(ntiles),
-                  dim3(kBlock), src, len, rev, (const uint8_t *)st.tmpch, mode, c, (const uint32_t *)st.hist,
-                  ntiles, (const uint32_t *)st.base, dir, st.SA, st.sigma);
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, (uint64_t)len * eb * 2, induce_scatter_kernel<WT, 8>, dim3(ntiles),
+                  dim3(kBlock), srcP, srcW, len, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, ntiles,
+                  (const uint32_t *)st.base, dir, st.SA, st.WN, st.nk);
     ctx->stats.induce_rounds++;
     if (added_c) SX_TRY(sx_readback(ctx, st.ctl, 1, added_c));
     return 0;
 }
-} // namespace
 
-int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
-              sx_arena &arena)
+template <class WT>
+int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
+                 uint8_t *bwt_out, sx_arena &arena, wnd_cfg cfg)
 {
     const uint64_t N = ti.N;
-    if (N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "induce: n exceeds 32-bit positions");
     // buckets that hold anything: 0 .. maxc
     const uint32_t nk = ti.maxc + 1 < sigma ? ti.maxc + 1 : sigma;
-    induce_state st;
+    induce_state<WT> st;
     st.ctx = ctx;
     st.T = ti.T;
     st.SA = SA;
-    st.sigma = nk;
+    st.nk = nk;
     st.small_alphabet = nk <= 8;
+    st.cfg = cfg;
     const uint64_t max_tiles = (N + kIndTile - 1) / kIndTile;
-    st.tmpch = arena.take<uint8_t>(N);
+    st.WN = arena.take<WT>(N);
+    WT *seedW = arena.take<WT>(ti.m ? ti.m : 1);
     st.hist = arena.take<uint32_t>((size_t)nk * max_tiles);
     st.cursor = arena.take<uint32_t>(256);
     st.base = arena.take<uint32_t>(256);
     st.ctl = arena.take<uint32_t>(16);
-    if (!st.tmpch || !st.hist || !st.cursor || !st.base || !st.ctl)
+    if (!st.WN || !seedW || !st.hist || !st.cursor || !st.base || !st.ctl)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
 
     // bucket boundaries on the host (sa_is.c:176-201)
@@ -231,8 +297,11 @@ int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_
         lms_off[c + 1] = lms_off[c] + ti.h_lms[c];
     }
 
+    // windows of the sorted LMS suffixes: the only systematic text access of both passes
+    sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.m * (4 + sizeof(WT) + 16), fill_windows_kernel<WT>,
+              dim3(sx_div_up(ti.m, kBlock)), dim3(kBlock), ti.T, sorted_lms, ti.m, cfg, seedW);
     // the sentinel suffix (sa_is.c:463: SA[0] = n)
-    sx_launch(ctx, SX_KC_MISC, 0, set_u32_kernel, dim3(1), dim3(1), SA, (uint32_t)ti.n);
+    sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, (uint32_t)ti.n, ti.T, cfg);
 
     // ---- L pass: buckets ascending, cursors at the bucket heads ------------------------
     SX_CHECK(hipMemcpyAsync(st.cursor, begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -244,14 +313,15 @@ int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_
         uint32_t lo = begin[c], hi = head_c;
         while (hi > lo) {
             uint32_t added = 0;
-            SX_TRY(induce_round(st, SA + lo, hi - lo, 0, MODE_L_FROM_L, c, +1, &added));
+            SX_TRY(induce_round<WT>(st, SA + lo, st.WN + lo, hi - lo, 0, MODE_L_FROM_L, c, +1, &added));
             lo = hi;
             hi += added;
         }
         if (hi - begin[c] != ti.h_l[c])
             return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
         if (ti.h_lms[c])
-            SX_TRY(induce_round(st, sorted_lms + lms_off[c], ti.h_lms[c], 0, MODE_L_FROM_LMS, c, +1, nullptr));
+            SX_TRY(induce_round<WT>(st, sorted_lms + lms_off[c], seedW + lms_off[c], ti.h_lms[c], 0, MODE_L_FROM_LMS, c,
+                                    +1, nullptr));
     }
 
     // ---- S pass: buckets descending, cursors at the bucket ends -------------------------
@@ -266,7 +336,7 @@ int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_
         uint32_t lo = tail_c, hi = end_c;
         while (hi > lo) {
             uint32_t added = 0;
-            SX_TRY(induce_round(st, SA + lo, hi - lo, 1, MODE_S_FROM_S, c, -1, &added));
+            SX_TRY(induce_round<WT>(st, SA + lo, st.WN + lo, hi - lo, 1, MODE_S_FROM_S, c, -1, &added));
             hi = lo;
             lo -= added;
         }
@@ -274,7 +344,31 @@ int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_
         if (c > 0 && end_c - lo != n_s)
             return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
         if (ti.h_l[c])
-            SX_TRY(induce_round(st, SA + begin[c], ti.h_l[c], 1, MODE_S_FROM_L, c, -1, nullptr));
+            SX_TRY(induce_round<WT>(st, SA + begin[c], st.WN + begin[c], ti.h_l[c], 1, MODE_S_FROM_L, c, -1, nullptr));
     }
+
+    // the windows now hold text[SA[i]-1] for every slot: the BWT for free (bwt.c:13-20)
+    if (bwt_out)
+        sx_launch(ctx, SX_KC_BWT_GATHER, N * (4 + sizeof(WT) + 1), bwt_from_windows_kernel<WT>,
+                  dim3(sx_div_up(N, kBlock)), dim3(kBlock), (const uint32_t *)SA, (const WT *)st.WN, N, cfg, bwt_out);
     return 0;
+}
+} // namespace
+
+int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
+              uint8_t *bwt_out, sx_arena &arena)
+{
+    if (ti.N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "induce: n exceeds 32-bit positions");
+    wnd_cfg cfg;
+    cfg.B = (uint32_t)sx_bitlen(ti.maxc > 0 ? ti.maxc - 1 : 0);
+    if (cfg.B < 1) cfg.B = 1;
+    cfg.mask = (1u << cfg.B) - 1u;
+    if (cfg.B <= 4) {
+        cfg.CW = (32 - kCntBits) / cfg.B;
+        if (cfg.CW > 15) cfg.CW = 15;
+        return induce_typed<uint32_t>(ctx, ti, sigma, sorted_lms, SA, bwt_out, arena, cfg);
+    }
+    cfg.CW = (64 - kCntBits) / cfg.B;
+    if (cfg.CW > 15) cfg.CW = 15;
+    return induce_typed<uint64_t>(ctx, ti, sigma, sorted_lms, SA, bwt_out, arena, cfg);
 }

@@ -64,5 +64,9 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);
-int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
-              uint32_t *SA, sx_arena &arena);
+int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
+              uint8_t *bwt_out, sx_arena &arena);
+
+// ---- sx_build.hip / sx_bwt.hip (shared by the fused host entry point)
+int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa, uint8_t *d_bwt);
+int sx_tables_from_bwt_impl(sx_ctx *ctx, const uint8_t *d_bwt, uint64_t N, uint32_t sigma, uint32_t *d_c, uint32_t *d_o);

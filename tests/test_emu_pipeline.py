@@ -71,6 +71,24 @@ def test_bwt_tables(emu_ctx, golden):
         assert (ot == oracle.o_table(x, sa, sigma)).all(), (sigma, n)
 
 
+def test_fused_build_tables(emu_ctx, golden):
+    """sx_build_tables: the BWT handed over by the induced sort's symbol windows (incl. refills
+    when a window runs dry: long runs, monotone stretches, byte alphabets)"""
+    import stralg_amd
+    for name in ("ref/mississippi", "struct/all-a", "struct/decreasing", "struct/runs", "ref/fasta1"):
+        c = golden[name]
+        t = stralg_amd.build_complete_table(bytes(c["raw"]), True, emu_ctx)
+        assert (t.sa.array == c["sa"]).all() and (t.c_table == c["c"]).all(), name
+        assert (t.o_table == c["o"]).all() and (t.ro_table == c["ro"]).all(), name
+    rng = np.random.default_rng(10)
+    for sigma, n in ((5, 3000), (100, 900), (17, 1500)):
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        sa, ct, ot = emu_ctx.build_tables(x, sigma)
+        want = oracle.sa_is(x, sigma)
+        assert (sa == want).all() and (ct == oracle.c_table(x, sigma)).all(), (sigma, n)
+        assert (ot == oracle.o_table(x, want, sigma)).all(), (sigma, n)
+
+
 def test_primitives(emu_ctx):
     rng = np.random.default_rng(1)
     n = 5000

@@ -183,6 +183,29 @@ def test_benchmark_shaped_against_oracle(gpu_ctx, sigma, n):
         assert (o == oracle.o_table(x[: 1 << 20], oracle.sa_is(x[: 1 << 20], sigma), sigma)).all()
 
 
+def test_fused_sa_bwt_tables(gpu_ctx):
+    """sx_sa_bwt_build_dev + sx_bwt_tables_from_bwt_dev (what bench.py times) and sx_build_tables"""
+    import torch
+    rng = np.random.default_rng(16)
+    for sigma, n in ((5, 1 << 20), (5, 1023), (4, 77), (17, 50_000), (128, 20_000), (200, 30_000)):
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        want = oracle.sa_is(x, sigma)
+        d = torch.from_numpy(x).cuda()
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+        gpu_ctx.sa_bwt_build_dev(d, n, sigma, sa, bw)
+        assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n)
+        assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), (sigma, n)
+        if sigma <= 128:
+            c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
+            o = torch.empty((n + 2) * sigma, dtype=torch.int32, device="cuda")
+            gpu_ctx.bwt_tables_from_bwt_dev(bw, n + 1, sigma, c, o)
+            assert (c.cpu().numpy().view(np.uint32) == oracle.c_table(x, sigma)).all(), (sigma, n)
+            assert (o.cpu().numpy().view(np.uint32).reshape(n + 2, sigma) == oracle.o_table(x, want, sigma)).all()
+            sa2, c2, o2 = gpu_ctx.build_tables(x, sigma)
+            assert (sa2 == want).all() and (o2 == oracle.o_table(x, want, sigma)).all(), (sigma, n)
+
+
 def test_wide_alphabet_tables(gpu_ctx):
     rng = np.random.default_rng(6)
     for sigma, n in ((9, 5000), (21, 70_000), (128, 30_000)):
@@ -279,6 +302,11 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
         o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
         bw = torch.empty(N, dtype=torch.uint8, device="cuda")
         gpu_ctx.bwt_tables_dev(text, sa, N, sigma, c, o, bw)
+        # the fused build must hand over the same BWT
+        sa2, bw2 = torch.empty_like(sa), torch.empty_like(bw)
+        gpu_ctx.sa_bwt_build_dev(text, n, sigma, sa2, bw2)
+        assert bool((sa2 == sa).all()) and bool((bw2 == bw).all())
+        del sa2, bw2
         counts = torch.bincount(text.long(), minlength=sigma)
         counts[0] += 1
         want_c = torch.cumsum(counts, 0) - counts
