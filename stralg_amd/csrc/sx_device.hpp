@@ -98,6 +98,49 @@ __device__ __forceinline__ uint32_t wave_rank_step(uint32_t digit, bool valid, u
     return old + r;
 }
 
+// ---- unaligned byte windows of the text from aligned 16-byte loads ------------------
+// (the text buffer is 256-byte aligned and padded, so the chunk after the last
+// byte wanted is always readable)
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t r)
+{
+    return r ? (lo >> r) | (hi << (64u - r)) : lo;
+}
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
+// bytes [p, p+16) as two little-endian u64
+__device__ __forceinline__ void load_bytes16(const uint8_t *__restrict__ T, uint64_t p, uint64_t &o0, uint64_t &o1)
+{
+    const uint64_t base = p & ~(uint64_t)15;
+    const uint32_t s = (uint32_t)(p & 15);
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(T + base);
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(T + base + 16);
+    const uint64_t q0 = pack64(v0.x, v0.y), q1 = pack64(v0.z, v0.w), q2 = pack64(v1.x, v1.y), q3 = pack64(v1.z, v1.w);
+    const bool up = s >= 8;
+    const uint64_t a = up ? q1 : q0, b = up ? q2 : q1, c = up ? q3 : q2;
+    const uint32_t r = 8u * (s & 7u);
+    o0 = funnel64(a, b, r);
+    o1 = funnel64(b, c, r);
+}
+
+// bytes [p, p+32) as four little-endian u64
+__device__ __forceinline__ void load_bytes32(const uint8_t *__restrict__ T, uint64_t p, uint64_t (&o)[4])
+{
+    const uint64_t base = p & ~(uint64_t)15;
+    const uint32_t s = (uint32_t)(p & 15);
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(T + base);
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(T + base + 16);
+    const uint4 v2 = *reinterpret_cast<const uint4 *>(T + base + 32);
+    const uint64_t q0 = pack64(v0.x, v0.y), q1 = pack64(v0.z, v0.w), q2 = pack64(v1.x, v1.y), q3 = pack64(v1.z, v1.w),
+                   q4 = pack64(v2.x, v2.y), q5 = pack64(v2.z, v2.w);
+    const bool up = s >= 8;
+    const uint64_t a = up ? q1 : q0, b = up ? q2 : q1, c = up ? q3 : q2, d = up ? q4 : q3, e = up ? q5 : q4;
+    const uint32_t r = 8u * (s & 7u);
+    o[0] = funnel64(a, b, r);
+    o[1] = funnel64(b, c, r);
+    o[2] = funnel64(c, d, r);
+    o[3] = funnel64(d, e, r);
+}
+
 // In-place exclusive prefix sum of row[0..count) by one workgroup; returns the total.
 __device__ __forceinline__ uint32_t block_scan_row_inplace(uint32_t *__restrict__ row, uint64_t count,
                                                            uint32_t *lds)

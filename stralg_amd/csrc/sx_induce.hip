@@ -73,8 +73,17 @@ template <class WT>
 __device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p, const wnd_cfg &c)
 {
     const uint32_t cnt = p < c.CW ? p : c.CW;
+    // text[p-cnt .. p-1]: two aligned 16-byte loads, bytes picked with static indices
+    uint64_t lo, hi;
+    load_bytes16(T, (uint64_t)(p - cnt), lo, hi);
     WT acc = 0;
-    for (uint32_t k = cnt; k-- > 0;) acc = (acc << c.B) | (WT)(T[p - 1u - k] - 1u);
+#pragma unroll
+    for (uint32_t i = 0; i < 15; ++i) {
+        if (i < cnt) {
+            const uint64_t byte = ((i < 8 ? lo : hi) >> (8u * (i & 7u))) & 0xFFull;
+            acc = (acc << c.B) | (WT)(byte - 1u); // ends with text[p-1] in the lowest field
+        }
+    }
     return (acc << kCntBits) | (WT)cnt;
 }
 

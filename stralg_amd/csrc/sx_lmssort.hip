@@ -25,22 +25,17 @@
 namespace sx {
 
 // C symbols starting at text position p, packed most-significant first.
-// Reads three aligned 16-byte chunks when C <= 32, byte loads otherwise.
+// Three aligned 16-byte loads when C <= 32 (statically indexed: no scratch), byte loads otherwise.
 __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, uint32_t b,
                                                uint32_t C)
 {
     uint64_t acc = 0;
     if (C <= 32) {
-        const uint64_t base = p & ~(uint64_t)15;
-        const uint32_t sh = (uint32_t)(p & 15);
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(T + base);
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(T + base + 16);
-        const uint4 v2 = *reinterpret_cast<const uint4 *>(T + base + 32);
-        const uint32_t w[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-        for (uint32_t s = 0; s < C; ++s) {
-            const uint32_t o = sh + s;
-            const uint32_t ch = (w[o >> 2] >> (8 * (o & 3))) & 0xFFu;
-            acc = (acc << b) | ch;
+        uint64_t q[4];
+        load_bytes32(T, p, q);
+#pragma unroll
+        for (uint32_t s = 0; s < 32; ++s) {
+            if (s < C) acc = (acc << b) | ((q[s >> 3] >> (8u * (s & 7u))) & 0xFFull);
         }
     } else {
         for (uint32_t s = 0; s < C; ++s) acc = (acc << b) | (uint64_t)T[p + s];
