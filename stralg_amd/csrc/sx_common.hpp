@@ -50,7 +50,7 @@ struct sx_event_pair {
     int kclass;
 };
 
-enum { SX_SLAB_N = 0, SX_SLAB_M = 1, SX_SLAB_TMP = 2, SX_SLAB_BWT = 3, SX_SLAB_SCAN = 4, SX_SLAB_SORT = 5, SX_SLAB_IO = 6, SX_NSLABS = 7 };
+enum { SX_SLAB_N = 0, SX_SLAB_M = 1, SX_SLAB_TMP = 2, SX_SLAB_BWT = 3, SX_SLAB_SCAN = 4, SX_SLAB_SORT = 5, SX_SLAB_IO = 6, SX_SLAB_CHAIN = 7, SX_NSLABS = 8 };
 
 struct sx_ctx {
     int device = 0;
@@ -59,6 +59,7 @@ struct sx_ctx {
     sx_slab slab[SX_NSLABS];
     uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB)
     // profiling
+    uint32_t chain_epoch = 0; // look-back status epoch (24 bits), see sx_device.hpp
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int prof_on = 0;
     std::vector<sx_event_pair> ev_used;

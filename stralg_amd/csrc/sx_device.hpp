@@ -98,6 +98,61 @@ __device__ __forceinline__ uint32_t wave_rank_step(uint32_t digit, bool valid, u
     return old + r;
 }
 
+// ---- chained scan across workgroups (decoupled look-back) ------------------------------
+// One 8-byte status word per (tile, digit): [63:40] epoch of the launch, [39:38] state
+// (1 = the tile's own count, 2 = inclusive prefix over tiles 0..tile), [31:0] value.
+// The word is written and read whole with relaxed agent-scope 8-byte atomics, so the
+// data is its own flag: no fence and no other memory needs to become visible
+// (MI355X guide, inter-workgroup visibility: data-tagged granules).  Tiles take their
+// index from an atomic ticket, so every tile a waiter polls has already started and
+// never waits on a later one: the chain cannot deadlock whatever the residency.
+// Epochs make stale words from earlier launches inert; no per-launch memset.
+// The first kChainHeader words of the status buffer are a header: word 0 is set
+// when a wait exceeds kChainSpinLimit polls (a bug, never expected); the waiter then
+// gives up so that the grid always drains, and the host reports the error.
+constexpr uint64_t kChainValueMask = 0xFFFFFFFFull;
+constexpr uint32_t kChainHeader = 8;
+constexpr uint32_t kChainSpinLimit = 1u << 22;
+__device__ __forceinline__ uint64_t chain_pack(uint32_t epoch, uint32_t state, uint32_t value)
+{
+    return ((uint64_t)epoch << 40) | ((uint64_t)state << 38) | (uint64_t)value;
+}
+
+// Called by the thread that owns digit d of tile `tile`; returns the sum of `count`
+// over tiles [0, tile) and publishes this tile's inclusive prefix.
+__device__ __forceinline__ uint32_t chain_exclusive_prefix(uint64_t *__restrict__ status, uint32_t ndigits,
+                                                           uint32_t tile, uint32_t d, uint32_t count,
+                                                           uint32_t epoch)
+{
+    uint64_t *words = status + kChainHeader;
+    uint64_t *mine = words + (uint64_t)tile * ndigits + d;
+    if (tile == 0) {
+        __hip_atomic_store(mine, chain_pack(epoch, 2u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0u;
+    }
+    __hip_atomic_store(mine, chain_pack(epoch, 1u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prefix = 0;
+    for (uint32_t j = tile; j-- > 0;) {
+        const uint64_t *theirs = words + (uint64_t)j * ndigits + d;
+        uint64_t w;
+        uint32_t spins = 0;
+        for (;;) {
+            w = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(w >> 40) == epoch && ((w >> 38) & 3ull) != 0) break;
+            if (++spins > kChainSpinLimit) { // give up: flag it, treat the predecessor as empty
+                __hip_atomic_store(status, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = chain_pack(epoch, 2u, 0u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        prefix += (uint32_t)(w & kChainValueMask);
+        if (((w >> 38) & 3ull) == 2ull) break;
+    }
+    __hip_atomic_store(mine, chain_pack(epoch, 2u, prefix + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prefix;
+}
+
 // ---- unaligned byte windows of the text from aligned 16-byte loads ------------------
 // (the text buffer is 256-byte aligned and padded, so the chunk after the last
 // byte wanted is always readable)

@@ -98,115 +98,120 @@ __global__ __launch_bounds__(kBlock) void fill_windows_kernel(const uint8_t *__r
     out[k] = p ? wnd_fill<WT>(T, p, cfg) : (WT)0;
 }
 
-// count accepted entries per destination bucket (no text access: the symbol is in the window)
-template <class WT>
-__global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__restrict__ srcP,
-                                                              const WT *__restrict__ srcW, uint32_t len, int rev,
-                                                              int mode, uint32_t c, wnd_cfg cfg,
-                                                              uint32_t *__restrict__ hist, uint32_t ntiles,
-                                                              uint32_t nkeys)
-{
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tile0 = blockIdx.x * (uint32_t)kIndTile;
-#pragma unroll
-    for (int k = 0; k < kIndItems; ++k) {
-        const uint32_t i = tile0 + (uint32_t)k * kBlock + threadIdx.x;
-        if (i < len) {
-            const uint32_t idx = rev ? len - 1u - i : i;
-            const uint32_t p = srcP[idx];
-            if (p != 0) {
-                const uint32_t ch = wnd_first<WT>(srcW[idx], cfg);
-                if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < nkeys) hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
-}
-
-// one workgroup per destination bucket: exclusive prefix over the tiles, cursor update
-__global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__restrict__ hist, uint32_t ntiles,
-                                                                uint32_t *__restrict__ cursor,
-                                                                uint32_t *__restrict__ base, int dir, uint32_t c,
-                                                                uint32_t *__restrict__ ctl)
-{
-    __shared__ uint32_t lds[kWavesPerBlock];
-    const uint32_t key = blockIdx.x;
-    const uint32_t carry = block_scan_row_inplace(hist + (uint64_t)key * ntiles, ntiles, lds);
-    if (threadIdx.x == 0) {
-        const uint32_t cur = cursor[key];
-        base[key] = cur;
-        cursor[key] = dir > 0 ? cur + carry : cur - carry;
-        if (key == c) ctl[0] = carry;
-    }
-}
-
-// stable scatter of p-1 (with its popped window) to the bucket cursors
+// ---- one round = one launch -----------------------------------------------------------
+// Stable multi-way split of the entries in range_in (read from device memory, so rounds
+// can be queued without the host knowing their sizes): entry p with window w induces
+// p-1 into bucket text[p-1] (= the window's first symbol) when the type test accepts
+// it.  Tiles take tickets; per destination bucket the tile-local counts are chained
+// across tiles by decoupled look-back (sx_device.hpp), so the entries are read once.
+// The last tile publishes the advanced bucket cursors and the range appended to
+// bucket c, which is the next round's input.
 template <class WT, int BITS>
-__global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
-    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, uint32_t len, int rev, int mode, uint32_t c,
-    wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs, uint32_t ntiles,
-    const uint32_t *__restrict__ base, int dir, uint32_t *__restrict__ SA, WT *__restrict__ WN, uint32_t nkeys)
+__global__ __launch_bounds__(kBlock) void induce_round_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in,
+    uint32_t *__restrict__ range_out, int rev, int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
+    const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt, int dir, uint32_t *__restrict__ SA,
+    WT *__restrict__ WN, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch, uint32_t *__restrict__ ticket)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
-    __shared__ uint32_t gpos[256]; // first destination index of the tile for each bucket
+    __shared__ uint32_t gpos[256];  // entries of earlier tiles per bucket
+    __shared__ uint32_t gbase[256]; // bucket cursors at the start of the round
+    __shared__ uint32_t s_tile;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t tile0 = blockIdx.x * (uint32_t)kIndTile;
-    const uint32_t wave0 = tile0 + (uint32_t)w * (kWave * kIndItems);
-    uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
-    WT wnd[kIndItems];
-    bool ok[kIndItems];
-#pragma unroll
-    for (int k = 0; k < kIndItems; ++k) {
-        const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
-        ok[k] = false;
-        dig[k] = 0;
-        val[k] = 0;
-        wnd[k] = 0;
-        if (i < len) {
-            const uint32_t idx = rev ? len - 1u - i : i;
-            const uint32_t p = srcP[idx];
-            if (p != 0) {
-                const WT ww = srcW[idx];
-                const uint32_t ch = wnd_first<WT>(ww, cfg);
-                ok[k] = induce_accept(ch, c, mode);
-                dig[k] = ch;
-                val[k] = p - 1u;
-                wnd[k] = wnd_pop<WT>(ww, cfg);
+    const uint32_t lo = range_in[0], hi = range_in[1];
+    const uint32_t len = hi - lo;
+    if (len == 0) { // nothing to do: carry the cursors over, hand on an empty range
+        if (blockIdx.x == 0) {
+            cursor_nxt[t] = cursor_cur[t];
+            if (t == 0 && range_out) {
+                range_out[0] = hi;
+                range_out[1] = hi;
             }
         }
+        return;
     }
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    gbase[t] = cursor_cur[t];
+    for (;;) {
+        if (t == 0) s_tile = atomicAdd(ticket, 1u);
+        for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= ntiles) break;
+        const uint32_t wave0 = tile * (uint32_t)kIndTile + (uint32_t)w * (kWave * kIndItems);
+        uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
+        WT wnd[kIndItems];
+        bool ok[kIndItems];
 #pragma unroll
-    for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
-    __syncthreads();
-    {
-        const uint32_t d = (uint32_t)t;
-        uint32_t s = 0;
-#pragma unroll
-        for (int ww = 0; ww < kWavesPerBlock; ++ww) {
-            const uint32_t x = wcount[ww][d];
-            wcount[ww][d] = s;
-            s += x;
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            ok[k] = false;
+            dig[k] = 0;
+            val[k] = 0;
+            wnd[k] = 0;
+            if (i < len) {
+                const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                const uint32_t p = srcP[idx];
+                if (p != 0) {
+                    const WT ww = srcW[idx];
+                    const uint32_t ch = wnd_first<WT>(ww, cfg);
+                    ok[k] = induce_accept(ch, c, mode);
+                    dig[k] = ch;
+                    val[k] = p - 1u;
+                    wnd[k] = wnd_pop<WT>(ww, cfg);
+                }
+            }
         }
-        gpos[d] = d < nkeys ? offs[(uint64_t)d * ntiles + blockIdx.x] : 0u;
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
+        __syncthreads();
+        {
+            const uint32_t d = (uint32_t)t;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+                const uint32_t x = wcount[ww][d];
+                wcount[ww][d] = cnt;
+                cnt += x;
+            }
+            uint32_t excl = 0;
+            if (d < nkeys) excl = chain_exclusive_prefix(status, nkeys, tile, d, cnt, epoch);
+            gpos[d] = excl;
+            if (tile == ntiles - 1) {
+                const uint32_t total = excl + cnt, cur = gbase[d];
+                cursor_nxt[d] = dir > 0 ? cur + total : cur - total;
+                if (d == c && range_out) {
+                    range_out[0] = dir > 0 ? cur : cur - total;
+                    range_out[1] = dir > 0 ? cur + total : cur;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            if (ok[k]) {
+                const uint32_t d = dig[k];
+                const uint32_t r = gpos[d] + wcount[w][d] + rnk[k];
+                const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
+                const uint32_t j = val[k];
+                WT nw = wnd[k];
+                if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
+                SA[dst] = j;
+                WN[dst] = nw;
+            }
+        }
+        __syncthreads(); // LDS is reused by the next tile
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kIndItems; ++k) {
-        if (ok[k]) {
-            const uint32_t d = dig[k];
-            const uint32_t r = gpos[d] + wcount[w][d] + rnk[k];
-            const uint32_t dst = dir > 0 ? base[d] + r : base[d] - 1u - r;
-            const uint32_t j = val[k];
-            WT nw = wnd[k];
-            if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
-            SA[dst] = j;
-            WN[dst] = nw;
-        }
+}
+
+// range <- [lo, hi) given by the host, or [a, cursor[c]) / [cursor[c], b) for the first round of a bucket
+__global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, const uint32_t *cursor, int c, int which)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (which == 1) hi = cursor[c];      // L pass: [bucket begin, head cursor)
+        else if (which == 2) lo = cursor[c]; // S pass: [tail cursor, bucket end)
+        range[0] = lo;
+        range[1] = hi;
     }
 }
 
@@ -231,46 +236,91 @@ using namespace sx;
 
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 {
-    const uint64_t ntiles = (N + kIndTile - 1) / kIndTile;
-    // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + tile histograms
-    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)sigma * ntiles * 4 + 256 + 3 * 1024 + 4096;
+    (void)sigma;
+    // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + control block
+    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + 16384;
 }
 
 namespace {
+constexpr int kMaxSpec = 16; // rounds queued per batch before the host looks at the range
+
 template <class WT> struct induce_state {
     sx_ctx *ctx;
     const uint8_t *T;
     uint32_t *SA;
     WT *WN;
-    uint32_t *hist, *cursor, *base, *ctl;
+    uint32_t *cursor[2]; // ping-pong: a round reads one, its last tile writes the other
+    uint32_t *ranges;    // (kMaxSpec + 2) x {lo, hi}
+    uint32_t *tickets;   // kMaxSpec + 2
+    uint64_t *status;
     uint32_t nk;
     int small_alphabet;
+    int par; // which cursor buffer is current
     wnd_cfg cfg;
 };
 
-// one stable multi-way split; *added_c = number of entries appended to bucket c
 template <class WT>
-int induce_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, uint32_t len, int rev, int mode,
-                 uint32_t c, int dir, uint32_t *added_c)
+void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, int range_slot, int out_slot,
+                  uint32_t tiles_bound, int rev, int mode, uint32_t c, int dir)
 {
     sx_ctx *ctx = st.ctx;
-    const uint32_t ntiles = sx_div_up(len, kIndTile);
-    const uint64_t eb = 4 + sizeof(WT);
-    sx_launch(ctx, SX_KC_INDUCE_GATHER, (uint64_t)len * eb, induce_count_kernel<WT>, dim3(ntiles), dim3(kBlock), srcP,
-              srcW, len, rev, mode, c, st.cfg, st.hist, ntiles, st.nk);
-    sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)ntiles * st.nk * 8, induce_offsets_kernel, dim3(st.nk), dim3(kBlock),
-              st.hist, ntiles, st.cursor, st.base, dir, c, st.ctl);
+    uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
+    if (grid > 4096) grid = 4096; // tiles are handed out by ticket: any grid size is correct
+    if (ctx->chain_epoch + 1 >= (1u << 24)) { // 24-bit epochs are about to wrap: retire every old status word
+        (void)hipMemsetAsync(st.status, 0, ctx->slab[SX_SLAB_CHAIN].cap, ctx->stream);
+        ctx->chain_epoch = 0;
+    }
+    ++ctx->chain_epoch;
+    uint32_t *rin = st.ranges + 2 * range_slot;
+    uint32_t *rout = out_slot >= 0 ? st.ranges + 2 * out_slot : nullptr;
+    const uint64_t eb = (uint64_t)tiles_bound * kIndTile * (4 + sizeof(WT));
     if (st.small_alphabet)
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, (uint64_t)len * eb * 2, induce_scatter_kernel<WT, 3>, dim3(ntiles),
-                  dim3(kBlock), srcP, srcW, len, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, ntiles,
-                  (const uint32_t *)st.base, dir, st.SA, st.WN, st.nk);
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb, induce_round_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.cursor[st.par],
+                  st.cursor[st.par ^ 1], dir, st.SA, st.WN, st.nk, st.status, ctx->chain_epoch,
+                  st.tickets + range_slot);
     else
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, (uint64_t)len * eb * 2, induce_scatter_kernel<WT, 8>, dim3(ntiles),
-                  dim3(kBlock), srcP, srcW, len, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, ntiles,
-                  (const uint32_t *)st.base, dir, st.SA, st.WN, st.nk);
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb, induce_round_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.cursor[st.par],
+                  st.cursor[st.par ^ 1], dir, st.SA, st.WN, st.nk, st.status, ctx->chain_epoch,
+                  st.tickets + range_slot);
+    st.par ^= 1;
     ctx->stats.induce_rounds++;
-    if (added_c) SX_TRY(sx_readback(ctx, st.ctl, 1, added_c));
-    return 0;
+}
+
+// all rounds of one region of bucket c: the first range comes from the cursor, every
+// round appends to bucket c what the next round reads; batches of queued rounds, one
+// host look per batch
+template <class WT>
+int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_entries, int rev, int mode, uint32_t c,
+                    int dir, int which, uint32_t *total_in_region)
+{
+    sx_ctx *ctx = st.ctx;
+    const int spec = st.small_alphabet ? kMaxSpec : 6;
+    bool first = true;
+    uint32_t bound_tiles = sx_div_up(region_entries ? region_entries : 1, kIndTile);
+    for (;;) {
+        SX_CHECK(hipMemsetAsync(st.tickets, 0, (kMaxSpec + 2) * sizeof(uint32_t), ctx->stream));
+        if (first)
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
+                      (const uint32_t *)st.cursor[st.par], (int)c, which);
+        for (int k = 0; k < spec; ++k) {
+            uint32_t tb = bound_tiles >> k;
+            const uint32_t floor_tiles = bound_tiles < 256 ? bound_tiles : 256;
+            if (tb < floor_tiles) tb = floor_tiles;
+            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, rev, mode, c, dir);
+        }
+        uint32_t r[2];
+        SX_TRY(sx_readback(ctx, st.ranges + 2 * spec, 2, r));
+        if (r[1] == r[0]) {
+            if (total_in_region) *total_in_region = dir > 0 ? r[1] : r[0];
+            return 0;
+        }
+        // a long run of symbol c: carry on from the last range
+        sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, r[0], r[1],
+                  (const uint32_t *)st.cursor[st.par], (int)c, 0);
+        first = false;
+    }
 }
 
 template <class WT>
@@ -287,23 +337,36 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.nk = nk;
     st.small_alphabet = nk <= 8;
     st.cfg = cfg;
-    const uint64_t max_tiles = (N + kIndTile - 1) / kIndTile;
+    st.par = 0;
     st.WN = arena.take<WT>(N);
     WT *seedW = arena.take<WT>(ti.m ? ti.m : 1);
-    st.hist = arena.take<uint32_t>((size_t)nk * max_tiles);
-    st.cursor = arena.take<uint32_t>(256);
-    st.base = arena.take<uint32_t>(256);
-    st.ctl = arena.take<uint32_t>(16);
-    if (!st.WN || !seedW || !st.hist || !st.cursor || !st.base || !st.ctl)
+    st.cursor[0] = arena.take<uint32_t>(256);
+    st.cursor[1] = arena.take<uint32_t>(256);
+    st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 2));
+    st.tickets = arena.take<uint32_t>(kMaxSpec + 2);
+    if (!st.WN || !seedW || !st.cursor[0] || !st.cursor[1] || !st.ranges || !st.tickets)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
 
     // bucket boundaries on the host (sa_is.c:176-201)
     uint32_t begin[257], lms_off[257];
     begin[0] = 0;
     lms_off[0] = 0;
+    uint32_t largest = 1;
     for (uint32_t c = 0; c < 256; ++c) {
         begin[c + 1] = begin[c] + ti.h_all[c];
         lms_off[c + 1] = lms_off[c] + ti.h_lms[c];
+        if (ti.h_all[c] > largest) largest = ti.h_all[c];
+    }
+    // look-back status words: one per (tile, bucket) of the largest round
+    const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 1) * nk + kChainHeader;
+    const bool fresh = ctx->slab[SX_SLAB_CHAIN].cap < status_words * 8;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_CHAIN, status_words * 8));
+    st.status = (uint64_t *)ctx->slab[SX_SLAB_CHAIN].p;
+    if (fresh) { // new memory holds arbitrary bits: start clean
+        SX_CHECK(hipMemsetAsync(st.status, 0, ctx->slab[SX_SLAB_CHAIN].cap, ctx->stream));
+        ctx->chain_epoch = 0;
+    } else {
+        SX_CHECK(hipMemsetAsync(st.status, 0, sizeof(uint64_t), ctx->stream)); // the time-out word
     }
 
     // windows of the sorted LMS suffixes: the only systematic text access of both passes
@@ -313,49 +376,49 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, (uint32_t)ti.n, ti.T, cfg);
 
     // ---- L pass: buckets ascending, cursors at the bucket heads ------------------------
-    SX_CHECK(hipMemcpyAsync(st.cursor, begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    SX_CHECK(hipStreamSynchronize(ctx->stream));
+    SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     for (uint32_t c = 0; c < nk; ++c) {
         if (ti.h_all[c] == 0) continue;
-        uint32_t head_c = begin[c];
-        if (c > 0) SX_TRY(sx_readback(ctx, st.cursor + c, 1, &head_c));
-        uint32_t lo = begin[c], hi = head_c;
-        while (hi > lo) {
-            uint32_t added = 0;
-            SX_TRY(induce_round<WT>(st, SA + lo, st.WN + lo, hi - lo, 0, MODE_L_FROM_L, c, +1, &added));
-            lo = hi;
-            hi += added;
+        if (ti.h_l[c]) {
+            uint32_t head_end = 0;
+            SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end));
+            if (head_end - begin[c] != ti.h_l[c])
+                return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
         }
-        if (hi - begin[c] != ti.h_l[c])
-            return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
-        if (ti.h_lms[c])
-            SX_TRY(induce_round<WT>(st, sorted_lms + lms_off[c], seedW + lms_off[c], ti.h_lms[c], 0, MODE_L_FROM_LMS, c,
-                                    +1, nullptr));
+        if (ti.h_lms[c]) {
+            SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
+                      (const uint32_t *)st.cursor[st.par], (int)c, 0);
+            launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), 0, MODE_L_FROM_LMS, c, +1);
+        }
     }
 
     // ---- S pass: buckets descending, cursors at the bucket ends -------------------------
-    SX_CHECK(hipMemcpyAsync(st.cursor, begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    SX_CHECK(hipStreamSynchronize(ctx->stream));
+    SX_CHECK(hipStreamSynchronize(ctx->stream)); // `begin` is about to be reused as the upload source
+    SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     for (uint32_t cc = nk; cc-- > 0;) {
         const uint32_t c = cc;
         if (ti.h_all[c] == 0) continue;
-        const uint32_t end_c = begin[c + 1];
-        uint32_t tail_c = end_c;
-        SX_TRY(sx_readback(ctx, st.cursor + c, 1, &tail_c));
-        uint32_t lo = tail_c, hi = end_c;
-        while (hi > lo) {
-            uint32_t added = 0;
-            SX_TRY(induce_round<WT>(st, SA + lo, st.WN + lo, hi - lo, 1, MODE_S_FROM_S, c, -1, &added));
-            hi = lo;
-            lo -= added;
-        }
         const uint32_t n_s = ti.h_all[c] - ti.h_l[c];
-        if (c > 0 && end_c - lo != n_s)
-            return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
-        if (ti.h_l[c])
-            SX_TRY(induce_round<WT>(st, SA + begin[c], st.WN + begin[c], ti.h_l[c], 1, MODE_S_FROM_L, c, -1, nullptr));
+        if (c > 0 && n_s) {
+            uint32_t tail_end = 0;
+            SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end));
+            if (begin[c + 1] - tail_end != n_s)
+                return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
+        }
+        if (ti.h_l[c]) {
+            SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
+                      begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0);
+            launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), 1, MODE_S_FROM_L, c, -1);
+        }
     }
 
+    {
+        uint32_t timed_out[2] = {0, 0};
+        SX_TRY(sx_readback(ctx, (const uint32_t *)st.status, 2, timed_out));
+        if (timed_out[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a look-back wait timed out");
+    }
     // the windows now hold text[SA[i]-1] for every slot: the BWT for free (bwt.c:13-20)
     if (bwt_out)
         sx_launch(ctx, SX_KC_BWT_GATHER, N * (4 + sizeof(WT) + 1), bwt_from_windows_kernel<WT>,

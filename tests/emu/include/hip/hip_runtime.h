@@ -154,6 +154,14 @@ static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 
+#define __ATOMIC_RELAXED_EMU 0
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+template <class T> static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
+template <class T, class V> static inline void __hip_atomic_store(T *p, V v, int, int) { *p = (T)v; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
+
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicSub(T *p, T v) { T o = *p; *p = o - v; return o; }
 template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
