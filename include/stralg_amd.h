@@ -46,6 +46,7 @@ enum {
     SX_KC_INDUCE_GATHER,  /* induce: gather text[SA[i]-1] + per-tile bucket histogram      */
     SX_KC_INDUCE_SCAN,    /* induce: per-bucket offsets                                    */
     SX_KC_INDUCE_SCATTER, /* induce: stable scatter to bucket cursors     sa_is.c:220-263 */
+    SX_KC_INDUCE_CHAIN,   /* induce: small rounds, one chained launch (count + look-back + scatter) */
     SX_KC_BWT_GATHER,     /* bwt[i] = text[SA[i]-1] + per-tile symbol counts bwt.c:13-20  */
     SX_KC_OTABLE,         /* O-table rows                                 bwt.c:47-65     */
     SX_KC_MISC,
@@ -81,7 +82,8 @@ const char *sx_last_error(const sx_ctx *ctx);
 void sx_ctx_trim(sx_ctx *ctx);
 /* behaviour switches (testing / measurement) */
 enum {
-    SX_FLAG_FORCE_GENERAL_PATH = 1 /* skip the prefix-key LMS sort: always pieces + names + prefix doubling */
+    SX_FLAG_FORCE_GENERAL_PATH = 1, /* skip the prefix-key LMS sort: always pieces + names + prefix doubling */
+    SX_FLAG_CHAIN_MAX_ENTRIES = 2   /* induce rounds up to this many entries use the single chained launch */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

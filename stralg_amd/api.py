@@ -147,6 +147,10 @@ class Context:
         """SX_FLAG_FORCE_GENERAL_PATH: pieces + names + prefix doubling even where the prefix-key sort would do."""
         self._check(self.lib.sx_ctx_set_flag(self.h, 1, 1 if on else 0), "sx_ctx_set_flag")
 
+    def set_chain_max_entries(self, entries):
+        """SX_FLAG_CHAIN_MAX_ENTRIES: longer induce rounds take the count / offsets / scatter launches."""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 2, int(entries)), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

@@ -6,7 +6,7 @@
 
 static const char *kClassNames[SX_KC_COUNT] = {
     "classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names",
-    "doubling", "induce_gather", "induce_scan", "induce_scatter", "bwt_gather", "otable", "misc",
+    "doubling", "induce_gather", "induce_scan", "induce_scatter", "induce_chain", "bwt_gather", "otable", "misc",
 };
 
 int sx_fail(sx_ctx *ctx, int code, const char *what, const char *file, int line)
@@ -166,6 +166,11 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     if (!ctx) return SX_E_ARG;
     if (flag == SX_FLAG_FORCE_GENERAL_PATH) {
         ctx->force_general = value ? 1 : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_CHAIN_MAX_ENTRIES) {
+        if (value < 0) return SX_E_ARG;
+        ctx->chain_max_entries = (uint32_t)value;
         return 0;
     }
     return SX_E_ARG;

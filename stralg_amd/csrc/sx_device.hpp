@@ -131,25 +131,93 @@ __device__ __forceinline__ uint32_t chain_exclusive_prefix(uint64_t *__restrict_
         return 0u;
     }
     __hip_atomic_store(mine, chain_pack(epoch, 1u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Walk back over the predecessors, kChainBatch status words in flight at a time (the
+    // first wave of tiles of a launch starts together, so early walks are long: without
+    // the batching every step would cost a full L2 round trip).
+    constexpr int kChainBatch = 8;
     uint32_t prefix = 0;
-    for (uint32_t j = tile; j-- > 0;) {
-        const uint64_t *theirs = words + (uint64_t)j * ndigits + d;
-        uint64_t w;
-        uint32_t spins = 0;
-        for (;;) {
-            w = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(w >> 40) == epoch && ((w >> 38) & 3ull) != 0) break;
-            if (++spins > kChainSpinLimit) { // give up: flag it, treat the predecessor as empty
-                __hip_atomic_store(status, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w = chain_pack(epoch, 2u, 0u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
+    bool done = false;
+    uint32_t j = tile; // predecessors still to visit: j-1, j-2, ...
+    while (!done && j > 0) {
+        uint64_t w[kChainBatch];
+#pragma unroll
+        for (int i = 0; i < kChainBatch; ++i) {
+            const uint32_t idx = j > (uint32_t)i ? j - 1u - (uint32_t)i : 0u;
+            w[i] = __hip_atomic_load(words + (uint64_t)idx * ndigits + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        prefix += (uint32_t)(w & kChainValueMask);
-        if (((w >> 38) & 3ull) == 2ull) break;
+#pragma unroll
+        for (int i = 0; i < kChainBatch; ++i) {
+            if (!done && j > (uint32_t)i) {
+                const uint64_t *theirs = words + (uint64_t)(j - 1u - (uint32_t)i) * ndigits + d;
+                uint64_t x = w[i];
+                uint32_t spins = 0;
+                while ((uint32_t)(x >> 40) != epoch || ((x >> 38) & 3ull) == 0) {
+                    if (++spins > kChainSpinLimit) { // give up: flag it, treat the predecessor as empty
+                        __hip_atomic_store(status, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        x = chain_pack(epoch, 2u, 0u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    x = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                prefix += (uint32_t)(x & kChainValueMask);
+                if (((x >> 38) & 3ull) == 2ull) done = true;
+            }
+        }
+        j = j > (uint32_t)kChainBatch ? j - (uint32_t)kChainBatch : 0u;
     }
     __hip_atomic_store(mine, chain_pack(epoch, 2u, prefix + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prefix;
+}
+
+// Wave-wide form for small digit counts: the whole wave (all 64 lanes must call) looks
+// back 64 predecessors of digit d at a time, so the walk over the tiles that started
+// together with this one takes tiles/64 steps instead of tiles/8.
+__device__ __forceinline__ uint32_t chain_exclusive_prefix_wave(uint64_t *__restrict__ status, uint32_t ndigits,
+                                                                uint32_t tile, uint32_t d, uint32_t count,
+                                                                uint32_t epoch)
+{
+    uint64_t *words = status + kChainHeader;
+    uint64_t *mine = words + (uint64_t)tile * ndigits + d;
+    const int lane = lane_id();
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(mine, chain_pack(epoch, 2u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0u;
+    }
+    if (lane == 0) __hip_atomic_store(mine, chain_pack(epoch, 1u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prefix = 0;
+    uint32_t base = tile; // predecessors still to visit: base-1, base-2, ...
+    for (;;) {
+        const bool valid = base > (uint32_t)lane;
+        const uint64_t *theirs = words + (uint64_t)(valid ? base - 1u - (uint32_t)lane : 0u) * ndigits + d;
+        uint64_t x = valid ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        uint32_t spins = 0;
+        for (;;) {
+            const bool ready = !valid || ((uint32_t)(x >> 40) == epoch && ((x >> 38) & 3ull) != 0);
+            if (!__any(ready ? 0 : 1)) break;
+            if (!ready) {
+                if (++spins > kChainSpinLimit) { // give up: flag it, treat the predecessor as empty
+                    __hip_atomic_store(status, (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x = chain_pack(epoch, 2u, 0u);
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        const bool incl = valid && ((x >> 38) & 3ull) == 2ull;
+        const uint64_t incl_mask = __ballot(incl ? 1 : 0);
+        // nearest predecessor holding an inclusive prefix = lowest lane in the mask
+        const int stop = incl_mask ? (__ffsll((unsigned long long)incl_mask) - 1) : 63;
+        uint32_t v = (valid && lane <= stop) ? (uint32_t)(x & kChainValueMask) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        prefix += v;
+        if (incl_mask) break;
+        base -= (uint32_t)kWave; // no inclusive word among 64 predecessors: base > 64 here (tile 0 is always inclusive)
+    }
+    if (lane == 0)
+        __hip_atomic_store(mine, chain_pack(epoch, 2u, prefix + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return prefix;
 }
 

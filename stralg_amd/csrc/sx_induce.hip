@@ -98,6 +98,146 @@ __global__ __launch_bounds__(kBlock) void fill_windows_kernel(const uint8_t *__r
     out[k] = p ? wnd_fill<WT>(T, p, cfg) : (WT)0;
 }
 
+// ---- large rounds: count, offsets, scatter ----------------------------------------------
+// A round whose range is longer than chain_max entries is split in three launches (the
+// entries are read twice); shorter rounds take the single chained launch below, whose
+// look-back walk costs a few microseconds per tile and would dominate a long round.
+// Both forms are queued for every round; each checks the range and returns at once when
+// the round belongs to the other.
+// (threshold: sx_ctx::chain_max_entries, default 256 tiles; SX_FLAG_CHAIN_MAX_ENTRIES)
+
+template <class WT>
+__global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__restrict__ srcP,
+                                                              const WT *__restrict__ srcW,
+                                                              const uint32_t *__restrict__ range_in, int rev,
+                                                              int mode, uint32_t c, wnd_cfg cfg,
+                                                              uint32_t *__restrict__ hist, uint32_t stride,
+                                                              uint32_t nkeys, uint32_t chain_max)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= chain_max) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t tile0 = tile * (uint32_t)kIndTile;
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = tile0 + (uint32_t)k * kBlock + threadIdx.x;
+            if (i < len) {
+                const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                const uint32_t p = srcP[idx];
+                if (p != 0) {
+                    const uint32_t ch = wnd_first<WT>(srcW[idx], cfg);
+                    if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nkeys) hist[(uint64_t)threadIdx.x * stride + tile] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// one workgroup per destination bucket: exclusive prefix over the tiles, cursor update
+__global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__restrict__ hist, uint32_t stride,
+                                                                const uint32_t *__restrict__ range_in,
+                                                                uint32_t *__restrict__ range_out,
+                                                                const uint32_t *__restrict__ cursor_cur,
+                                                                uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
+                                                                uint32_t chain_max)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const uint32_t len = range_in[1] - range_in[0];
+    if (len <= chain_max) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const uint32_t key = blockIdx.x;
+    const uint32_t total = block_scan_row_inplace(hist + (uint64_t)key * stride, ntiles, lds);
+    if (threadIdx.x == 0) {
+        const uint32_t cur = cursor_cur[key];
+        cursor_nxt[key] = dir > 0 ? cur + total : cur - total;
+        if (key == c && range_out) {
+            range_out[0] = dir > 0 ? cur : cur - total;
+            range_out[1] = dir > 0 ? cur + total : cur;
+        }
+    }
+}
+
+template <class WT, int BITS>
+__global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev,
+    int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs,
+    uint32_t stride, const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA,
+    WT *__restrict__ WN, uint32_t nkeys, uint32_t chain_max)
+{
+    __shared__ uint32_t wcount[kWavesPerBlock][256];
+    __shared__ uint32_t gpos[256]; // destination index of the tile's first entry, per bucket
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= chain_max) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const uint32_t base_d = t < (int)nkeys ? cursor_cur[t] : 0u;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t wave0 = tile * (uint32_t)kIndTile + (uint32_t)w * (kWave * kIndItems);
+        uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
+        WT wnd[kIndItems];
+        bool ok[kIndItems];
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            ok[k] = false;
+            dig[k] = 0;
+            val[k] = 0;
+            wnd[k] = 0;
+            if (i < len) {
+                const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                const uint32_t p = srcP[idx];
+                if (p != 0) {
+                    const WT ww = srcW[idx];
+                    const uint32_t ch = wnd_first<WT>(ww, cfg);
+                    ok[k] = induce_accept(ch, c, mode);
+                    dig[k] = ch;
+                    val[k] = p - 1u;
+                    wnd[k] = wnd_pop<WT>(ww, cfg);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
+        __syncthreads();
+        {
+            const uint32_t d = (uint32_t)t;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+                const uint32_t x = wcount[ww][d];
+                wcount[ww][d] = sum;
+                sum += x;
+            }
+            const uint32_t pre = d < nkeys ? offs[(uint64_t)d * stride + tile] : 0u;
+            gpos[d] = dir > 0 ? base_d + pre : base_d - 1u - pre;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            if (ok[k]) {
+                const uint32_t d = dig[k];
+                const uint32_t r = wcount[w][d] + rnk[k];
+                const uint32_t dst = dir > 0 ? gpos[d] + r : gpos[d] - r;
+                const uint32_t j = val[k];
+                WT nw = wnd[k];
+                if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
+                SA[dst] = j;
+                WN[dst] = nw;
+            }
+        }
+        __syncthreads(); // LDS is reused by the next tile
+    }
+}
+
 // ---- one round = one launch -----------------------------------------------------------
 // Stable multi-way split of the entries in range_in (read from device memory, so rounds
 // can be queued without the host knowing their sizes): entry p with window w induces
@@ -111,15 +251,18 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in,
     uint32_t *__restrict__ range_out, int rev, int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
     const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt, int dir, uint32_t *__restrict__ SA,
-    WT *__restrict__ WN, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch, uint32_t *__restrict__ ticket)
+    WT *__restrict__ WN, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch, uint32_t *__restrict__ ticket,
+    uint32_t chain_max)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gpos[256];  // entries of earlier tiles per bucket
     __shared__ uint32_t gbase[256]; // bucket cursors at the start of the round
+    __shared__ uint32_t tcount[256]; // this tile's entries per bucket
     __shared__ uint32_t s_tile;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const uint32_t lo = range_in[0], hi = range_in[1];
     const uint32_t len = hi - lo;
+    if (len > chain_max) return; // a large round: the three-launch form handles it
     if (len == 0) { // nothing to do: carry the cursors over, hand on an empty range
         if (blockIdx.x == 0) {
             cursor_nxt[t] = cursor_cur[t];
@@ -175,15 +318,29 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
                 cnt += x;
             }
             uint32_t excl = 0;
-            if (d < nkeys) excl = chain_exclusive_prefix(status, nkeys, tile, d, cnt, epoch);
-            gpos[d] = excl;
-            if (tile == ntiles - 1) {
-                const uint32_t total = excl + cnt, cur = gbase[d];
-                cursor_nxt[d] = dir > 0 ? cur + total : cur - total;
-                if (d == c && range_out) {
-                    range_out[0] = dir > 0 ? cur : cur - total;
-                    range_out[1] = dir > 0 ? cur + total : cur;
-                }
+            if (BITS > 3) { // one thread per bucket walks back on its own
+                if (d < nkeys) excl = chain_exclusive_prefix(status, nkeys, tile, d, cnt, epoch);
+                gpos[d] = excl;
+                tcount[d] = cnt;
+            } else {
+                tcount[d] = cnt;
+            }
+        }
+        if (BITS <= 3) { // <= 8 buckets: a whole wave walks back for each of them, 64 tiles a step
+            __syncthreads();
+            for (uint32_t d = (uint32_t)w; d < nkeys; d += kWavesPerBlock) {
+                const uint32_t excl = chain_exclusive_prefix_wave(status, nkeys, tile, d, tcount[d], epoch);
+                if (lane == 0) gpos[d] = excl;
+            }
+        }
+        __syncthreads();
+        if (tile == ntiles - 1) {
+            const uint32_t d = (uint32_t)t;
+            const uint32_t total = (d < nkeys ? gpos[d] : 0u) + tcount[d], cur = gbase[d];
+            cursor_nxt[d] = dir > 0 ? cur + total : cur - total;
+            if (d == c && range_out) {
+                range_out[0] = dir > 0 ? cur : cur - total;
+                range_out[1] = dir > 0 ? cur + total : cur;
             }
         }
         __syncthreads();
@@ -236,9 +393,9 @@ using namespace sx;
 
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 {
-    (void)sigma;
     // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + control block
-    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + 16384;
+    const uint64_t ntiles = (N + kIndTile - 1) / kIndTile + 1;
+    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)sigma * ntiles * 4 + 256 + 16384;
 }
 
 namespace {
@@ -253,6 +410,8 @@ template <class WT> struct induce_state {
     uint32_t *ranges;    // (kMaxSpec + 2) x {lo, hi}
     uint32_t *tickets;   // kMaxSpec + 2
     uint64_t *status;
+    uint32_t *hist;   // [nk][stride] tile counts of the three-launch form
+    uint32_t stride;
     uint32_t nk;
     int small_alphabet;
     int par; // which cursor buffer is current
@@ -274,16 +433,35 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     uint32_t *rin = st.ranges + 2 * range_slot;
     uint32_t *rout = out_slot >= 0 ? st.ranges + 2 * out_slot : nullptr;
     const uint64_t eb = (uint64_t)tiles_bound * kIndTile * (4 + sizeof(WT));
+    const uint32_t *cur = st.cursor[st.par];
+    uint32_t *nxt = st.cursor[st.par ^ 1];
+    const uint32_t chain_max = ctx->chain_max_entries;
+    if ((uint64_t)tiles_bound * kIndTile > chain_max) {
+        // the round may be a large one: queue the three-launch form as well
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT>, dim3(grid), dim3(kBlock), srcP, srcW,
+                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
+        sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
+                  dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
+        if (st.small_alphabet)
+            sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
+                      st.SA, st.WN, st.nk, chain_max);
+        else
+            sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
+                      st.SA, st.WN, st.nk, chain_max);
+    }
+    const uint32_t ctiles = chain_max / kIndTile + 1;
+    uint32_t cgrid = grid > ctiles ? ctiles : grid; // chained form: at most chain_max / kIndTile tiles
+    if (cgrid > 256) cgrid = 256;
     if (st.small_alphabet)
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb, induce_round_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
-                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.cursor[st.par],
-                  st.cursor[st.par ^ 1], dir, st.SA, st.WN, st.nk, st.status, ctx->chain_epoch,
-                  st.tickets + range_slot);
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
+                  ctx->chain_epoch, st.tickets + range_slot, chain_max);
     else
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb, induce_round_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
-                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.cursor[st.par],
-                  st.cursor[st.par ^ 1], dir, st.SA, st.WN, st.nk, st.status, ctx->chain_epoch,
-                  st.tickets + range_slot);
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 8>, dim3(cgrid), dim3(kBlock), srcP, srcW,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
+                  ctx->chain_epoch, st.tickets + range_slot, chain_max);
     st.par ^= 1;
     ctx->stats.induce_rounds++;
 }
@@ -358,7 +536,10 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (ti.h_all[c] > largest) largest = ti.h_all[c];
     }
     // look-back status words: one per (tile, bucket) of the largest round
-    const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 1) * nk + kChainHeader;
+    const size_t status_words = ((size_t)ctx->chain_max_entries / kIndTile + 2) * nk + kChainHeader;
+    st.stride = sx_div_up(largest, kIndTile) + 1;
+    st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
+    if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
     const bool fresh = ctx->slab[SX_SLAB_CHAIN].cap < status_words * 8;
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_CHAIN, status_words * 8));
     st.status = (uint64_t *)ctx->slab[SX_SLAB_CHAIN].p;

@@ -56,6 +56,19 @@ def test_both_lms_paths(emu_ctx):
     assert (1, False) in seen and (1, True) in seen and any(p == 2 for p, _ in seen)
 
 
+def test_both_induce_round_forms(emu_ctx):
+    """large rounds (count / offsets / scatter launches) and small rounds (one chained launch)"""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([np.full(5000, 1, np.uint8), rng.integers(1, 5, size=9000, dtype=np.uint8)])
+    want = oracle.sa_is(x, 5)
+    try:
+        for thr in (0, 2048, 5000, 1 << 19):
+            emu_ctx.set_chain_max_entries(thr)
+            assert (_sa(emu_ctx, x, 5) == want).all(), thr
+    finally:
+        emu_ctx.set_chain_max_entries(256 * 2048)
+
+
 def test_bwt_tables(emu_ctx, golden):
     for name in ("ref/mississippi", "ref/serialise", "struct/periodic", "ref/fasta0"):
         c = golden[name]

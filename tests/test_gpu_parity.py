@@ -155,6 +155,22 @@ def test_tie_refinement_rounds(gpu_ctx):
     assert paths[0][1] == 1 and paths[1][1] == 1 and paths[1][2] >= 1 and paths[-1][1] == 2, paths
 
 
+def test_both_induce_round_forms(gpu_ctx):
+    """every round through the chained launch (look-back across up to thousands of tiles), every round
+    through the three-launch form, and the default mix"""
+    x = synth(1 << 22, 5, 77)
+    want = oracle.sa_is(x, 5)
+    y = synth(1 << 20, 200, 78)
+    want_y = oracle.sa_is(y, 200)
+    try:
+        for thr in (0, 1 << 14, 1 << 30):
+            gpu_ctx.set_chain_max_entries(thr)
+            assert (gpu_ctx.sa_build(x, 5) == want).all(), thr
+            assert (gpu_ctx.sa_build(y, 200) == want_y).all(), thr
+    finally:
+        gpu_ctx.set_chain_max_entries(256 * 2048)
+
+
 def test_structured_against_oracle(gpu_ctx):
     rng = np.random.default_rng(5)
     cases = {
