@@ -13,6 +13,7 @@
 // bound by the 4*sigma output bytes per position.
 #include "sx_common.hpp"
 #include "sx_device.hpp"
+#include "sx_scan.hpp"
 #include "sx_internal.hpp"
 
 namespace sx {
@@ -66,24 +67,34 @@ __global__ __launch_bounds__(kBlock) void bwt_count_kernel(const uint8_t *__rest
     if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// per symbol: exclusive prefix of the tile counts (in place) and the symbol total
-__global__ __launch_bounds__(kBlock) void bwt_offsets_kernel(uint32_t *__restrict__ tilehist, uint32_t ntiles,
-                                                             uint32_t *__restrict__ totals)
-{
-    __shared__ uint32_t lds[kWavesPerBlock];
-    const uint32_t tot = block_scan_row_inplace(tilehist + (uint64_t)blockIdx.x * ntiles, ntiles, lds);
-    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
-}
-
-__global__ void c_table_kernel(const uint32_t *__restrict__ totals, uint32_t sigma, uint32_t *__restrict__ c_out)
+// The tile counts [sigma][ntiles] are scanned as one flat array (device_scan); the prefix of
+// (symbol a, tile t) inside its row is flat[a*ntiles + t] - flat[a*ntiles], and the symbol
+// totals -- hence the C table (bwt.c:35-45) -- are differences of the row starts.
+__global__ void c_table_kernel(const uint32_t *__restrict__ flat, const uint32_t *__restrict__ grand_total,
+                               uint32_t ntiles, uint32_t sigma, uint32_t *__restrict__ totals,
+                               uint32_t *__restrict__ c_out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t acc = 0;
         for (uint32_t a = 0; a < sigma; ++a) {
+            const uint32_t start = flat[(uint64_t)a * ntiles];
+            const uint32_t next = a + 1 < sigma ? flat[(uint64_t)(a + 1) * ntiles] : *grand_total;
+            totals[a] = next - start;
             c_out[a] = acc;
-            acc += totals[a];
+            acc += next - start;
         }
     }
+}
+
+// copy a tile of finished O rows from LDS to its contiguous place in the table, 16 bytes a lane
+__device__ __forceinline__ void store_rows(const uint32_t *__restrict__ rows, uint32_t *__restrict__ dst,
+                                           uint32_t nwords)
+{
+    const uint32_t nvec = nwords >> 2;
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(rows);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) dst4[i] = src4[i];
+    for (uint32_t i = (nvec << 2) + threadIdx.x; i < nwords; i += kBlock) dst[i] = rows[i];
 }
 
 // O rows for sigma <= 8: every thread owns 4 consecutive rows and keeps the
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
                                                               uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
-    __shared__ uint32_t rows[kSmallTile * SIG];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kSmallTile * SIG];
     const int t = (int)threadIdx.x;
     const uint64_t tile0 = (uint64_t)blockIdx.x * kSmallTile;
     const uint64_t r0 = tile0 + (uint64_t)t * kSmallRowsPerThread;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     for (int a = 0; a < SIG; ++a) {
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan<OpAdd>(cnt[a], lds, tot);
-        run[a] = ex + ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] : 0u);
+        run[a] = ex + ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u);
     }
 #pragma unroll
     for (int k = 0; k < kSmallRowsPerThread; ++k) {
@@ -131,8 +142,7 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     const uint64_t rows_left = N + 1 - tile0;
     const uint32_t nrows = rows_left < (uint64_t)kSmallTile ? (uint32_t)rows_left : (uint32_t)kSmallTile;
     const uint32_t nwords = nrows * sigma;
-    uint32_t *dst = o_out + tile0 * sigma;
-    for (uint32_t i = (uint32_t)t; i < nwords; i += kBlock) dst[i] = rows[i];
+    store_rows(rows, o_out + tile0 * sigma, nwords);
 }
 
 // O rows for 8 < sigma <= 128: 64 rows per workgroup; symbols mark a +1 in the
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
                                                              const uint32_t *__restrict__ tilepre,
                                                              uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
-    __shared__ uint32_t rows[kWideTile * kMaxSigmaO];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kWideTile * kMaxSigmaO];
     const int t = (int)threadIdx.x;
     const uint64_t tile0 = (uint64_t)blockIdx.x * kWideTile;
     for (uint32_t i = (uint32_t)t; i < (uint32_t)kWideTile * sigma; i += kBlock) rows[i] = 0;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
     }
     __syncthreads();
     if ((uint32_t)t < sigma) {
-        uint32_t run = tilepre[(uint64_t)t * ntiles + blockIdx.x];
+        uint32_t run = tilepre[(uint64_t)t * ntiles + blockIdx.x] - tilepre[(uint64_t)t * ntiles];
         for (int r = 0; r < kWideTile; ++r) {
             run += rows[(uint32_t)r * sigma + t];
             rows[(uint32_t)r * sigma + t] = run;
@@ -163,8 +173,7 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
     const uint64_t rows_left = N + 1 - tile0;
     const uint32_t nrows = rows_left < (uint64_t)kWideTile ? (uint32_t)rows_left : (uint32_t)kWideTile;
     const uint32_t nwords = nrows * sigma;
-    uint32_t *dst = o_out + tile0 * sigma;
-    for (uint32_t i = (uint32_t)t; i < nwords; i += kBlock) dst[i] = rows[i];
+    store_rows(rows, o_out + tile0 * sigma, nwords);
 }
 
 } // namespace sx
@@ -190,7 +199,7 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     uint8_t *bwt_own = d_bwt_in ? nullptr : (d_bwt_out ? d_bwt_out : ar.take<uint8_t>(N));
     const uint8_t *bwt = d_bwt_in ? d_bwt_in : bwt_own;
     uint32_t *tilehist = ar.take<uint32_t>((size_t)sigma * ntiles);
-    uint32_t *totals = ar.take<uint32_t>(256);
+    uint32_t *totals = ar.take<uint32_t>(256 + 16); // per-symbol totals, then the grand total
     if (!bwt || !tilehist || !totals) return sx_fail_msg(ctx, SX_E_INTERNAL, "bwt: arena too small");
 
     if (d_bwt_in)
@@ -199,9 +208,11 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     else
         sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_gather_kernel, dim3(ntiles), dim3(kBlock), d_text, d_sa, N,
                   tile_rows, sigma, bwt_own, tilehist, ntiles);
-    sx_launch(ctx, SX_KC_SCAN, (uint64_t)sigma * ntiles * 8, bwt_offsets_kernel, dim3(sigma), dim3(kBlock),
-              tilehist, ntiles, totals);
-    sx_launch(ctx, SX_KC_MISC, 0, c_table_kernel, dim3(1), dim3(64), (const uint32_t *)totals, sigma, d_c);
+    const uint64_t flat_n = (uint64_t)sigma * ntiles;
+    SX_TRY((device_scan<OpAdd>(ctx, flat_n, InU32{tilehist}, OutExclusive{tilehist}, totals + 256, SX_KC_SCAN,
+                               flat_n * 12)));
+    sx_launch(ctx, SX_KC_MISC, 0, c_table_kernel, dim3(1), dim3(64), (const uint32_t *)tilehist,
+              (const uint32_t *)(totals + 256), ntiles, sigma, totals, d_c);
     // every bwt symbol must be < sigma (the O kernels index rows by symbol)
     uint32_t h_tot[256];
     SX_TRY(sx_readback(ctx, totals, sigma, h_tot));

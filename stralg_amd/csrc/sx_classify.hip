@@ -196,13 +196,47 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     if (p0 > n) valid = 0;
     else if (n - p0 < 15) valid = (2u << (uint32_t)(n - p0)) - 1u; // positions p0 .. n
     lmsmask &= valid;
+    // Histograms.  Symbols below 8 (all of DNA) are counted in registers, eight 8-bit
+    // counters per u64 (a thread holds 16 positions, so a counter cannot overflow), reduced
+    // over the wave in two halves of 16-bit lanes, and reach LDS as one add per wave and
+    // symbol; LDS atomics from 64 lanes on four hot addresses would serialise.  Larger
+    // symbols go to LDS directly (their addresses spread).
+    uint64_t pk_all = 0, pk_l = 0, pk_lms = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if ((valid >> i) & 1u) {
             const uint32_t ch = (p0 + i == n) ? 0u : c[i];
-            atomicAdd(&h[0][ch], 1u);
-            if (!((smask >> i) & 1u)) atomicAdd(&h[1][ch], 1u);
-            if ((lmsmask >> i) & 1u) atomicAdd(&h[2][ch], 1u);
+            const bool is_l = !((smask >> i) & 1u), is_lms = (lmsmask >> i) & 1u;
+            if (ch < 8u) {
+                const uint64_t one = 1ull << (8u * ch);
+                pk_all += one;
+                if (is_l) pk_l += one;
+                if (is_lms) pk_lms += one;
+            } else {
+                atomicAdd(&h[0][ch], 1u);
+                if (is_l) atomicAdd(&h[1][ch], 1u);
+                if (is_lms) atomicAdd(&h[2][ch], 1u);
+            }
+        }
+    }
+    {
+        const uint64_t m16 = 0x00FF00FF00FF00FFull;
+        uint64_t part[6] = {pk_all & m16, (pk_all >> 8) & m16, pk_l & m16, (pk_l >> 8) & m16,
+                            pk_lms & m16, (pk_lms >> 8) & m16};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part[k] += __shfl_xor(part[k], o, kWave);
+        }
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const uint32_t v = (uint32_t)((part[k] >> (16 * f)) & 0xFFFFull);
+                    if (v) atomicAdd(&h[k >> 1][2 * f + (k & 1)], v); // even fields: symbols 0,2,4,6; odd: 1,3,5,7
+                }
+            }
         }
     }
     lmsbits[(uint64_t)blockIdx.x * kBlock + t] = (uint16_t)lmsmask;

@@ -60,7 +60,7 @@ struct sx_ctx {
     uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB)
     // profiling
     uint32_t chain_epoch = 0; // look-back status epoch (24 bits), see sx_device.hpp
-    uint32_t chain_max_entries = 256u * 2048u; // rounds up to this many entries take the chained launch
+    int64_t chain_max_override = -1; // SX_FLAG_CHAIN_MAX_ENTRIES; -1 = choose by alphabet size
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int prof_on = 0;
     std::vector<sx_event_pair> ev_used;

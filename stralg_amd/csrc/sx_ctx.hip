@@ -169,8 +169,7 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         return 0;
     }
     if (flag == SX_FLAG_CHAIN_MAX_ENTRIES) {
-        if (value < 0) return SX_E_ARG;
-        ctx->chain_max_entries = (uint32_t)value;
+        ctx->chain_max_override = value < 0 ? -1 : (int64_t)value; // negative: back to the default
         return 0;
     }
     return SX_E_ARG;

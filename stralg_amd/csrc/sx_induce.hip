@@ -372,13 +372,17 @@ __global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, cons
     }
 }
 
+// bwt[i] = text[SA[i]-1]: the first symbol of slot i's window; the one slot whose entry is
+// position 0 has an empty window (count 0) and gets the sentinel (bwt.c:13-20)
 template <class WT>
-__global__ __launch_bounds__(kBlock) void bwt_from_windows_kernel(const uint32_t *__restrict__ SA,
-                                                                  const WT *__restrict__ WN, uint64_t N, wnd_cfg cfg,
+__global__ __launch_bounds__(kBlock) void bwt_from_windows_kernel(const WT *__restrict__ WN, uint64_t N, wnd_cfg cfg,
                                                                   uint8_t *__restrict__ bwt)
 {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < N) bwt[i] = SA[i] == 0 ? (uint8_t)0 : (uint8_t)wnd_first<WT>(WN[i], cfg);
+    if (i < N) {
+        const WT w = WN[i];
+        bwt[i] = wnd_count<WT>(w) == 0 ? (uint8_t)0 : (uint8_t)wnd_first<WT>(w, cfg);
+    }
 }
 
 template <class WT> __global__ void set_entry_kernel(uint32_t *SA, WT *WN, uint32_t p, const uint8_t *T, wnd_cfg cfg)
@@ -410,6 +414,7 @@ template <class WT> struct induce_state {
     uint32_t *ranges;    // (kMaxSpec + 2) x {lo, hi}
     uint32_t *tickets;   // kMaxSpec + 2
     uint64_t *status;
+    uint32_t chain_max; // rounds up to this many entries take the chained launch
     uint32_t *hist;   // [nk][stride] tile counts of the three-launch form
     uint32_t stride;
     uint32_t nk;
@@ -435,7 +440,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     const uint64_t eb = (uint64_t)tiles_bound * kIndTile * (4 + sizeof(WT));
     const uint32_t *cur = st.cursor[st.par];
     uint32_t *nxt = st.cursor[st.par ^ 1];
-    const uint32_t chain_max = ctx->chain_max_entries;
+    const uint32_t chain_max = st.chain_max;
     if ((uint64_t)tiles_bound * kIndTile > chain_max) {
         // the round may be a large one: queue the three-launch form as well
         sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT>, dim3(grid), dim3(kBlock), srcP, srcW,
@@ -453,7 +458,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     }
     const uint32_t ctiles = chain_max / kIndTile + 1;
     uint32_t cgrid = grid > ctiles ? ctiles : grid; // chained form: at most chain_max / kIndTile tiles
-    if (cgrid > 256) cgrid = 256;
+    if (cgrid > 1024) cgrid = 1024;
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
@@ -536,7 +541,12 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (ti.h_all[c] > largest) largest = ti.h_all[c];
     }
     // look-back status words: one per (tile, bucket) of the largest round
-    const size_t status_words = ((size_t)ctx->chain_max_entries / kIndTile + 2) * nk + kChainHeader;
+    // Small alphabets walk back a wave at a time, so long rounds are better off with the three
+    // launches; with one thread per bucket the walk is slower, but wide alphabets have short
+    // rounds (a bucket holds ~N/sigma entries) and three launches per round cost more.
+    st.chain_max = ctx->chain_max_override >= 0 ? (uint32_t)ctx->chain_max_override
+                                                : (st.small_alphabet ? 256u : 2048u) * (uint32_t)kIndTile;
+    const size_t status_words = ((size_t)st.chain_max / kIndTile + 2) * nk + kChainHeader;
     st.stride = sx_div_up(largest, kIndTile) + 1;
     st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
     if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
@@ -602,8 +612,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     }
     // the windows now hold text[SA[i]-1] for every slot: the BWT for free (bwt.c:13-20)
     if (bwt_out)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N * (4 + sizeof(WT) + 1), bwt_from_windows_kernel<WT>,
-                  dim3(sx_div_up(N, kBlock)), dim3(kBlock), (const uint32_t *)SA, (const WT *)st.WN, N, cfg, bwt_out);
+        sx_launch(ctx, SX_KC_BWT_GATHER, N * (sizeof(WT) + 1), bwt_from_windows_kernel<WT>, dim3(sx_div_up(N, kBlock)),
+                  dim3(kBlock), (const WT *)st.WN, N, cfg, bwt_out);
     return 0;
 }
 } // namespace

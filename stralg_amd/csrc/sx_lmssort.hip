@@ -6,11 +6,13 @@
 // byte strings are: the expected longest repeat is ~2 log_sigma n symbols --
 // that order is simply a radix sort of (prefix key, position) pairs:
 //
-//   key(p)  = the first C symbols of suffix p, b = bitlen(max symbol) bits each,
-//             C = 64 / b (21 for DNA, 8 for bytes); past the end the text reads
-//             0, the unique smallest symbol, so no key containing the sentinel
-//             can tie with another.
-//   sort    one 64-bit LSD radix sort (sx_radix.hip) of all m LMS suffixes
+//   key(p)  = the first C symbols of suffix p as a base-(max symbol + 1) number; past
+//             the end the text reads 0, the unique smallest symbol, so no key
+//             containing the sentinel can tie with another.  C is the smallest
+//             length at which random text leaves ~3 % of the suffixes tied
+//             (17 symbols = 40 bits for 1 GiB of DNA, 5 symbols = 40 bits for bytes):
+//             fewer key bits = fewer radix passes.
+//   sort    one LSD radix sort (sx_radix.hip) of all m LMS suffixes
 //   ties    groups of equal keys are refined by the next C symbols, a few
 //             rounds, on the tied elements only.
 //
@@ -24,9 +26,12 @@
 
 namespace sx {
 
-// C symbols starting at text position p, packed most-significant first.
-// Three aligned 16-byte loads when C <= 32 (statically indexed: no scratch), byte loads otherwise.
-__device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, uint32_t b,
+// The first C symbols of suffix p as one number in base `base` (= largest symbol + 1),
+// most significant first: numeric order == lexicographic order, the sentinel (0) is the
+// smallest digit, and no bits are wasted when the alphabet is not a power of two
+// (DNA + sentinel: base 5, 17 symbols in 40 bits).  Three aligned 16-byte loads when
+// C <= 32 (statically indexed: no scratch), byte loads otherwise.
+__device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, uint32_t base,
                                                uint32_t C)
 {
     uint64_t acc = 0;
@@ -35,23 +40,23 @@ __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, ui
         load_bytes32(T, p, q);
 #pragma unroll
         for (uint32_t s = 0; s < 32; ++s) {
-            if (s < C) acc = (acc << b) | ((q[s >> 3] >> (8u * (s & 7u))) & 0xFFull);
+            if (s < C) acc = acc * base + ((q[s >> 3] >> (8u * (s & 7u))) & 0xFFull);
         }
     } else {
-        for (uint32_t s = 0; s < C; ++s) acc = (acc << b) | (uint64_t)T[p + s];
+        for (uint32_t s = 0; s < C; ++s) acc = acc * base + (uint64_t)T[p + s];
     }
-    return acc << (64u - b * C);
+    return acc;
 }
 
 __global__ __launch_bounds__(kBlock) void lms_prefix_keys_kernel(const uint8_t *__restrict__ T,
                                                                  const uint32_t *__restrict__ pos, uint64_t m,
-                                                                 uint32_t b, uint32_t C, uint64_t *__restrict__ keys,
+                                                                 uint32_t base, uint32_t C, uint64_t *__restrict__ keys,
                                                                  uint32_t *__restrict__ vals)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= m) return;
     const uint32_t p = pos[k];
-    keys[k] = prefix_key(T, p, b, C);
+    keys[k] = prefix_key(T, p, base, C);
     vals[k] = p;
 }
 
@@ -91,7 +96,7 @@ struct OutActKey {
     const uint8_t *T;
     const uint32_t *ap;
     uint64_t n, skip;
-    uint32_t b, C;
+    uint32_t base, C;
     uint32_t *agid;
     uint64_t *key_keep, *key_sort;
     uint32_t *order;
@@ -100,7 +105,7 @@ struct OutActKey {
         agid[t] = (excl > v ? excl : v) - 1u;
         const uint64_t q = (uint64_t)ap[t] + skip;
         // q > n cannot happen inside a tie (a key holding the sentinel is unique); stay in bounds anyway
-        const uint64_t k = q <= n ? prefix_key(T, q, b, C) : 0ull;
+        const uint64_t k = q <= n ? prefix_key(T, q, base, C) : 0ull;
         key_keep[t] = k;
         key_sort[t] = k;
         order[t] = (uint32_t)t;
@@ -186,9 +191,21 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 {
     *resolved = 0;
     const uint64_t m = ti.m;
-    uint32_t b = (uint32_t)sx_bitlen(ti.maxc);
-    if (b < 1) b = 1;
-    const uint32_t C = 64 / b;
+    const uint32_t base = ti.maxc + 1;
+    // longest prefix whose number fits 63 bits
+    uint32_t Cmax = 0;
+    for (double cap63 = 9.2e18, v = 1.0; v * base <= cap63 && Cmax < 63; v *= base) ++Cmax;
+    if (Cmax < 1) Cmax = 1;
+    // shortest prefix that tells ~97 % of m suffixes of a uniformly random text apart
+    uint32_t C = 1;
+    {
+        const double eff = ti.maxc > 2 ? (double)ti.maxc : 2.0, target = 32.0 * (double)m;
+        double v = eff;
+        while (v < target && C < Cmax) {
+            v *= eff;
+            ++C;
+        }
+    }
     const uint32_t cap = (uint32_t)(m / 8 + 1024);
     uint64_t *ka = am.take<uint64_t>(m), *kb = am.take<uint64_t>(m);
     uint32_t *va = am.take<uint32_t>(m), *vb = am.take<uint32_t>(m);
@@ -203,32 +220,53 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
     const dim3 block(kBlock);
 
-    sx_launch(ctx, SX_KC_KEYS, m * (4 + 12) + ti.N, lms_prefix_keys_kernel, dim3(sx_div_up(m, kBlock)), block,
-              ti.T, pos, m, b, C, ka, va);
-    int in_b = 0;
-    SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, (int)(64 - b * C), 64, &in_b));
-    const uint64_t *ks = in_b ? kb : ka;
-    uint32_t *vs = in_b ? vb : va;
-
-    // members of groups with equal keys
-    SX_TRY((device_scan<OpAdd>(ctx, m, InTied{ks, m}, OutTied{ks, vs, apos, ap, head, cap}, d_scalar,
-                               SX_KC_NAMES, m * 16)));
+    const uint64_t *ks = nullptr;
+    uint32_t *vs = nullptr;
     uint32_t A = 0;
-    SX_TRY(sx_readback(ctx, d_scalar, 1, &A));
-    ctx->stats.n_names = m - A; // suffixes told apart by the first sort
-    if (A > cap - 1024) return 0; // repetitive text: general path
+    int kbits = 64;
+    for (int attempt = 0;; ++attempt) {
+        {
+            uint64_t top = 1; // base^C - 1 is the largest key
+            for (uint32_t i = 0; i < C; ++i) top *= base;
+            kbits = sx_bitlen(top - 1);
+            if (kbits < 1) kbits = 1;
+        }
+        sx_launch(ctx, SX_KC_KEYS, m * (4 + 12) + ti.N, lms_prefix_keys_kernel, dim3(sx_div_up(m, kBlock)), block,
+                  ti.T, pos, m, base, C, ka, va);
+        int in_b = 0;
+        SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b));
+        ks = in_b ? kb : ka;
+        vs = in_b ? vb : va;
+        // members of groups with equal keys
+        SX_TRY((device_scan<OpAdd>(ctx, m, InTied{ks, m}, OutTied{ks, vs, apos, ap, head, cap}, d_scalar,
+                                   SX_KC_NAMES, m * 16)));
+        SX_TRY(sx_readback(ctx, d_scalar, 1, &A));
+        ctx->stats.n_names = m - A; // suffixes told apart by the first sort
+        ctx->stats.key_slots = C;
+        ctx->stats.key_bits = (uint32_t)kbits;
+        if (A <= cap - 1024) break;
+        if (attempt == 0 && C < Cmax) { // skewed symbol frequencies: once more with the longest key
+            C = Cmax;
+            continue;
+        }
+        return 0; // repetitive text: general path
+    }
 
+    // ties are refined with the longest key that fits (Cmax symbols a round)
+    uint64_t top_r = 1;
+    for (uint32_t i = 0; i < Cmax; ++i) top_r *= base;
+    const int kbits_r = sx_bitlen(top_r - 1) > 0 ? sx_bitlen(top_r - 1) : 1;
     for (int round = 1; A > 0; ++round) {
-        if (round > 3) return 0; // still tied after 4C symbols: general path
+        if (round > 4) return 0; // still tied after C + 4 Cmax symbols: general path
         ctx->stats.doubling_rounds++;
         const uint32_t gbits = (uint32_t)(sx_bitlen(A) > 0 ? sx_bitlen(A) : 1);
         // group ids and the next C symbols of every tied suffix
         SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head},
-                                   OutActKey{ti.T, ap, ti.n, (uint64_t)C * round, b, C, agid, key_keep, rk_a, ord_a},
+                                   OutActKey{ti.T, ap, ti.n, (uint64_t)C + (uint64_t)Cmax * (round - 1), base, Cmax, agid, key_keep, rk_a, ord_a},
                                    nullptr, SX_KC_DOUBLING, (uint64_t)A * 32)));
         // order by (group, next key), LSD: stable sort by next key, then stable sort by group
         int f = 0;
-        SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A, (int)(64 - b * C), 64, &f));
+        SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A, 0, kbits_r, &f));
         uint32_t *ord1 = f ? ord_b : ord_a, *ord1_other = f ? ord_a : ord_b;
         uint64_t *k1 = f ? rk_a : rk_b, *k1_other = f ? rk_b : rk_a; // k1: free to overwrite
         sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 16, gid_keys_kernel, dim3(sx_div_up(A, kBlock)), block,
