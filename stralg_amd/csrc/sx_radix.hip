@@ -20,7 +20,10 @@
 
 namespace sx {
 
-constexpr int kRadixItems = 8;
+#ifndef SX_RADIX_ITEMS
+#define SX_RADIX_ITEMS 16
+#endif
+constexpr int kRadixItems = SX_RADIX_ITEMS;
 constexpr int kRadixTile = kBlock * kRadixItems;
 
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
@@ -49,8 +52,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
     __shared__ uint32_t goff[256];                   // global offset of the digit minus dbase
     __shared__ uint32_t scan_lds[kWavesPerBlock];
-    __shared__ uint64_t skey[kRadixTile];
-    __shared__ uint32_t sval[kRadixTile];
+    __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
 
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
@@ -59,19 +61,17 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const uint64_t tile0 = (uint64_t)blockIdx.x * kRadixTile;
     const uint64_t wave0 = tile0 + (uint64_t)w * (kWave * kRadixItems);
     uint64_t key[kRadixItems];
-    uint32_t val[kRadixItems], rnk[kRadixItems];
+    uint32_t lpos[kRadixItems]; // rank within (wave, digit), then slot in the tile's digit order
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        const bool ok = i < n;
-        key[k] = ok ? kin[i] : ~0ull;
-        val[k] = ok ? vin[i] : 0u;
+        key[k] = i < n ? kin[i] : ~0ull;
     }
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
         const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-        rnk[k] = wave_rank_step<8>(d, i < n, wcount[w]);
+        lpos[k] = wave_rank_step<8>(d, i < n, wcount[w]);
     }
     __syncthreads();
     {
@@ -89,25 +89,46 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
         goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - ex;
     }
     __syncthreads();
+    // A large tile keeps the runs per digit long (a tile of 4096 keys with uniformly random
+    // digits still leaves only 16 keys = 128 bytes per digit), so the LDS image is used
+    // twice, for the keys and then for the values, instead of holding both.
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+        lpos[k] += dbase[d] + wcount[w][d];
+    }
+    const uint64_t left = n - tile0;
+    const uint32_t cnt = left < (uint64_t)kRadixTile ? (uint32_t)left : (uint32_t)kRadixTile;
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        if (i < n) {
-            const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-            const uint32_t pos = dbase[d] + wcount[w][d] + rnk[k];
-            skey[pos] = key[k];
-            sval[pos] = val[k];
+        if (i < n) skey[lpos[k]] = key[k];
+    }
+    __syncthreads();
+    uint32_t dstv[kRadixItems]; // destinations of the slots this thread copies out
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kBlock;
+        dstv[k] = 0;
+        if (i < cnt) {
+            const uint64_t kk = skey[i];
+            const uint32_t d = (uint32_t)(kk >> shift) & mask;
+            dstv[k] = goff[d] + i;
+            kout[dstv[k]] = kk;
         }
     }
     __syncthreads();
-    const uint64_t left = n - tile0;
-    const uint32_t cnt = left < (uint64_t)kRadixTile ? (uint32_t)left : (uint32_t)kRadixTile;
-    for (uint32_t i = (uint32_t)t; i < cnt; i += kBlock) {
-        const uint64_t kk = skey[i];
-        const uint32_t d = (uint32_t)(kk >> shift) & mask;
-        const uint32_t dst = goff[d] + i;
-        kout[dst] = kk;
-        vout[dst] = sval[i];
+    uint32_t *sval = reinterpret_cast<uint32_t *>(skey);
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
+        if (i < n) sval[lpos[k]] = vin[i]; // the values are only read now: fewer live registers
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kBlock;
+        if (i < cnt) vout[dstv[k]] = sval[i];
     }
 }
 
