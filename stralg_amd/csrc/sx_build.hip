@@ -97,6 +97,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     ctx->stats.n_lms = ti.m;
 
     const uint32_t *sorted_lms = nullptr;
+    const void *seed_windows = nullptr; // windows of the sorted LMS suffixes, when the sort carried them
     if (ti.m <= 1) {
         // only the sentinel is LMS: it alone seeds the induction
         uint32_t *one = an.take<uint32_t>(1);
@@ -119,12 +120,13 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         if (!pos || !is_lms) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS positions");
         SX_TRY(sx_sample_write(ctx, ti, pos, is_lms));
         int resolved = 0;
-        SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, pos, &sorted_lms, &resolved));
+        SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, pos, &sorted_lms, &seed_windows, &resolved));
         if (resolved) {
             ctx->stats.lms_path = 1;
             ctx->stats.n_samples = ti.m;
         } else {
             sorted_lms = nullptr;
+            seed_windows = nullptr;
         }
     }
     if (ti.m > 1 && !sorted_lms) {
@@ -186,7 +188,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         sorted_lms = slms;
     }
 
-    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, d_sa, d_bwt, an));
+    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, seed_windows, d_sa, d_bwt, an));
     SX_TRY(sx_sync(ctx));
     ctx->stats.ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

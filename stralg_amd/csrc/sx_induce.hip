@@ -27,6 +27,7 @@
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
 #include "sx_internal.hpp"
+#include "sx_window.hpp"
 
 namespace sx {
 
@@ -43,48 +44,6 @@ __device__ __forceinline__ bool induce_accept(uint32_t ch, uint32_t c, int mode)
     case MODE_S_FROM_S: return ch <= c;
     default: return ch < c;
     }
-}
-
-// ---- symbol windows ---------------------------------------------------------------
-// Every suffix-array entry p travels with a window word holding the symbols to
-// its left, text[p-1], text[p-2], ... (codes = symbol - 1, B bits each, the
-// nearest one in the lowest field) and, in the low 4 bits, how many are valid.
-// Inducing p-1 from p pops one symbol; the text is touched again only when a
-// window runs dry.
-constexpr int kCntBits = 4;
-struct wnd_cfg {
-    uint32_t B;    // bits per symbol code
-    uint32_t CW;   // symbols per window (<= 15)
-    uint32_t mask; // (1 << B) - 1
-};
-
-template <class WT> __device__ __forceinline__ uint32_t wnd_count(WT w) { return (uint32_t)(w & (WT)15); }
-template <class WT> __device__ __forceinline__ uint32_t wnd_first(WT w, const wnd_cfg &c)
-{
-    return (uint32_t)((w >> kCntBits) & (WT)c.mask) + 1u;
-}
-template <class WT> __device__ __forceinline__ WT wnd_pop(WT w, const wnd_cfg &c)
-{
-    const WT cnt = w & (WT)15;
-    return (((w >> kCntBits) >> c.B) << kCntBits) | (cnt - 1);
-}
-// window of position p, read from the text (p >= 1)
-template <class WT>
-__device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p, const wnd_cfg &c)
-{
-    const uint32_t cnt = p < c.CW ? p : c.CW;
-    // text[p-cnt .. p-1]: two aligned 16-byte loads, bytes picked with static indices
-    uint64_t lo, hi;
-    load_bytes16(T, (uint64_t)(p - cnt), lo, hi);
-    WT acc = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 15; ++i) {
-        if (i < cnt) {
-            const uint64_t byte = ((i < 8 ? lo : hi) >> (8u * (i & 7u))) & 0xFFull;
-            acc = (acc << c.B) | (WT)(byte - 1u); // ends with text[p-1] in the lowest field
-        }
-    }
-    return (acc << kCntBits) | (WT)cnt;
 }
 
 template <class WT>
@@ -507,8 +466,8 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
 }
 
 template <class WT>
-int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
-                 uint8_t *bwt_out, sx_arena &arena, wnd_cfg cfg)
+int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
+                 const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena, wnd_cfg cfg)
 {
     const uint64_t N = ti.N;
     // buckets that hold anything: 0 .. maxc
@@ -522,7 +481,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.cfg = cfg;
     st.par = 0;
     st.WN = arena.take<WT>(N);
-    WT *seedW = arena.take<WT>(ti.m ? ti.m : 1);
+    WT *seedW = seed_windows ? (WT *)seed_windows : arena.take<WT>(ti.m ? ti.m : 1);
     st.cursor[0] = arena.take<uint32_t>(256);
     st.cursor[1] = arena.take<uint32_t>(256);
     st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 2));
@@ -560,9 +519,11 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         SX_CHECK(hipMemsetAsync(st.status, 0, sizeof(uint64_t), ctx->stream)); // the time-out word
     }
 
-    // windows of the sorted LMS suffixes: the only systematic text access of both passes
-    sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.m * (4 + sizeof(WT) + 16), fill_windows_kernel<WT>,
-              dim3(sx_div_up(ti.m, kBlock)), dim3(kBlock), ti.T, sorted_lms, ti.m, cfg, seedW);
+    // windows of the sorted LMS suffixes: the only systematic text access of both passes, unless
+    // they already came along with the sort keys (sx_lmssort.hip)
+    if (!seed_windows)
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.m * (4 + sizeof(WT) + 16), fill_windows_kernel<WT>,
+                  dim3(sx_div_up(ti.m, kBlock)), dim3(kBlock), ti.T, sorted_lms, ti.m, cfg, seedW);
     // the sentinel suffix (sa_is.c:463: SA[0] = n)
     sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, (uint32_t)ti.n, ti.T, cfg);
 
@@ -618,20 +579,12 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
 }
 } // namespace
 
-int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
-              uint8_t *bwt_out, sx_arena &arena)
+int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
+              const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena)
 {
     if (ti.N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "induce: n exceeds 32-bit positions");
     wnd_cfg cfg;
-    cfg.B = (uint32_t)sx_bitlen(ti.maxc > 0 ? ti.maxc - 1 : 0);
-    if (cfg.B < 1) cfg.B = 1;
-    cfg.mask = (1u << cfg.B) - 1u;
-    if (cfg.B <= 4) {
-        cfg.CW = (32 - kCntBits) / cfg.B;
-        if (cfg.CW > 15) cfg.CW = 15;
-        return induce_typed<uint32_t>(ctx, ti, sigma, sorted_lms, SA, bwt_out, arena, cfg);
-    }
-    cfg.CW = (64 - kCntBits) / cfg.B;
-    if (cfg.CW > 15) cfg.CW = 15;
-    return induce_typed<uint64_t>(ctx, ti, sigma, sorted_lms, SA, bwt_out, arena, cfg);
+    const bool wide = sx_window_cfg(ti.maxc, cfg);
+    if (!wide) return induce_typed<uint32_t>(ctx, ti, sigma, sorted_lms, seed_windows, SA, bwt_out, arena, cfg);
+    return induce_typed<uint64_t>(ctx, ti, sigma, sorted_lms, seed_windows, SA, bwt_out, arena, cfg);
 }

@@ -60,12 +60,13 @@ int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const 
 // ---- sx_lmssort.hip
 size_t sx_lms_prefix_bytes(uint64_t m);
 int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t *pos,
-                          const uint32_t **out, int *resolved);
+                          const uint32_t **out, const void **seed_windows, int *resolved);
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);
-int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms, uint32_t *SA,
-              uint8_t *bwt_out, sx_arena &arena);
+// seed_windows: optional device array (one window per sorted LMS suffix, layout of sx_window.hpp)
+int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
+              const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena);
 
 // ---- sx_build.hip / sx_bwt.hip (shared by the fused host entry point)
 int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa, uint8_t *d_bwt);

@@ -23,6 +23,7 @@
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
 #include "sx_internal.hpp"
+#include "sx_window.hpp"
 
 namespace sx {
 
@@ -50,25 +51,31 @@ __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, ui
 
 __global__ __launch_bounds__(kBlock) void lms_prefix_keys_kernel(const uint8_t *__restrict__ T,
                                                                  const uint32_t *__restrict__ pos, uint64_t m,
-                                                                 uint32_t base, uint32_t C, uint64_t *__restrict__ keys,
+                                                                 uint32_t base, uint32_t C, uint32_t kbits, wnd_cfg wcfg,
+                                                                 uint64_t *__restrict__ keys,
                                                                  uint32_t *__restrict__ vals)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= m) return;
     const uint32_t p = pos[k];
-    keys[k] = prefix_key(T, p, base, C);
+    uint64_t key = prefix_key(T, p, base, C);
+    // The key bits above kbits are not sorted on, they just ride along: put the suffix's
+    // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
+    // this part of the text is in cache, instead of gathering it again after the sort.
+    if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
+    keys[k] = key;
     vals[k] = p;
 }
 
 // members of groups of equal keys: (index in the sorted order, text position, group head index)
 struct InTied {
     const uint64_t *ks;
-    uint64_t m;
+    uint64_t m, kmask; // kmask: the sorted-on bits (the rest of a key is payload)
     __device__ __forceinline__ uint32_t operator()(uint64_t j) const
     {
-        const uint64_t k = ks[j];
-        const bool eq_prev = j > 0 && ks[j - 1] == k;
-        const bool eq_next = j + 1 < m && ks[j + 1] == k;
+        const uint64_t k = ks[j] & kmask;
+        const bool eq_prev = j > 0 && (ks[j - 1] & kmask) == k;
+        const bool eq_next = j + 1 < m && (ks[j + 1] & kmask) == k;
         return (eq_prev || eq_next) ? 1u : 0u;
     }
 };
@@ -78,12 +85,16 @@ struct OutTied {
     uint32_t *apos, *ap;
     uint8_t *ahead;
     uint32_t cap;
+    uint64_t kmask;
+    uint32_t *seedw; // optional: window of every sorted slot, taken from the key's payload bits
+    uint32_t kbits;
     __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const
     {
+        if (seedw) seedw[j] = (uint32_t)(ks[j] >> kbits);
         if (!v || excl >= cap) return;
         apos[excl] = (uint32_t)j;
         ap[excl] = vs[j];
-        ahead[excl] = (j == 0 || ks[j - 1] != ks[j]) ? 1 : 0;
+        ahead[excl] = (j == 0 || (ks[j - 1] & kmask) != (ks[j] & kmask)) ? 1 : 0;
     }
 };
 
@@ -128,13 +139,16 @@ __global__ __launch_bounds__(kBlock) void refine_write_kernel(const uint32_t *__
                                                               const uint64_t *__restrict__ key_keep, uint64_t A,
                                                               uint32_t *__restrict__ vals_sorted,
                                                               uint32_t *__restrict__ ap_new,
-                                                              uint8_t *__restrict__ head_new)
+                                                              uint8_t *__restrict__ head_new,
+                                                              uint32_t *__restrict__ seedw,
+                                                              const uint8_t *__restrict__ T, wnd_cfg wcfg)
 {
     const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= A) return;
     const uint32_t o = order[t];
     const uint32_t p = ap[o];
     vals_sorted[apos[t]] = p; // slot t of the active list keeps its place in the sorted order
+    if (seedw) seedw[apos[t]] = p ? wnd_fill<uint32_t>(T, p, wcfg) : 0u; // its window moves with it
     ap_new[t] = p;
     bool head = true;
     if (t > 0) {
@@ -177,7 +191,7 @@ size_t sx_lms_prefix_bytes(uint64_t m)
     const uint64_t cap = m / 8 + 1024;
     size_t b = 0;
     b += 2 * (m * 8 + a);   // keys
-    b += 2 * (m * 4 + a);   // values
+    b += 3 * (m * 4 + a);   // values, seed windows
     b += 3 * (cap * 8 + a); // refinement keys: kept copy + sort ping-pong
     b += 8 * (cap * 4 + a); // apos x2, ap x2, ap_new, agid, order x2
     b += 3 * (cap + a);     // heads
@@ -187,9 +201,10 @@ size_t sx_lms_prefix_bytes(uint64_t m)
 // Returns 0 and *resolved = 1 with *out = device array of the m LMS suffix positions in
 // suffix order; *resolved = 0 when the caller must use the general path.
 int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t *pos,
-                          const uint32_t **out, int *resolved)
+                          const uint32_t **out, const void **seed_windows, int *resolved)
 {
     *resolved = 0;
+    *seed_windows = nullptr;
     const uint64_t m = ti.m;
     const uint32_t base = ti.maxc + 1;
     // longest prefix whose number fits 63 bits
@@ -214,8 +229,9 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t *ap = am.take<uint32_t>(cap), *ap2 = am.take<uint32_t>(cap), *ap_new = am.take<uint32_t>(cap);
     uint32_t *agid = am.take<uint32_t>(cap), *ord_a = am.take<uint32_t>(cap), *ord_b = am.take<uint32_t>(cap);
     uint8_t *head = am.take<uint8_t>(cap), *head2 = am.take<uint8_t>(cap), *head_new = am.take<uint8_t>(cap);
+    uint32_t *seedw = am.take<uint32_t>(m);
     uint32_t *d_scalar = am.take<uint32_t>(16);
-    if (!ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
+    if (!seedw || !ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
         !agid || !ord_a || !ord_b || !head || !head2 || !head_new || !d_scalar)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
     const dim3 block(kBlock);
@@ -224,6 +240,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t *vs = nullptr;
     uint32_t A = 0;
     int kbits = 64;
+    bool embed = false;
+    uint64_t kmask = ~0ull;
     for (int attempt = 0;; ++attempt) {
         {
             uint64_t top = 1; // base^C - 1 is the largest key
@@ -231,14 +249,24 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             kbits = sx_bitlen(top - 1);
             if (kbits < 1) kbits = 1;
         }
+        // symbol windows in the unsorted key bits, when at least four symbols fit (32-bit windows only)
+        wnd_cfg wcfg;
+        const bool wide = sx_window_cfg(ti.maxc, wcfg);
+        uint32_t wchars = 0;
+        if (!wide && 64 - kbits > kCntBits) wchars = (uint32_t)(64 - kbits - kCntBits) / wcfg.B;
+        if (wchars > wcfg.CW) wchars = wcfg.CW;
+        embed = wchars >= 4;
+        wcfg.CW = embed ? wchars : 0;
+        kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
         sx_launch(ctx, SX_KC_KEYS, m * (4 + 12) + ti.N, lms_prefix_keys_kernel, dim3(sx_div_up(m, kBlock)), block,
-                  ti.T, pos, m, base, C, ka, va);
+                  ti.T, pos, m, base, C, (uint32_t)kbits, wcfg, ka, va);
         int in_b = 0;
         SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b));
         ks = in_b ? kb : ka;
         vs = in_b ? vb : va;
         // members of groups with equal keys
-        SX_TRY((device_scan<OpAdd>(ctx, m, InTied{ks, m}, OutTied{ks, vs, apos, ap, head, cap}, d_scalar,
+        SX_TRY((device_scan<OpAdd>(ctx, m, InTied{ks, m, kmask},
+                                   OutTied{ks, vs, apos, ap, head, cap, kmask, embed ? seedw : nullptr, (uint32_t)kbits}, d_scalar,
                                    SX_KC_NAMES, m * 16)));
         SX_TRY(sx_readback(ctx, d_scalar, 1, &A));
         ctx->stats.n_names = m - A; // suffixes told apart by the first sort
@@ -252,6 +280,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         return 0; // repetitive text: general path
     }
 
+    wnd_cfg full_wcfg; // refined slots get their windows straight from the text
+    (void)sx_window_cfg(ti.maxc, full_wcfg);
     // ties are refined with the longest key that fits (Cmax symbols a round)
     uint64_t top_r = 1;
     for (uint32_t i = 0; i < Cmax; ++i) top_r *= base;
@@ -275,7 +305,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         const uint32_t *order = f ? ord1_other : ord1;
         sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 40, refine_write_kernel, dim3(sx_div_up(A, kBlock)), block, order,
                   (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid, (const uint64_t *)key_keep,
-                  (uint64_t)A, vs, ap_new, head_new);
+                  (uint64_t)A, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
         // keep what is still tied
         SX_TRY((device_scan<OpAdd>(ctx, A, InStillTied{head_new, A},
                                    OutStillTied{apos, ap_new, head_new, apos2, ap2, head2}, d_scalar, SX_KC_DOUBLING,
@@ -288,6 +318,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         A = A2;
     }
     *out = vs;
+    *seed_windows = embed ? seedw : nullptr;
     *resolved = 1;
     return 0;
 }

@@ -1,0 +1,62 @@
+// sx_window.hpp -- symbol windows carried by suffix-array entries during induction.
+#pragma once
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+
+namespace sx {
+
+// Every suffix-array entry p travels with a window word holding the symbols to
+// its left, text[p-1], text[p-2], ... (codes = symbol - 1, B bits each, the
+// nearest one in the lowest field) and, in the low 4 bits, how many are valid.
+// Inducing p-1 from p pops one symbol; the text is touched again only when a
+// window runs dry.
+constexpr int kCntBits = 4;
+struct wnd_cfg {
+    uint32_t B;    // bits per symbol code
+    uint32_t CW;   // symbols per window (<= 15)
+    uint32_t mask; // (1 << B) - 1
+};
+
+template <class WT> __device__ __forceinline__ uint32_t wnd_count(WT w) { return (uint32_t)(w & (WT)15); }
+template <class WT> __device__ __forceinline__ uint32_t wnd_first(WT w, const wnd_cfg &c)
+{
+    return (uint32_t)((w >> kCntBits) & (WT)c.mask) + 1u;
+}
+template <class WT> __device__ __forceinline__ WT wnd_pop(WT w, const wnd_cfg &c)
+{
+    const WT cnt = w & (WT)15;
+    return (((w >> kCntBits) >> c.B) << kCntBits) | (cnt - 1);
+}
+// window of position p, read from the text (p >= 1)
+template <class WT>
+__device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p, const wnd_cfg &c)
+{
+    const uint32_t cnt = p < c.CW ? p : c.CW;
+    // text[p-cnt .. p-1]: two aligned 16-byte loads, bytes picked with static indices
+    uint64_t lo, hi;
+    load_bytes16(T, (uint64_t)(p - cnt), lo, hi);
+    WT acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 15; ++i) {
+        if (i < cnt) {
+            const uint64_t byte = ((i < 8 ? lo : hi) >> (8u * (i & 7u))) & 0xFFull;
+            acc = (acc << c.B) | (WT)(byte - 1u); // ends with text[p-1] in the lowest field
+        }
+    }
+    return (acc << kCntBits) | (WT)cnt;
+}
+
+
+} // namespace sx
+
+// window layout for a text whose largest symbol is maxc; returns true when windows are 64-bit
+static inline bool sx_window_cfg(uint32_t maxc, sx::wnd_cfg &cfg)
+{
+    cfg.B = (uint32_t)sx_bitlen(maxc > 0 ? maxc - 1 : 0);
+    if (cfg.B < 1) cfg.B = 1;
+    cfg.mask = (1u << cfg.B) - 1u;
+    const bool wide = cfg.B > 4;
+    cfg.CW = ((wide ? 64u : 32u) - (uint32_t)sx::kCntBits) / cfg.B;
+    if (cfg.CW > 15) cfg.CW = 15;
+    return wide;
+}
