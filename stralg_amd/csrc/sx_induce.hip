@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     uint32_t *__restrict__ range_out, int rev, int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
     const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt, int dir, uint32_t *__restrict__ SA,
     WT *__restrict__ WN, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch, uint32_t *__restrict__ ticket,
-    uint32_t chain_max)
+    uint32_t chain_max /* rounds longer than this are left to the three-launch form; ~0u: take any round */)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gpos[256];  // entries of earlier tiles per bucket
@@ -384,7 +384,7 @@ template <class WT> struct induce_state {
 
 template <class WT>
 void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, int range_slot, int out_slot,
-                  uint32_t tiles_bound, int rev, int mode, uint32_t c, int dir)
+                  uint32_t tiles_bound, uint32_t tiles_likely, int rev, int mode, uint32_t c, int dir)
 {
     sx_ctx *ctx = st.ctx;
     uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
@@ -399,8 +399,11 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     const uint64_t eb = (uint64_t)tiles_bound * kIndTile * (4 + sizeof(WT));
     const uint32_t *cur = st.cursor[st.par];
     uint32_t *nxt = st.cursor[st.par ^ 1];
-    const uint32_t chain_max = st.chain_max;
-    if ((uint64_t)tiles_bound * kIndTile > chain_max) {
+    // tiles_likely: what the round is expected to need (decides which forms are queued);
+    // a round that turns out longer is still handled, by the chained form alone if need be.
+    const bool both = (uint64_t)tiles_likely * kIndTile > st.chain_max;
+    const uint32_t chain_max = both ? st.chain_max : ~0u;
+    if (both) {
         // the round may be a large one: queue the three-launch form as well
         sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT>, dim3(grid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
@@ -415,9 +418,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
                       st.SA, st.WN, st.nk, chain_max);
     }
-    const uint32_t ctiles = chain_max / kIndTile + 1;
-    uint32_t cgrid = grid > ctiles ? ctiles : grid; // chained form: at most chain_max / kIndTile tiles
-    if (cgrid > 1024) cgrid = 1024;
+    uint32_t cgrid = grid > 1024 ? 1024 : grid;
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
@@ -450,7 +451,10 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             uint32_t tb = bound_tiles >> k;
             const uint32_t floor_tiles = bound_tiles < 256 ? bound_tiles : 256;
             if (tb < floor_tiles) tb = floor_tiles;
-            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, rev, mode, c, dir);
+            // a run of c's continues with probability ~1/#symbols: expect the rounds to shrink fast
+            const int sh = st.small_alphabet ? k : 3 * k;
+            const uint32_t likely = sh < 32 ? (bound_tiles >> sh) : 0u;
+            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir);
         }
         uint32_t r[2];
         SX_TRY(sx_readback(ctx, st.ranges + 2 * spec, 2, r));
@@ -500,12 +504,11 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (ti.h_all[c] > largest) largest = ti.h_all[c];
     }
     // look-back status words: one per (tile, bucket) of the largest round
-    // Small alphabets walk back a wave at a time, so long rounds are better off with the three
-    // launches; with one thread per bucket the walk is slower, but wide alphabets have short
-    // rounds (a bucket holds ~N/sigma entries) and three launches per round cost more.
+    // The look-back walk costs a few microseconds per tile: rounds of more than 256 tiles are
+    // better off with the three launches.
     st.chain_max = ctx->chain_max_override >= 0 ? (uint32_t)ctx->chain_max_override
-                                                : (st.small_alphabet ? 256u : 2048u) * (uint32_t)kIndTile;
-    const size_t status_words = ((size_t)st.chain_max / kIndTile + 2) * nk + kChainHeader;
+                                                : 256u * (uint32_t)kIndTile;
+    const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 2) * nk + kChainHeader; // any round may be chained
     st.stride = sx_div_up(largest, kIndTile) + 1;
     st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
     if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
@@ -541,7 +544,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
                       (const uint32_t *)st.cursor[st.par], (int)c, 0);
-            launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), 0, MODE_L_FROM_LMS, c, +1);
+            launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), sx_div_up(ti.h_lms[c], kIndTile), 0,
+                             MODE_L_FROM_LMS, c, +1);
         }
     }
 
@@ -562,7 +566,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
                       begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0);
-            launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), 1, MODE_S_FROM_L, c, -1);
+            launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), sx_div_up(ti.h_l[c], kIndTile), 1,
+                             MODE_S_FROM_L, c, -1);
         }
     }
 
