@@ -504,10 +504,12 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (ti.h_all[c] > largest) largest = ti.h_all[c];
     }
     // look-back status words: one per (tile, bucket) of the largest round
-    // The look-back walk costs a few microseconds per tile: rounds of more than 256 tiles are
-    // better off with the three launches.
+    // The look-back walk costs a few microseconds per tile, so long rounds are better off with
+    // the three launches: beyond 256 tiles when a wave walks back for each of <= 8 buckets,
+    // beyond 2048 tiles when there is one thread per bucket (wide alphabets have many short
+    // rounds, where three launches per round cost more than the walk: measured).
     st.chain_max = ctx->chain_max_override >= 0 ? (uint32_t)ctx->chain_max_override
-                                                : 256u * (uint32_t)kIndTile;
+                                                : (st.small_alphabet ? 256u : 2048u) * (uint32_t)kIndTile;
     const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 2) * nk + kChainHeader; // any round may be chained
     st.stride = sx_div_up(largest, kIndTile) + 1;
     st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
