@@ -13,5 +13,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 find "$OUT" -name "*.csv" | head -50
-python3 "$ROOT/tools_profile_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python3 "$ROOT/tools/profile_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

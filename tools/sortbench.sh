@@ -5,5 +5,5 @@ for items in 16 24 32 40; do
   touch stralg_amd/csrc/sx_radix.hip
   make -s -C stralg_amd/csrc -j8 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSX_RADIX_ITEMS=$items" 2>&1 | grep -E "error" | head -3
   echo "== items $items"
-  python tools_sortbench.py 3e8 40 2>&1 | tail -1
+  python tools/sortbench.py 3e8 40 2>&1 | tail -1
 done
