@@ -56,6 +56,18 @@ def cpu_baseline(log2_sample, sigma, seed):
     }
 
 
+def pmc_traffic(log2n, sigma, tables, klass):
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
+    same command (profiles/pmc_traffic.json, made by tools/profile.sh + tools/pmc_to_json.py); PMC
+    counters cannot be read from inside the process, so this is null for workloads not profiled."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        c = doc[f"log2n={log2n} sigma={sigma} tables={int(tables)}"]["classes"][klass]
+        return round(c["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +163,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(args.log2n, sigma, tables, dom),
                 "launches": d["launches"],
                 "avg_ms": round(d["ms"] / max(1, d["launches"]), 4),
             },

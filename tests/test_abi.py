@@ -76,3 +76,14 @@ def test_no_cpu_fallback_without_gpu():
     from stralg_amd.api import Context, StralgAmdError
     with pytest.raises(StralgAmdError):
         Context(0)
+
+
+def test_c_harness_links_against_the_library(product_lib, tmp_path):
+    """tools/sa_construction_harness.c (the restated performance harness) compiles as plain C against
+    include/stralg_compat.h and links with nothing but libstralg_amd.so; the gpu suite runs it."""
+    exe = tmp_path / "harness"
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "sa_construction_harness.c"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "stralg_amd"), "-lstralg_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "stralg_amd")])
+    assert exe.exists()

@@ -281,6 +281,21 @@ def test_reference_named_c_api(gpu_ctx, golden):
     lib.free_suffix_array(b)
 
 
+def test_c_harness_runs(tmp_path):
+    """a plain C caller of the reference-named API (restated performance/suffix_array_construction.c)"""
+    import subprocess
+    exe = tmp_path / "harness"
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "sa_construction_harness.c"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "stralg_amd"), "-lstralg_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "stralg_amd")])
+    for args in (["-n", "65536", "-k", "dna", "-r", "1", "-t"], ["-n", "49000", "-k", "equal", "-r", "1"],
+                 ["-n", "200000", "-k", "ascii", "-r", "1", "-t"], ["-n", "0", "-r", "1", "-t"]):
+        out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (args, out.stderr[-500:])
+        assert "SA-IS " in out.stdout and "Skew " in out.stdout
+
+
 # ---- BASELINE.json's full sizes: size-independent properties -------------------------------
 
 def _verify_sa_on_device(text_u8, sa_i32, n):

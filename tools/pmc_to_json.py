@@ -1,0 +1,63 @@
+"""Turns the rocprofv3 PMC passes collected by tools/profile.sh into profiles/pmc_traffic.json:
+HBM bytes per launch for every kernel class of bench.py, corrected as the MI355X guide's
+HBM section prescribes (FETCH_SIZE counts half of wide streaming reads on gfx950 -> x2;
+WRITE_SIZE is exact; both counters are in KiB).
+
+    python tools/pmc_to_json.py gpurun_out/prof "2^30 sigma=5" profiles/pmc_traffic.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+CLASS_OF = [
+    ("radix_scatter_kernel", "radix_scatter"), ("radix_hist_kernel", "radix_hist"),
+    ("induce_scatter_kernel", "induce_scatter"), ("induce_count_kernel", "induce_gather"),
+    ("fill_windows_kernel", "induce_gather"), ("induce_offsets_kernel", "induce_scan"),
+    ("induce_round_kernel", "induce_chain"), ("otable_", "otable"), ("bwt_", "bwt_gather"),
+    ("cls_", "classify"), ("samp_", "samples"), ("lms_prefix_keys", "keys"), ("piece_keys", "keys"),
+    ("InTied", "names"), ("InKeyBoundary", "names"),
+]
+
+
+def klass(kernel):
+    for pat, c in CLASS_OF:
+        if pat in kernel:
+            return c
+    return None
+
+
+def collect(out, sub, counter):
+    agg = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            c = klass(r["Kernel_Name"])
+            if c:
+                agg[c][0] += 1
+                agg[c][1] += float(r["Counter_Value"]) * 1024.0
+    return agg
+
+
+def main():
+    out, workload, dest = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch, write = collect(out, "pmc_fetch", "FETCH_SIZE"), collect(out, "pmc_write", "WRITE_SIZE")
+    res = {}
+    for c in sorted(set(fetch) | set(write)):
+        launches = max(fetch[c][0], write[c][0], 1)
+        res[c] = {"launches_profiled": launches,
+                  "fetch_bytes_per_launch_corrected": 2.0 * fetch[c][1] / launches,
+                  "write_bytes_per_launch": write[c][1] / launches,
+                  "hbm_bytes_per_launch": (2.0 * fetch[c][1] + write[c][1]) / launches}
+    doc = json.load(open(dest)) if os.path.exists(dest) else {}
+    doc[workload] = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, "
+                               "FETCH_SIZE doubled (gfx950 wide streaming reads), per class", "classes": res}
+    json.dump(doc, open(dest, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res.get("radix_scatter"), indent=1))
+
+
+if __name__ == "__main__":
+    main()
