@@ -320,6 +320,105 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     }
 }
 
+// ---- the tail of a bucket's rounds: one workgroup, many rounds, one launch -------------
+// Once a round fits one tile, its successors are smaller still (each keeps only the entries
+// whose run of symbol c goes on), and a launch per round is all latency.  This kernel runs
+// successive rounds of bucket c in a single workgroup -- read <= one tile, rank, scatter,
+// advance the cursors held in LDS -- until the range is empty, grows beyond a tile (it
+// cannot, but then the host's ordinary rounds take over) or max_iters rounds have run.
+// Entries written in one iteration are read in the next by other waves of the same
+// workgroup: the barrier's workgroup-scope fence orders them (the waves share the CU's L1).
+template <class WT, int BITS>
+__global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *WN, const uint32_t *__restrict__ range_in,
+                                                             uint32_t *__restrict__ range_out, int rev, int mode,
+                                                             uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
+                                                             const uint32_t *__restrict__ cursor_cur,
+                                                             uint32_t *__restrict__ cursor_nxt, int dir,
+                                                             uint32_t max_iters)
+{
+    __shared__ uint32_t wcount[kWavesPerBlock][256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t s_range[2];
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    gbase[t] = cursor_cur[t];
+    if (t == 0) {
+        s_range[0] = range_in[0];
+        s_range[1] = range_in[1];
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < max_iters; ++it) {
+        const uint32_t lo = s_range[0], len = s_range[1] - lo;
+        if (len == 0 || len > (uint32_t)kIndTile) break; // uniform
+        for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t wave0 = (uint32_t)w * (kWave * kIndItems);
+        uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
+        WT wnd[kIndItems];
+        bool ok[kIndItems];
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            ok[k] = false;
+            dig[k] = 0;
+            val[k] = 0;
+            wnd[k] = 0;
+            if (i < len) {
+                const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                const uint32_t p = SA[idx];
+                if (p != 0) {
+                    const WT ww = WN[idx];
+                    const uint32_t ch = wnd_first<WT>(ww, cfg);
+                    ok[k] = induce_accept(ch, c, mode);
+                    dig[k] = ch;
+                    val[k] = p - 1u;
+                    wnd[k] = wnd_pop<WT>(ww, cfg);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
+        __syncthreads();
+        uint32_t cnt = 0; // entries of this round for bucket t
+        {
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+                const uint32_t x = wcount[ww][t];
+                wcount[ww][t] = cnt;
+                cnt += x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            if (ok[k]) {
+                const uint32_t d = dig[k];
+                const uint32_t r = wcount[w][d] + rnk[k];
+                const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
+                const uint32_t j = val[k];
+                WT nw = wnd[k];
+                if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg);
+                SA[dst] = j;
+                WN[dst] = nw;
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t old = gbase[t];
+            gbase[t] = dir > 0 ? old + cnt : old - cnt;
+            if ((uint32_t)t == c) {
+                s_range[0] = dir > 0 ? old : old - cnt;
+                s_range[1] = dir > 0 ? old + cnt : old;
+            }
+        }
+        __syncthreads(); // also orders this round's stores before the next round's loads
+    }
+    cursor_nxt[t] = gbase[t];
+    if (t == 0) {
+        range_out[0] = s_range[0];
+        range_out[1] = s_range[1];
+    }
+}
+
 // range <- [lo, hi) given by the host, or [a, cursor[c]) / [cursor[c], b) for the first round of a bucket
 __global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, const uint32_t *cursor, int c, int which)
 {
@@ -362,7 +461,7 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 }
 
 namespace {
-constexpr int kMaxSpec = 16; // rounds queued per batch before the host looks at the range
+constexpr int kMaxSpec = 16; // rounds queued per batch (then the tail kernel) before the host looks at the range
 
 template <class WT> struct induce_state {
     sx_ctx *ctx;
@@ -431,6 +530,23 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     ctx->stats.induce_rounds++;
 }
 
+template <class WT>
+void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, int mode, uint32_t c, int dir)
+{
+    sx_ctx *ctx = st.ctx;
+    const uint32_t *cur = st.cursor[st.par];
+    uint32_t *nxt = st.cursor[st.par ^ 1];
+    if (st.small_alphabet)
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kBlock), st.SA, st.WN,
+                  (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
+                  cur, nxt, dir, 4096u);
+    else
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kBlock), st.SA, st.WN,
+                  (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
+                  cur, nxt, dir, 4096u);
+    st.par ^= 1;
+}
+
 // all rounds of one region of bucket c: the first range comes from the cursor, every
 // round appends to bucket c what the next round reads; batches of queued rounds, one
 // host look per batch
@@ -439,9 +555,15 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
                     int dir, int which, uint32_t *total_in_region)
 {
     sx_ctx *ctx = st.ctx;
-    const int spec = st.small_alphabet ? kMaxSpec : 6;
     bool first = true;
     uint32_t bound_tiles = sx_div_up(region_entries ? region_entries : 1, kIndTile);
+    // queued rounds per batch: until the expected round size (a run of c continues with
+    // probability ~1/#symbols) is down to one tile; the tail kernel takes it from there
+    int spec = 1;
+    {
+        const int sh = st.small_alphabet ? 2 : 6;
+        while (spec < kMaxSpec && (bound_tiles >> (sh * spec)) >= 1) ++spec;
+    }
     for (;;) {
         SX_CHECK(hipMemsetAsync(st.tickets, 0, (kMaxSpec + 2) * sizeof(uint32_t), ctx->stream));
         if (first)
@@ -456,8 +578,9 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             const uint32_t likely = sh < 32 ? (bound_tiles >> sh) : 0u;
             launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir);
         }
+        launch_tail<WT>(st, spec, spec + 1, rev, mode, c, dir);
         uint32_t r[2];
-        SX_TRY(sx_readback(ctx, st.ranges + 2 * spec, 2, r));
+        SX_TRY(sx_readback(ctx, st.ranges + 2 * (spec + 1), 2, r));
         if (r[1] == r[0]) {
             if (total_in_region) *total_in_region = dir > 0 ? r[1] : r[0];
             return 0;
@@ -488,8 +611,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     WT *seedW = seed_windows ? (WT *)seed_windows : arena.take<WT>(ti.m ? ti.m : 1);
     st.cursor[0] = arena.take<uint32_t>(256);
     st.cursor[1] = arena.take<uint32_t>(256);
-    st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 2));
-    st.tickets = arena.take<uint32_t>(kMaxSpec + 2);
+    st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 3));
+    st.tickets = arena.take<uint32_t>(kMaxSpec + 3);
     if (!st.WN || !seedW || !st.cursor[0] || !st.cursor[1] || !st.ranges || !st.tickets)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
 
