@@ -629,8 +629,9 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     // look-back status words: one per (tile, bucket) of the largest round
     // The look-back walk costs a few microseconds per tile, so long rounds are better off with
     // the three launches: beyond 256 tiles when a wave walks back for each of <= 8 buckets,
-    // beyond 2048 tiles when there is one thread per bucket (wide alphabets have many short
-    // rounds, where three launches per round cost more than the walk: measured).
+    // beyond 2048 tiles with one thread per bucket (wide alphabets have short rounds -- a bucket
+    // holds ~N/sigma entries -- that are latency-bound either way; three launches cost more:
+    // measured 183 vs 163 ms at sigma = 256, 1 GiB).
     st.chain_max = ctx->chain_max_override >= 0 ? (uint32_t)ctx->chain_max_override
                                                 : (st.small_alphabet ? 256u : 2048u) * (uint32_t)kIndTile;
     const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 2) * nk + kChainHeader; // any round may be chained
