@@ -339,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t s_range[2];
+    __shared__ uint32_t s_flag;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     gbase[t] = cursor_cur[t];
     if (t == 0) {
@@ -349,6 +350,51 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
     for (uint32_t it = 0; it < max_iters; ++it) {
         const uint32_t lo = s_range[0], len = s_range[1] - lo;
         if (len == 0 || len > (uint32_t)kIndTile) break; // uniform
+        // ---- run jump -------------------------------------------------------------------
+        // Inside a long run of symbol c every entry of the range induces its left neighbour
+        // into bucket c again, round after round, in the same order.  If the L symbols to the
+        // left of every entry are all c, the next L rounds are known: round j holds the same
+        // entries minus j, in the next `len` slots.  They are written at once (L = 16 symbols
+        // per checking thread; 4096 rounds a step for a single run) instead of one at a time.
+        if (mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) {
+            const uint32_t G = len <= (uint32_t)kBlock ? (uint32_t)kBlock / len : 1u; // threads per entry
+            const uint32_t L = 16u * G;
+            const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
+            bool all_c = true;
+            for (uint32_t e = (uint32_t)t; e < len * G; e += kBlock) {
+                const uint32_t i = e / G, q = e % G;
+                const uint32_t p = SA[lo + (rev ? len - 1u - i : i)];
+                if (p < 16u * (q + 1u)) {
+                    all_c = false;
+                } else {
+                    uint64_t o0, o1;
+                    load_bytes16(T, (uint64_t)(p - 16u * (q + 1u)), o0, o1);
+                    if (o0 != cpat || o1 != cpat) all_c = false;
+                }
+            }
+            if (t == 0) s_flag = 1;
+            __syncthreads();
+            if (!all_c) s_flag = 0; // benign race: every writer stores 0
+            __syncthreads();
+            if (s_flag) { // uniform
+                const uint32_t cur = gbase[c], total = L * len;
+                for (uint32_t o = (uint32_t)t; o < total; o += kBlock) {
+                    const uint32_t j = o / len + 1u, i = o % len;
+                    const uint32_t v = SA[lo + (rev ? len - 1u - i : i)] - j;
+                    const uint32_t dst = dir > 0 ? cur + o : cur - 1u - o;
+                    SA[dst] = v;
+                    WN[dst] = v ? wnd_fill<WT>(T, v, cfg) : (WT)0;
+                }
+                __syncthreads();
+                if ((uint32_t)t == c) {
+                    gbase[c] = dir > 0 ? cur + total : cur - total;
+                    s_range[0] = dir > 0 ? cur + total - len : cur - total;
+                    s_range[1] = dir > 0 ? cur + total : cur - total + len;
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
         __syncthreads();
         const uint32_t wave0 = (uint32_t)w * (kWave * kIndItems);

@@ -171,6 +171,26 @@ def test_both_induce_round_forms(gpu_ctx):
         gpu_ctx.set_chain_max_entries(256 * 2048)
 
 
+def test_long_runs(gpu_ctx):
+    """runs of one symbol far longer than a tile: the tail kernel's run jump (closed-form rounds)"""
+    rng = np.random.default_rng(21)
+    r = lambda n: rng.integers(1, 5, size=n, dtype=np.uint8)
+    cases = {
+        "all-equal-300k": (np.full(300_000, 1, np.uint8), 2),
+        "n-run": (np.concatenate([r(50_000), np.full(400_000, 5, np.uint8), r(50_000)]), 6),
+        "a-run": (np.concatenate([r(50_000), np.full(400_000, 1, np.uint8), r(50_000)]), 5),
+        "three-runs": (np.concatenate([np.full(150_000, 3, np.uint8), [1], np.full(170_001, 3, np.uint8), [4],
+                                       np.full(160_000, 3, np.uint8), [2], r(5000)]).astype(np.uint8), 5),
+        "forty-runs": (np.concatenate([np.concatenate([r(500), np.full(20_000 + 37 * i, 4, np.uint8)])
+                                       for i in range(40)]), 5),
+        "run-at-both-ends": (np.concatenate([np.full(100_000, 2, np.uint8), r(30_000), np.full(100_000, 2, np.uint8)]), 5),
+        "bytes-run": (np.concatenate([rng.integers(1, 200, size=20_000, dtype=np.uint8), np.full(300_000, 77, np.uint8),
+                                      rng.integers(1, 200, size=20_000, dtype=np.uint8)]), 200),
+    }
+    for name, (x, sigma) in cases.items():
+        assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), name
+
+
 def test_structured_against_oracle(gpu_ctx):
     rng = np.random.default_rng(5)
     cases = {
