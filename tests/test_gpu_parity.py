@@ -301,6 +301,39 @@ def test_reference_named_c_api(gpu_ctx, golden):
     lib.free_suffix_array(b)
 
 
+def test_c_batch_farm(gpu_ctx, golden):
+    """stralg_amd_build_tables_batch: independent records, one host thread (and context) per listed device;
+    here two threads share GPU 0, which also exercises concurrent contexts"""
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.c_void_p), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.c_void_p),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.c_void_p)]
+
+    lib = gpu_ctx.lib
+    names = ["ref/fasta0", "ref/fasta1", "ref/fasta2", "ref/fasta3", "ref/fasta4", "ref/mississippi", "struct/periodic"]
+    raws = [bytes(golden[n]["raw"]) for n in names]
+    arr = (C.c_char_p * len(raws))(*raws)
+    out = (C.POINTER(BT) * len(raws))()
+    devs = (C.c_int * 2)(0, 0)
+    lib.stralg_amd_build_tables_batch.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_bool, C.POINTER(C.c_int), C.c_int,
+                                                  C.POINTER(C.POINTER(BT))]
+    lib.stralg_amd_build_tables_batch.restype = C.c_int
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    assert lib.stralg_amd_build_tables_batch(arr, len(raws), True, devs, 2, out) == 0
+    for n, t in zip(names, out):
+        c = golden[n]
+        N, sigma = t.contents.sa.contents.length, c["sigma"]
+        assert (np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)) == c["sa"]).all(), n
+        assert (np.ctypeslib.as_array(t.contents.o_table, shape=(N + 1, sigma)) == c["o"]).all(), n
+        assert (np.ctypeslib.as_array(t.contents.ro_table, shape=(N + 1, sigma)) == c["ro"]).all(), n
+        lib.completely_free_bwt_table(t)
+
+
 def test_c_harness_runs(tmp_path):
     """a plain C caller of the reference-named API (restated performance/suffix_array_construction.c)"""
     import subprocess
