@@ -86,9 +86,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; STRALG_BENCH_BACKEND=gloo + STRALG_BENCH_SHARE_GPU=1 let the N > 1 path be
+    # exercised on a single-GPU box (tests): every rank then uses cuda:0 and the scalars travel on the CPU
+    backend = os.environ.get("STRALG_BENCH_BACKEND", "nccl")
+    if os.environ.get("STRALG_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -127,7 +135,7 @@ def main():
     prof = ctx.profile_read()
     stats = ctx.last_stats()
     # max time over ranks, total suffixes over ranks (the only collectives; none on the data path)
-    elapsed, total_units = farm.reduce_scalars(elapsed, args.steps * N, device=dev)
+    elapsed, total_units = farm.reduce_scalars(elapsed, args.steps * N, device=dev if backend == "nccl" else None)
 
     if rank == 0:
         value = total_units / elapsed / 1e6

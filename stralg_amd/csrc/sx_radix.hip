@@ -24,6 +24,9 @@ namespace sx {
 #define SX_RADIX_ITEMS 16
 #endif
 constexpr int kRadixItems = SX_RADIX_ITEMS;
+#ifndef SX_RADIX_MINWAVES
+#define SX_RADIX_MINWAVES 4
+#endif
 constexpr int kRadixTile = kBlock * kRadixItems;
 
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
@@ -43,7 +46,8 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__re
     hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+// (second launch bound: workgroups per CU to plan registers for; 129 VGPRs would leave only 3)
+__global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
     uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
     uint32_t ntiles)
