@@ -354,11 +354,6 @@ __global__ __launch_bounds__(kBlock) void expand_bits_kernel(const uint16_t *__r
     if (i < N) out[i] = (uint8_t)((bits[i >> 4] >> (i & 15)) & 1u);
 }
 
-struct InPlus1Max {
-    const uint32_t *p;
-    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return p[i]; }
-};
-
 } // namespace sx
 
 using namespace sx;

@@ -50,7 +50,17 @@ struct sx_event_pair {
     int kclass;
 };
 
-enum { SX_SLAB_N = 0, SX_SLAB_M = 1, SX_SLAB_TMP = 2, SX_SLAB_BWT = 3, SX_SLAB_SCAN = 4, SX_SLAB_SORT = 5, SX_SLAB_IO = 6, SX_SLAB_CHAIN = 7, SX_NSLABS = 8 };
+// grow-only device slabs of a context
+enum {
+    SX_SLAB_N = 0,     // text copy, bit arrays, windows, induce control: proportional to n
+    SX_SLAB_M = 1,     // LMS-suffix sort / reduced problem: proportional to the LMS count
+    SX_SLAB_BWT = 2,   // bwt bytes and tile counts of the table build
+    SX_SLAB_SCAN = 3,  // tile totals of the device scan in flight
+    SX_SLAB_SORT = 4,  // radix tile histograms
+    SX_SLAB_IO = 5,    // staging of the host-buffer entry points
+    SX_SLAB_CHAIN = 6, // look-back status words
+    SX_NSLABS = 7
+};
 
 struct sx_ctx {
     int device = 0;
