@@ -105,28 +105,34 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
                                                               const uint32_t *__restrict__ tilepre,
                                                               uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
-    __shared__ uint32_t lds[kWavesPerBlock];
+    __shared__ uint64_t lds[kWavesPerBlock];
     __shared__ __attribute__((aligned(16))) uint32_t rows[kSmallTile * SIG];
     const int t = (int)threadIdx.x;
     const uint64_t tile0 = (uint64_t)blockIdx.x * kSmallTile;
     const uint64_t r0 = tile0 + (uint64_t)t * kSmallRowsPerThread;
     uint32_t sym[kSmallRowsPerThread];
-    uint32_t cnt[SIG];
-#pragma unroll
-    for (int a = 0; a < SIG; ++a) cnt[a] = 0;
+    // per-thread symbol counts as 16-bit fields of two u64 (symbols 0-3, 4-7): a tile holds at most
+    // 1024 symbols, so one 64-bit block scan replaces four 32-bit ones
+    uint64_t pk[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < kSmallRowsPerThread; ++k) {
         const uint64_t i = r0 + k;
         sym[k] = i < N ? (uint32_t)bwt[i] : 0xFFu;
-#pragma unroll
-        for (int a = 0; a < SIG; ++a) cnt[a] += sym[k] == (uint32_t)a ? 1u : 0u;
+        const uint64_t one = 1ull << (16u * (sym[k] & 3u));
+        if (sym[k] < 4u) pk[0] += one; // static indices: the pair stays in registers
+        else if (sym[k] < 8u) pk[1] += one;
     }
     uint32_t run[SIG];
 #pragma unroll
-    for (int a = 0; a < SIG; ++a) {
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan<OpAdd>(cnt[a], lds, tot);
-        run[a] = ex + ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u);
+    for (int h = 0; h < SIG / 4; ++h) {
+        uint64_t ex = 0, tot;
+        if ((uint32_t)(4 * h) < sigma) ex = block_exclusive_sum64(pk[h], lds, tot); // sigma is uniform
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int a = 4 * h + f;
+            run[a] = (uint32_t)((ex >> (16 * f)) & 0xFFFFull) +
+                     ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kSmallRowsPerThread; ++k) {

@@ -62,6 +62,30 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
     return Op::apply(base, exc);
 }
 
+// 64-bit sum variant (packed 16-bit counters: several small scans in one)
+__device__ __forceinline__ uint64_t block_exclusive_sum64(uint64_t v, uint64_t *lds /* kWavesPerBlock */, uint64_t &total)
+{
+    const int lane = lane_id(), w = wave_id();
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, (unsigned)d, kWave);
+        if (lane >= d) inc += t;
+    }
+    if (lane == kWave - 1) lds[w] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) {
+        const uint64_t x = lds[i];
+        if (i < w) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
 template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v, uint32_t *lds)
 {
     uint32_t total;
