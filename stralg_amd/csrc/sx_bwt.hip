@@ -19,8 +19,11 @@
 namespace sx {
 
 constexpr int kSmallSigma = 8;      // register-vector O kernel for sigma <= 8
-constexpr int kSmallRowsPerThread = 4;
-constexpr int kSmallTile = kBlock * kSmallRowsPerThread; // 1024 rows, 32 KiB of LDS at sigma 8
+// rows per thread: 8 for sigma <= 5 (DNA + sentinel: 2048-row tiles, 40 KiB of LDS), 4 up to sigma 8
+template <int SIG> struct small_cfg {
+    static constexpr int rows = SIG <= 5 ? 8 : 4;
+    static constexpr int tile = kBlock * rows;
+};
 constexpr int kWideTile = 64;       // rows per workgroup of the wide-alphabet O kernel
 constexpr int kMaxSigmaO = 128;     // stralg/remap.h:14-18
 
@@ -97,7 +100,7 @@ __device__ __forceinline__ void store_rows(const uint32_t *__restrict__ rows, ui
     for (uint32_t i = (nvec << 2) + threadIdx.x; i < nwords; i += kBlock) dst[i] = rows[i];
 }
 
-// O rows for sigma <= 8: every thread owns 4 consecutive rows and keeps the
+// O rows for sigma <= SIG <= 8: every thread owns `rows` consecutive rows and keeps the
 // running counts of all symbols in registers.
 template <int SIG>
 __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
@@ -106,37 +109,38 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
                                                               uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
     __shared__ uint64_t lds[kWavesPerBlock];
-    __shared__ __attribute__((aligned(16))) uint32_t rows[kSmallTile * SIG];
+    constexpr int kRows = small_cfg<SIG>::rows, kTile = small_cfg<SIG>::tile;
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kTile * SIG];
     const int t = (int)threadIdx.x;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kSmallTile;
-    const uint64_t r0 = tile0 + (uint64_t)t * kSmallRowsPerThread;
-    uint32_t sym[kSmallRowsPerThread];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+    const uint64_t r0 = tile0 + (uint64_t)t * kRows;
+    uint32_t sym[kRows];
     // per-thread symbol counts as 16-bit fields of two u64 (symbols 0-3, 4-7): a tile holds at most
     // 1024 symbols, so one 64-bit block scan replaces four 32-bit ones
     uint64_t pk[2] = {0, 0};
 #pragma unroll
-    for (int k = 0; k < kSmallRowsPerThread; ++k) {
+    for (int k = 0; k < kRows; ++k) {
         const uint64_t i = r0 + k;
         sym[k] = i < N ? (uint32_t)bwt[i] : 0xFFu;
         const uint64_t one = 1ull << (16u * (sym[k] & 3u));
         if (sym[k] < 4u) pk[0] += one; // static indices: the pair stays in registers
-        else if (sym[k] < 8u) pk[1] += one;
+        else if (sym[k] < (uint32_t)SIG) pk[1] += one;
     }
     uint32_t run[SIG];
 #pragma unroll
-    for (int h = 0; h < SIG / 4; ++h) {
+    for (int h = 0; h < (SIG + 3) / 4; ++h) {
         uint64_t ex = 0, tot;
         if ((uint32_t)(4 * h) < sigma) ex = block_exclusive_sum64(pk[h], lds, tot); // sigma is uniform
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int a = 4 * h + f;
-            run[a] = (uint32_t)((ex >> (16 * f)) & 0xFFFFull) +
+            if (a < SIG) run[a] = (uint32_t)((ex >> (16 * f)) & 0xFFFFull) +
                      ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u);
         }
     }
 #pragma unroll
-    for (int k = 0; k < kSmallRowsPerThread; ++k) {
-        const uint32_t lr = (uint32_t)t * kSmallRowsPerThread + k;
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t lr = (uint32_t)t * kRows + k;
 #pragma unroll
         for (int a = 0; a < SIG; ++a) {
             if ((uint32_t)a < sigma) rows[lr * sigma + a] = run[a];
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     __syncthreads();
     // rows tile0 .. min(tile0 + tile, N + 1) leave as one contiguous block
     const uint64_t rows_left = N + 1 - tile0;
-    const uint32_t nrows = rows_left < (uint64_t)kSmallTile ? (uint32_t)rows_left : (uint32_t)kSmallTile;
+    const uint32_t nrows = rows_left < (uint64_t)kTile ? (uint32_t)rows_left : (uint32_t)kTile;
     const uint32_t nwords = nrows * sigma;
     store_rows(rows, o_out + tile0 * sigma, nwords);
 }
@@ -195,7 +199,7 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     if (d_o && sigma > kMaxSigmaO)
         return sx_fail_msg(ctx, SX_E_ARG, "the O table is defined for sigma <= 128 (stralg/remap.h:14-18)");
     const bool small = sigma <= kSmallSigma;
-    const uint32_t tile_rows = small ? kSmallTile : kWideTile;
+    const uint32_t tile_rows = small ? (sigma <= 5 ? small_cfg<5>::tile : small_cfg<8>::tile) : kWideTile;
     const uint32_t ntiles = sx_div_up(N + 1, tile_rows);
     const size_t need = (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 1024 + 4096;
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, need));
@@ -227,9 +231,12 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     if (sum != N) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= sigma, or sa is not over this text");
     if (d_o) {
         const uint64_t out_bytes = (N + 1) * (uint64_t)sigma * 4 + N;
-        if (small)
-            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<kSmallSigma>, dim3(ntiles), dim3(kBlock), bwt, N,
-                      sigma, (const uint32_t *)tilehist, ntiles, d_o);
+        if (small && sigma <= 5)
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<5>, dim3(ntiles), dim3(kBlock), bwt, N, sigma,
+                      (const uint32_t *)tilehist, ntiles, d_o);
+        else if (small)
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<8>, dim3(ntiles), dim3(kBlock), bwt, N, sigma,
+                      (const uint32_t *)tilehist, ntiles, d_o);
         else
             sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_wide_kernel, dim3(ntiles), dim3(kBlock), bwt, N, sigma,
                       (const uint32_t *)tilehist, ntiles, d_o);
