@@ -138,13 +138,39 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
                      ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u);
         }
     }
+    if (sigma == (uint32_t)SIG && (kRows * SIG) % 4 == 0) {
+        // the thread's rows are kRows * SIG consecutive words of the tile: build them in
+        // registers and hand them to LDS 16 bytes at a time (scalar stores at a 40-word lane
+        // stride would hit 8-way bank conflicts; storing straight to memory from here was
+        // measured slower: 9.2 vs 6.0 ms at 1 GiB)
+        uint32_t out[kRows * SIG];
 #pragma unroll
-    for (int k = 0; k < kRows; ++k) {
-        const uint32_t lr = (uint32_t)t * kRows + k;
+        for (int k = 0; k < kRows; ++k) {
 #pragma unroll
-        for (int a = 0; a < SIG; ++a) {
-            if ((uint32_t)a < sigma) rows[lr * sigma + a] = run[a];
-            run[a] += sym[k] == (uint32_t)a ? 1u : 0u;
+            for (int a = 0; a < SIG; ++a) {
+                out[k * SIG + a] = run[a];
+                run[a] += sym[k] == (uint32_t)a ? 1u : 0u;
+            }
+        }
+        uint4 *dst4 = reinterpret_cast<uint4 *>(rows + (uint32_t)t * (kRows * SIG));
+#pragma unroll
+        for (int q = 0; q < kRows * SIG / 4; ++q) {
+            uint4 v;
+            v.x = out[4 * q];
+            v.y = out[4 * q + 1];
+            v.z = out[4 * q + 2];
+            v.w = out[4 * q + 3];
+            dst4[q] = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const uint32_t lr = (uint32_t)t * kRows + k;
+#pragma unroll
+            for (int a = 0; a < SIG; ++a) {
+                if ((uint32_t)a < sigma) rows[lr * sigma + a] = run[a];
+                run[a] += sym[k] == (uint32_t)a ? 1u : 0u;
+            }
         }
     }
     __syncthreads();
