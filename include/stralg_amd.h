@@ -121,6 +121,23 @@ int sx_bwt_tables_from_bwt_dev(sx_ctx *ctx, const uint8_t *d_bwt, uint64_t N, ui
 int sx_build_tables(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma, uint32_t *sa_out,
                     uint32_t *c_out, uint32_t *o_out);
 
+/* ---- consumers of a resident suffix array / table (SURVEY.md section 8f "next") ------------ */
+/* stralg/suffix_array.c:53-60 compute_inverse: inv[sa[i]] = i. */
+int sx_sa_inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv_out);
+/* stralg/suffix_array.c:62-85 compute_lcp: lcp[0] = 0, lcp[j] = lcp(suffix sa[j-1], suffix sa[j]).
+ * d_text has N-1 bytes; d_inv_out (N entries) is optional and receives the inverse. */
+int sx_sa_lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv_out,
+                  uint32_t *d_lcp_out);
+/* host buffers; inv_out or lcp_out may be NULL (not both) */
+int sx_sa_inverse_lcp(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t N, uint32_t *inv_out,
+                      uint32_t *lcp_out);
+/* stralg/bwt.c:164-199 init_bwt_exact_match_iter for `count` patterns at once: pattern q is
+ * d_patterns[d_offsets[q] .. d_offsets[q+1]) (remapped symbols); the matches of q are
+ * sa[l_out[q] .. r_out[q]) (empty when l_out[q] >= r_out[q]).  Tables as sx_bwt_tables_dev writes them. */
+int sx_bwt_exact_search_dev(sx_ctx *ctx, const uint32_t *d_c_table, const uint32_t *d_o_table, uint64_t N,
+                            uint32_t sigma, const uint8_t *d_patterns, const uint32_t *d_offsets, uint32_t count,
+                            uint32_t *d_l_out, uint32_t *d_r_out);
+
 /* ---- measurement ------------------------------------------------------------ */
 int sx_profile_enable(sx_ctx *ctx, int on);       /* bracket every launch with HIP events */
 int sx_profile_reset(sx_ctx *ctx);

@@ -63,6 +63,11 @@ struct suffix_array *skew_sa_construction(uint8_t *string);
 void free_suffix_array(struct suffix_array *sa);
 void free_complete_suffix_array(struct suffix_array *sa);
 
+/* stralg/suffix_array.h:94-99 (suffix_array.c:53-85): fill sa->inverse / sa->lcp (malloc'd; no-ops when
+ * already present).  SURVEY.md section 8f "next" row 3: computed on the device. */
+void compute_inverse(struct suffix_array *sa);
+void compute_lcp(struct suffix_array *sa);
+
 /* stralg/remap.h:21-33,43-47,80-86 (remap.c:8-114,155-165) */
 struct remap_table *alloc_remap_table(const uint8_t *string);
 void init_remap_table(struct remap_table *table, const uint8_t *string);
@@ -86,6 +91,22 @@ void completely_dealloc_bwt_table(struct bwt_table *bwt_table);
 void completely_free_bwt_table(struct bwt_table *bwt_table);
 /* stralg/bwt.h:156-160 (bwt.c:134-161) */
 struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse);
+
+/* stralg/bwt.h:168-230 (bwt.c:164-223): exact FM-index search over host tables, one pattern at a time
+ * (the batched device form is sx_bwt_exact_search_dev in stralg_amd.h) */
+struct bwt_exact_match_iter {
+    const struct suffix_array *sa;
+    uint32_t L;
+    int64_t i;
+    uint32_t R;
+};
+struct bwt_exact_match {
+    uint32_t pos;
+};
+void init_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_table *bwt_table,
+                               const uint8_t *remapped_pattern);
+bool next_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_exact_match *match);
+void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter);
 
 /* ---- additions (not in the reference) --------------------------------------- */
 /* GPU used by the calling thread's constructors (default: $STRALG_AMD_DEVICE or 0).

@@ -371,6 +371,52 @@ uint32_t oracle_remap(const uint8_t *in, size_t n, uint8_t *out, int16_t table_o
     return next;
 }
 
+/* ---- extended suffix array, exact search ------------------------------------------ */
+
+void oracle_inverse(const uint32_t *sa, size_t N, uint32_t *inv_out)
+{
+    for (size_t i = 0; i < N; ++i)
+        inv_out[sa[i]] = (uint32_t)i;
+}
+
+void oracle_lcp(const uint8_t *text, const uint32_t *sa, size_t N, uint32_t *lcp_out)
+{
+    uint32_t *inv = malloc(N * sizeof *inv);
+    const size_t n = N - 1;
+    oracle_inverse(sa, N, inv);
+    lcp_out[0] = 0;
+    size_t l = 0;
+    for (size_t i = 0; i < N; ++i) {
+        size_t j = inv[i];
+        if (j == 0) /* suffix_array.c:74-75: no predecessor; l is left alone */
+            continue;
+        size_t k = sa[j - 1];
+        /* the reference compares through the 0 terminator, which only the shorter suffix holds */
+        while (k + l < n && i + l < n && text[k + l] == text[i + l])
+            ++l;
+        lcp_out[j] = (uint32_t)l;
+        l = l > 0 ? l - 1 : 0;
+    }
+    free(inv);
+}
+
+void oracle_bwt_exact_search(const uint32_t *c, const uint32_t *o, size_t N, uint32_t sigma,
+                             const uint8_t *pattern, size_t m, uint32_t *l_out, uint32_t *r_out)
+{
+    uint32_t L = 0, R = (uint32_t)N;
+    if (m > N) { /* bwt.c:178-180 */
+        R = 0;
+        L = 1;
+    }
+    for (size_t s = m; s-- > 0 && L < R;) {
+        uint8_t a = pattern[s];
+        L = c[a] + o[(size_t)L * sigma + a];
+        R = c[a] + o[(size_t)R * sigma + a];
+    }
+    *l_out = L;
+    *r_out = R;
+}
+
 /* ---- verifier ------------------------------------------------------------- */
 
 int oracle_check_sa(const uint8_t *text, size_t n, const uint32_t *sa)

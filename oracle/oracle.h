@@ -58,6 +58,18 @@ void oracle_o_table(const uint8_t *text, const uint32_t *sa, size_t N, uint32_t 
  * more than 127 distinct symbols are present (remap.h:14-18). */
 uint32_t oracle_remap(const uint8_t *in, size_t n, uint8_t *out, int16_t table_out[256]);
 
+/* stralg/suffix_array.c:53-60 compute_inverse: inv[sa[i]] = i. */
+void oracle_inverse(const uint32_t *sa, size_t N, uint32_t *inv_out);
+
+/* stralg/suffix_array.c:62-85 compute_lcp (Kasai): lcp[0] = 0, lcp[j] = length of the longest common
+ * prefix of the suffixes sa[j-1] and sa[j].  text holds N-1 symbols (the sentinel is implicit). */
+void oracle_lcp(const uint8_t *text, const uint32_t *sa, size_t N, uint32_t *lcp_out);
+
+/* stralg/bwt.c:164-199 init_bwt_exact_match_iter: the final (L, R) of the backward search of one
+ * remapped pattern of length m; o is position-major with (N+1)*sigma entries. */
+void oracle_bwt_exact_search(const uint32_t *c, const uint32_t *o, size_t N, uint32_t sigma,
+                             const uint8_t *pattern, size_t m, uint32_t *l_out, uint32_t *r_out);
+
 /* O(n) verifier independent of any construction algorithm: 1 if sa is a
  * permutation of 0..n with strictly increasing suffixes, else 0. */
 int oracle_check_sa(const uint8_t *text, size_t n, const uint32_t *sa);

@@ -15,7 +15,7 @@ _REF = None
 
 __all__ = [
     "build", "sa_is", "sa_is_strict", "sa_naive", "bwt", "c_table", "o_table", "remap",
-    "check_sa", "last_levels", "synth", "have_ref", "ref",
+    "check_sa", "last_levels", "synth", "have_ref", "ref", "inverse", "lcp", "bwt_exact_search",
 ]
 
 
@@ -56,6 +56,12 @@ def _lib():
         lib.oracle_o_table.restype = None
         lib.oracle_remap.argtypes = [P8, C.c_size_t, P8, C.POINTER(C.c_int16)]
         lib.oracle_remap.restype = C.c_uint32
+        lib.oracle_inverse.argtypes = [P32, C.c_size_t, P32]
+        lib.oracle_inverse.restype = None
+        lib.oracle_lcp.argtypes = [P8, P32, C.c_size_t, P32]
+        lib.oracle_lcp.restype = None
+        lib.oracle_bwt_exact_search.argtypes = [P32, P32, C.c_size_t, C.c_uint32, P8, C.c_size_t, P32, P32]
+        lib.oracle_bwt_exact_search.restype = None
         lib.oracle_check_sa.argtypes = [P8, C.c_size_t, P32]
         lib.oracle_check_sa.restype = C.c_int
         lib.oracle_last_levels.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
@@ -120,6 +126,33 @@ def o_table(text, sa, sigma):
     out = np.empty((n + 2, sigma), dtype=np.uint32)
     _lib().oracle_o_table(_u8(buf), _u32(sa), n + 1, sigma, _u32(out))
     return out
+
+
+def inverse(sa):
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    out = np.empty(sa.size, dtype=np.uint32)
+    _lib().oracle_inverse(_u32(sa), sa.size, _u32(out))
+    return out
+
+
+def lcp(text, sa):
+    """stralg/suffix_array.c:62-85 compute_lcp."""
+    buf, n = _text(text)
+    sa = np.ascontiguousarray(sa, dtype=np.uint32)
+    out = np.empty(n + 1, dtype=np.uint32)
+    _lib().oracle_lcp(_u8(buf), _u32(sa), n + 1, _u32(out))
+    return out
+
+
+def bwt_exact_search(c, o, sigma, pattern):
+    """stralg/bwt.c:164-199: final (L, R) of the backward search; o has shape (N+1, sigma)."""
+    c = np.ascontiguousarray(c, dtype=np.uint32)
+    o = np.ascontiguousarray(o, dtype=np.uint32)
+    pat = np.ascontiguousarray(pattern, dtype=np.uint8)
+    L, R = C.c_uint32(0), C.c_uint32(0)
+    _lib().oracle_bwt_exact_search(_u32(c), _u32(o), o.shape[0] - 1, sigma, _u8(pat) if pat.size else _u8(np.zeros(1, np.uint8)),
+                                   pat.size, C.byref(L), C.byref(R))
+    return int(L.value), int(R.value)
 
 
 def remap(raw):
@@ -232,6 +265,42 @@ class _Ref:
         out = np.zeros(n + 1, dtype=np.uint8)
         sigma = self.lib.remap_string(_u8(out), _u8(buf))
         return out[:n].copy(), int(sigma)
+
+    def lcp(self, text, sigma):
+        """compute_lcp on the reference's own sa_is suffix array; returns (sa, inverse, lcp)."""
+        buf, _ = _text(text)
+        self.lib.compute_lcp.argtypes = [C.POINTER(_RefSA)]
+        self.lib.compute_lcp.restype = None
+        sa = self.lib.sa_is_construction(_u8(buf), sigma)
+        self.lib.compute_lcp(sa)
+        N = sa.contents.length
+        out = tuple(np.ctypeslib.as_array(p, shape=(N,)).copy() for p in (sa.contents.array, sa.contents.inverse, sa.contents.lcp))
+        self.lib.free_suffix_array(sa)
+        return out
+
+    def exact_search(self, raw, patterns):
+        """(L, R) of init_bwt_exact_match_iter for every pattern (bytes of the raw alphabet)."""
+        class Iter(C.Structure):
+            _fields_ = [("sa", C.c_void_p), ("L", C.c_uint32), ("i", C.c_int64), ("R", C.c_uint32)]
+        buf, _ = _text(raw)
+        t = self.lib.build_complete_table(_u8(buf), False)
+        self.lib.init_bwt_exact_match_iter.argtypes = [C.POINTER(Iter), C.POINTER(_RefBwt), C.POINTER(C.c_uint8)]
+        self.lib.init_bwt_exact_match_iter.restype = None
+        self.lib.remap.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(_RefRemap)]
+        self.lib.remap.restype = C.c_void_p
+        res = []
+        for pat in patterns:
+            pb, m = _text(pat)
+            rp = np.zeros(m + 1, dtype=np.uint8)
+            ok = self.lib.remap(_u8(rp), _u8(pb), t.contents.remap_table)
+            if not ok:
+                res.append(None)  # a letter that is not in the text's alphabet
+                continue
+            it = Iter()
+            self.lib.init_bwt_exact_match_iter(C.byref(it), t, _u8(rp))
+            res.append((int(it.L), int(it.R), rp[:m].copy()))
+        self.lib.completely_free_bwt_table(t)
+        return res
 
     def build_complete_table(self, raw, include_reverse=True):
         """Returns dict(sigma, remapped, sa, c, o[(N+1), sigma], ro or None)."""

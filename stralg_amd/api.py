@@ -110,6 +110,28 @@ class Context:
     def synth_dev(self, d_out, n, sigma, seed):
         self._check(self.lib.sx_synth_dev(self.h, _ptr(d_out), n, sigma, seed), "sx_synth_dev")
 
+    # ---- consumers of a resident suffix array / table ---------------------------------
+    def inverse_lcp(self, text, sa, want_lcp=True):
+        """sx_sa_inverse_lcp: (inverse, lcp or None) as compute_inverse / compute_lcp (suffix_array.c:53-85)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        sa = np.ascontiguousarray(sa, dtype=np.uint32)
+        inv = np.empty(sa.size, dtype=np.uint32)
+        lcp = np.empty(sa.size, dtype=np.uint32) if want_lcp else None
+        self._check(self.lib.sx_sa_inverse_lcp(self.h, _ptr(text), _ptr(sa), sa.size, _ptr(inv), _ptr(lcp)),
+                    "sx_sa_inverse_lcp")
+        return inv, lcp
+
+    def sa_inverse_dev(self, d_sa, N, d_inv):
+        self._check(self.lib.sx_sa_inverse_dev(self.h, _ptr(d_sa), N, _ptr(d_inv)), "sx_sa_inverse_dev")
+
+    def sa_lcp_dev(self, d_text, d_sa, N, d_inv, d_lcp):
+        self._check(self.lib.sx_sa_lcp_dev(self.h, _ptr(d_text), _ptr(d_sa), N, _ptr(d_inv), _ptr(d_lcp)), "sx_sa_lcp_dev")
+
+    def bwt_exact_search_dev(self, d_c, d_o, N, sigma, d_patterns, d_offsets, count, d_l, d_r):
+        self._check(self.lib.sx_bwt_exact_search_dev(self.h, _ptr(d_c), _ptr(d_o), N, sigma, _ptr(d_patterns),
+                                                     _ptr(d_offsets), count, _ptr(d_l), _ptr(d_r)),
+                    "sx_bwt_exact_search_dev")
+
     # ---- primitives (kernel-level tests) ------------------------------------------
     def prim_sort_pairs_dev(self, ka, va, kb, vb, n, begin_bit, end_bit):
         flag = C.c_int(0)

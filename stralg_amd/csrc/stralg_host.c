@@ -109,6 +109,28 @@ void free_complete_suffix_array(struct suffix_array *sa)
     free_suffix_array(sa);
 }
 
+/* ---- extended suffix array (stralg/suffix_array.c:53-85) ------------------------------- */
+
+void compute_inverse(struct suffix_array *sa)
+{
+    if (sa->inverse) return;
+    sa->inverse = malloc((size_t)sa->length * sizeof *sa->inverse);
+    sx_ctx *ctx = thread_ctx();
+    int rc = sx_sa_inverse_lcp(ctx, sa->string, sa->array, sa->length, sa->inverse, NULL);
+    if (rc != 0) die("compute_inverse", rc, ctx);
+}
+
+void compute_lcp(struct suffix_array *sa)
+{
+    if (sa->lcp) return;
+    sa->lcp = malloc((size_t)sa->length * sizeof *sa->lcp);
+    uint32_t *inv = sa->inverse ? NULL : malloc((size_t)sa->length * sizeof *inv);
+    sx_ctx *ctx = thread_ctx();
+    int rc = sx_sa_inverse_lcp(ctx, sa->string, sa->array, sa->length, inv, sa->lcp);
+    if (rc != 0) die("compute_lcp", rc, ctx);
+    if (inv) sa->inverse = inv; /* compute_lcp leaves the inverse behind, as suffix_array.c:69 does */
+}
+
 /* ---- remap (stralg/remap.c:8-114,155-165) ----------------------------------------- */
 
 void init_remap_table(struct remap_table *table, const uint8_t *string)
@@ -294,6 +316,39 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
     }
     return table;
 }
+
+/* ---- exact search over host tables (stralg/bwt.c:164-223) -------------------------------- */
+
+void init_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_table *bwt_table,
+                               const uint8_t *remapped_pattern)
+{
+    const struct suffix_array *sa = bwt_table->sa;
+    const size_t m = strlen((const char *)remapped_pattern);
+    uint32_t L = 0, R = sa->length;
+    if (m > sa->length) { /* bwt.c:178-180 */
+        R = 0;
+        L = 1;
+    }
+    for (size_t s = m; s-- > 0 && L < R;) {
+        const uint8_t a = remapped_pattern[s];
+        L = bwt_table->c_table[a] + bwt_table->o_indices[L][a];
+        R = bwt_table->c_table[a] + bwt_table->o_indices[R][a];
+    }
+    iter->sa = sa;
+    iter->L = L;
+    iter->R = R;
+    iter->i = L;
+}
+
+bool next_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_exact_match *match)
+{
+    if (iter->i < 0 || iter->i >= iter->R) return false;
+    match->pos = iter->sa->array[iter->i];
+    iter->i++;
+    return true;
+}
+
+void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter) { (void)iter; }
 
 /* ---- batch farm: independent records, one host thread per GPU ------------------------ */
 

@@ -1,0 +1,185 @@
+// sx_extras.hip -- consumers of a suffix array / BWT tables that is already on the device
+// ("next" rows 3 and 4):
+//
+//   inverse[sa[i]] = i                                   stralg/suffix_array.c:53-60  compute_inverse
+//   lcp[j] = longest common prefix of suffixes sa[j-1], sa[j]; lcp[0] = 0
+//                                                        stralg/suffix_array.c:62-85  compute_lcp (Kasai)
+//   exact FM-index search: (L, R) <- (C[a] + O(a, L), C[a] + O(a, R)) over the pattern, right to left
+//                                                        stralg/bwt.c:164-199  init_bwt_exact_match_iter
+//
+// LCP keeps Kasai's invariant (the value drops by at most one from text position i to i+1) inside
+// chunks of 64 consecutive text positions handled by one thread; a chunk starts from 0, and
+// suffixes are compared 16 bytes at a time.  Work is O(n + chunks x typical lcp): linear on
+// ordinary text; on highly repetitive text the chunk starts dominate (documented limitation).
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+__global__ __launch_bounds__(kBlock) void inverse_kernel(const uint32_t *__restrict__ sa, uint64_t N,
+                                                         uint32_t *__restrict__ inv, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t p = sa[i];
+    if ((uint64_t)p < N) inv[p] = (uint32_t)i;
+    else atomicAdd(bad, 1u); // not a suffix array over N positions
+}
+
+constexpr int kLcpChunk = 64;
+
+// length of the common prefix of text[a..] and text[b..], starting the comparison at offset l
+__device__ __forceinline__ uint32_t extend_match(const uint8_t *__restrict__ T, uint32_t a, uint32_t b, uint32_t l)
+{
+    for (;;) {
+        uint64_t a0, a1, b0, b1;
+        load_bytes16(T, (uint64_t)a + l, a0, a1);
+        load_bytes16(T, (uint64_t)b + l, b0, b1);
+        const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+        if (x0) return l + (uint32_t)((__ffsll((unsigned long long)x0) - 1) >> 3);
+        if (x1) return l + 8u + (uint32_t)((__ffsll((unsigned long long)x1) - 1) >> 3);
+        l += 16u;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lcp_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ sa,
+                                                     const uint32_t *__restrict__ inv, uint64_t N,
+                                                     uint32_t *__restrict__ lcp)
+{
+    const uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t i0 = chunk * kLcpChunk;
+    if (i0 >= N) return;
+    const uint64_t i1 = i0 + kLcpChunk < N ? i0 + kLcpChunk : N;
+    uint32_t l = 0;
+    for (uint64_t i = i0; i < i1; ++i) {
+        const uint32_t j = inv[i];
+        if (j == 0) { // the sentinel suffix has no predecessor: lcp[0] = 0 (suffix_array.c:74-75)
+            lcp[0] = 0;
+            continue;
+        }
+        const uint32_t k = sa[j - 1];
+        // text[n] = 0 differs from every symbol, so the comparison stops before either suffix ends
+        l = extend_match(T, (uint32_t)i, k, l);
+        lcp[j] = l;
+        l = l > 0 ? l - 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bwt_exact_search_kernel(const uint32_t *__restrict__ c_table,
+                                                                  const uint32_t *__restrict__ o_table, uint64_t N,
+                                                                  uint32_t sigma, const uint8_t *__restrict__ patterns,
+                                                                  const uint32_t *__restrict__ offsets, uint32_t count,
+                                                                  uint32_t *__restrict__ out_l,
+                                                                  uint32_t *__restrict__ out_r)
+{
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= count) return;
+    const uint32_t begin = offsets[q], m = offsets[q + 1] - begin;
+    uint32_t L = 0, R = (uint32_t)N;
+    if ((uint64_t)m > N) { // bwt.c:178-180: a pattern longer than the text cannot match
+        R = 0;
+        L = 1;
+    }
+    for (uint32_t s = m; s-- > 0 && L < R;) {
+        const uint32_t a = patterns[begin + s];
+        if (a == 0 || a >= sigma) { // the reference asserts 0 < a < alphabet_size: no match here
+            L = 1;
+            R = 0;
+            break;
+        }
+        L = c_table[a] + o_table[(uint64_t)L * sigma + a];
+        R = c_table[a] + o_table[(uint64_t)R * sigma + a];
+    }
+    out_l[q] = L;
+    out_r[q] = R;
+}
+
+} // namespace sx
+
+using namespace sx;
+
+static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv)
+{
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, 4096));
+    uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
+    SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+    sx_launch(ctx, SX_KC_MISC, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
+    uint32_t h_bad = 0;
+    SX_TRY(sx_readback(ctx, bad, 1, &h_bad));
+    if (h_bad) return sx_fail_msg(ctx, SX_E_ARG, "sa holds an entry outside [0, N)");
+    return 0;
+}
+
+static int lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv_opt,
+                   uint32_t *d_lcp)
+{
+    const uint64_t n = N - 1;
+    const size_t text_b = (n + 128 + 255) & ~(size_t)255;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, text_b + (d_inv_opt ? 0 : N * 4 + 256) + 256));
+    uint8_t *T = (uint8_t *)ctx->slab[SX_SLAB_N].p; // padded copy: text[n] = 0 and zeros behind it
+    uint32_t *inv = d_inv_opt ? d_inv_opt : (uint32_t *)((char *)ctx->slab[SX_SLAB_N].p + text_b);
+    if (n) SX_CHECK(hipMemcpyAsync(T, d_text, n, hipMemcpyDeviceToDevice, ctx->stream));
+    SX_CHECK(hipMemsetAsync(T + n, 0, text_b - n, ctx->stream));
+    SX_TRY(inverse_dev(ctx, d_sa, N, inv));
+    const uint64_t chunks = (N + kLcpChunk - 1) / kLcpChunk;
+    sx_launch(ctx, SX_KC_MISC, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
+              (const uint32_t *)inv, N, d_lcp);
+    return 0;
+}
+
+extern "C" {
+
+int sx_sa_inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv_out)
+{
+    if (!ctx || !d_sa || !d_inv_out || N == 0 || N > 0xFFFFFFFFull) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(inverse_dev(ctx, d_sa, N, d_inv_out));
+    return sx_sync(ctx);
+}
+
+int sx_sa_lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv_out,
+                  uint32_t *d_lcp_out)
+{
+    if (!ctx || !d_sa || !d_lcp_out || N == 0 || N > 0xFFFFFFFFull || (N > 1 && !d_text)) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(lcp_dev(ctx, d_text, d_sa, N, d_inv_out, d_lcp_out));
+    return sx_sync(ctx);
+}
+
+int sx_sa_inverse_lcp(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t N, uint32_t *inv_out,
+                      uint32_t *lcp_out)
+{
+    if (!ctx || !sa || N == 0 || N > 0xFFFFFFFFull || (N > 1 && !text) || (!inv_out && !lcp_out)) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n = N - 1;
+    const size_t text_b = (n + 255) & ~(size_t)255, arr_b = (N * 4 + 255) & ~(size_t)255;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, text_b + 3 * arr_b + 1024));
+    char *base = (char *)ctx->slab[SX_SLAB_IO].p;
+    uint8_t *d_text = (uint8_t *)base;
+    uint32_t *d_sa = (uint32_t *)(base + text_b + 256), *d_inv = (uint32_t *)(base + text_b + 256 + arr_b),
+             *d_lcp = (uint32_t *)(base + text_b + 256 + 2 * arr_b);
+    if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
+    SX_CHECK(hipMemcpyAsync(d_sa, sa, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (lcp_out) SX_TRY(lcp_dev(ctx, d_text, d_sa, N, d_inv, d_lcp));
+    else SX_TRY(inverse_dev(ctx, d_sa, N, d_inv));
+    if (inv_out) SX_CHECK(hipMemcpyAsync(inv_out, d_inv, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (lcp_out) SX_CHECK(hipMemcpyAsync(lcp_out, d_lcp, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sx_sync(ctx);
+}
+
+int sx_bwt_exact_search_dev(sx_ctx *ctx, const uint32_t *d_c_table, const uint32_t *d_o_table, uint64_t N,
+                            uint32_t sigma, const uint8_t *d_patterns, const uint32_t *d_offsets, uint32_t count,
+                            uint32_t *d_l_out, uint32_t *d_r_out)
+{
+    if (!ctx || !d_c_table || !d_o_table || !d_offsets || !d_l_out || !d_r_out || N == 0 || N > 0xFFFFFFFFull ||
+        sigma < 1 || sigma > 256)
+        return SX_E_ARG;
+    if (count == 0) return 0;
+    SX_CHECK(hipSetDevice(ctx->device));
+    sx_launch(ctx, SX_KC_MISC, 0, bwt_exact_search_kernel, dim3(sx_div_up(count, kBlock)), dim3(kBlock), d_c_table,
+              d_o_table, N, sigma, d_patterns, d_offsets, count, d_l_out, d_r_out);
+    return sx_sync(ctx);
+}
+
+} // extern "C"

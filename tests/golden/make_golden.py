@@ -104,6 +104,33 @@ def main():
                                             np.full(8200, 3, np.uint8), [4]]).astype(np.uint8),
         pre_remapped_sigma=5)
 
+    # "next" rows: inverse + LCP (suffix_array.c:53-85) and exact BWT search intervals
+    # (bwt.c:164-199) from the reference, for a subset of the cases above
+    nxt = {}
+    for name in ("ref/ababacabac", "ref/mississippi", "ref/serialise", "ref/modest-proposal", "ref/repetitive",
+                 "struct/fibonacci", "struct/periodic", "struct/all-a", "rand/s5/n65536", "rand/s21/n1000"):
+        sym, sigma = cases[name + "/sym"], int(cases[name + "/sigma"][0])
+        sa, inv, lcp = ref.lcp(sym, sigma)
+        assert (sa == cases[name + "/sa"]).all()
+        nxt[name + "/inverse"] = inv
+        nxt[name + "/lcp"] = lcp
+    prng = np.random.default_rng(7)
+    for name in ("ref/mississippi", "ref/serialise", "ref/fasta0", "ref/fasta3", "struct/periodic", "ref/repetitive"):
+        raw = bytes(cases[name + "/raw"])
+        pats = [raw[i:i + L] for L in (1, 2, 3, 5, 9, 17) for i in prng.integers(0, max(1, len(raw) - L), size=6)
+                if 0 < len(raw[i:i + L])]
+        letters = sorted(set(raw))
+        pats += [bytes(prng.choice(letters, size=L).astype(np.uint8)) for L in (2, 4, 7, 12) for _ in range(6)]
+        pats += [raw, raw + raw[:1]]  # the whole text, and a pattern longer than the text
+        res = ref.exact_search(raw, pats)
+        flat = np.concatenate([r[2] for r in res]).astype(np.uint8)
+        offs = np.concatenate(([0], np.cumsum([r[2].size for r in res]))).astype(np.uint32)
+        nxt[name + "/patterns"] = flat
+        nxt[name + "/offsets"] = offs
+        nxt[name + "/lr"] = np.array([[r[0], r[1]] for r in res], dtype=np.uint32)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_next.npz"), **nxt)
+    print(f"{len(nxt)} arrays -> golden_next.npz")
+
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz")
     np.savez_compressed(out, **cases)
     names = sorted({k.rsplit("/", 1)[0] for k in cases})

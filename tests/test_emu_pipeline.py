@@ -102,6 +102,23 @@ def test_fused_build_tables(emu_ctx, golden):
         assert (ot == oracle.o_table(x, want, sigma)).all(), (sigma, n)
 
 
+def test_next_rows(emu_ctx, golden):
+    """inverse, LCP and batched exact search kernels against the reference's vectors"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_next.npz"))
+    for name in ("ref/mississippi", "ref/repetitive", "struct/fibonacci", "struct/all-a", "rand/s21/n1000"):
+        c = golden[name]
+        inv, lcp = emu_ctx.inverse_lcp(c["sym"], c["sa"])
+        assert (inv == z[name + "/inverse"]).all() and (lcp == z[name + "/lcp"]).all(), name
+    for name in ("ref/mississippi", "ref/fasta3", "struct/periodic"):
+        c = golden[name]
+        pats, offs, lr = z[name + "/patterns"], z[name + "/offsets"], z[name + "/lr"]
+        l, r = np.zeros(lr.shape[0], np.uint32), np.zeros(lr.shape[0], np.uint32)
+        emu_ctx.bwt_exact_search_dev(np.ascontiguousarray(c["c"]), np.ascontiguousarray(c["o"]), c["sa"].size, c["sigma"],
+                                     pats, offs, lr.shape[0], l, r)
+        assert (l == lr[:, 0]).all() and (r == lr[:, 1]).all(), name
+
+
 def test_primitives(emu_ctx):
     rng = np.random.default_rng(1)
     n = 5000

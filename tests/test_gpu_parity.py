@@ -301,6 +301,35 @@ def test_reference_named_c_api(gpu_ctx, golden):
     lib.free_suffix_array(b)
 
 
+def test_next_rows_inverse_lcp_search(gpu_ctx, golden):
+    """SURVEY 8f rows 3 and 4 on the device: compute_inverse / compute_lcp and batched exact BWT search,
+    against the reference's vectors and the oracle"""
+    import torch
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_next.npz"))
+    for name in sorted({k.rsplit("/", 1)[0] for k in z.files}):
+        c = golden[name]
+        if name + "/lcp" in z.files:
+            inv, lcp = gpu_ctx.inverse_lcp(c["sym"], c["sa"])
+            assert (inv == z[name + "/inverse"]).all() and (lcp == z[name + "/lcp"]).all(), name
+        if name + "/lr" in z.files:
+            pats, offs, lr = z[name + "/patterns"], z[name + "/offsets"], z[name + "/lr"]
+            dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda()
+            l = torch.zeros(lr.shape[0], dtype=torch.int32, device="cuda")
+            r = torch.zeros_like(l)
+            gpu_ctx.bwt_exact_search_dev(dev(c["c"], np.int32), dev(c["o"], np.int32), c["sa"].size, c["sigma"],
+                                         dev(pats, np.uint8), dev(offs, np.int32), lr.shape[0], l, r)
+            assert (l.cpu().numpy().view(np.uint32) == lr[:, 0]).all(), name
+            assert (r.cpu().numpy().view(np.uint32) == lr[:, 1]).all(), name
+    # larger, against the oracle
+    x = synth(1 << 22, 5, 5)
+    sa = gpu_ctx.sa_build(x, 5)
+    inv, lcp = gpu_ctx.inverse_lcp(x, sa)
+    assert (inv == oracle.inverse(sa)).all() and (lcp == oracle.lcp(x, sa)).all()
+    y = np.tile(synth(3000, 5, 6), 40)  # repetitive: long common prefixes
+    sa = gpu_ctx.sa_build(y, 5)
+    assert (gpu_ctx.inverse_lcp(y, sa)[1] == oracle.lcp(y, sa)).all()
+
+
 def test_c_batch_farm(gpu_ctx, golden):
     """stralg_amd_build_tables_batch: independent records, one host thread (and context) per listed device;
     here two threads share GPU 0, which also exercises concurrent contexts"""

@@ -44,6 +44,27 @@ def test_golden_vectors(golden):
             assert (oracle.o_table(rsym, rsa, sigma) == c["ro"]).all(), name
 
 
+def test_next_rows_golden(golden):
+    """inverse / LCP (suffix_array.c:53-85) and exact-search intervals (bwt.c:164-199) from the reference"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_next.npz"))
+    names = sorted({k.rsplit("/", 1)[0] for k in z.files})
+    n_lcp = n_search = 0
+    for name in names:
+        c = golden[name]
+        if name + "/lcp" in z.files:
+            assert (oracle.inverse(c["sa"]) == z[name + "/inverse"]).all(), name
+            assert (oracle.lcp(c["sym"], c["sa"]) == z[name + "/lcp"]).all(), name
+            n_lcp += 1
+        if name + "/lr" in z.files:
+            pats, offs, lr = z[name + "/patterns"], z[name + "/offsets"], z[name + "/lr"]
+            for q in range(lr.shape[0]):
+                got = oracle.bwt_exact_search(c["c"], c["o"], c["sigma"], pats[offs[q]: offs[q + 1]])
+                assert got == (int(lr[q, 0]), int(lr[q, 1])), (name, q)
+            n_search += lr.shape[0]
+    assert n_lcp >= 8 and n_search > 200
+
+
 def test_naive_agrees():
     rng = np.random.default_rng(5)
     for sigma in (2, 4, 17):
