@@ -1,0 +1,31 @@
+"""timings of the "next" rows: inverse + LCP, batched exact BWT search, with the oracle beside
+them on a bounded sample (GPU box)"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+import stralg_amd, oracle
+ctx = stralg_amd.Context(0)
+log2n, sigma = 28, 5
+n = 1 << log2n; N = n + 1
+text = torch.empty(n, dtype=torch.uint8, device="cuda"); ctx.synth_dev(text, n, sigma, 42)
+sa = torch.empty(N, dtype=torch.int32, device="cuda"); bwt = torch.empty(N, dtype=torch.uint8, device="cuda")
+ctx.sa_bwt_build_dev(text, n, sigma, sa, bwt)
+inv = torch.empty(N, dtype=torch.int32, device="cuda"); lcp = torch.empty(N, dtype=torch.int32, device="cuda")
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.sa_lcp_dev(text, sa, N, inv, lcp); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"inverse + LCP, 2^{log2n} DNA: {dt*1e3:.1f} ms = {N/dt/1e6:.0f} Mpositions/s; max lcp {int(lcp.max())}")
+ns = 1 << 24
+xs = stralg_amd.synth(ns, sigma, 42); sas = oracle.sa_is(xs, sigma)
+t0 = time.perf_counter(); oracle.lcp(xs, sas); dt = time.perf_counter() - t0
+print(f"oracle compute_lcp on 2^24 symbols: {dt*1e3:.0f} ms = {ns/dt/1e6:.1f} Mpositions/s (1 core)")
+c = torch.zeros(sigma, dtype=torch.int32, device="cuda"); o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
+ctx.bwt_tables_from_bwt_dev(bwt, N, sigma, c, o)
+q, m = 10_000_000, 30
+starts = torch.randint(0, n - m, (q,), device="cuda")
+idx = (starts[:, None] + torch.arange(m, device="cuda")[None, :]).reshape(-1)
+pats = text[idx].contiguous(); offs = (torch.arange(q + 1, device="cuda") * m).to(torch.int32)
+l = torch.zeros(q, dtype=torch.int32, device="cuda"); r = torch.zeros_like(l)
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.bwt_exact_search_dev(c, o, N, sigma, pats, offs, q, l, r); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+hits = int(((r - l) > 0).sum())
+print(f"exact search, {q} patterns x {m} symbols over 2^{log2n}: {dt*1e3:.1f} ms = {q/dt/1e6:.1f} Mpatterns/s ({q*m*2/dt/1e9:.2f} G table look-ups/s), {hits} found")
