@@ -265,7 +265,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         ks = in_b ? kb : ka;
         vs = in_b ? vb : va;
         // members of groups with equal keys
-        SX_TRY((device_scan<OpAdd>(ctx, m, InTied{ks, m, kmask},
+        SX_TRY((device_compact(ctx, m, InTied{ks, m, kmask},
                                    OutTied{ks, vs, apos, ap, head, cap, kmask, embed ? seedw : nullptr, (uint32_t)kbits}, d_scalar,
                                    SX_KC_NAMES, m * 16)));
         SX_TRY(sx_readback(ctx, d_scalar, 1, &A));

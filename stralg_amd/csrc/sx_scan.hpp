@@ -109,6 +109,86 @@ static inline int device_scan(sx_ctx *ctx, uint64_t n, In in, Out out, uint32_t 
     return 0;
 }
 
+// ---- stream compaction of 0/1 flags -------------------------------------------------------
+//   device_compact(ctx, n, flag, out, d_total)
+//     flag(i)          -> bool
+//     out(i, dst, f)   <- called for every i; dst = number of set flags before i
+// Same three launches as device_scan, but the elements are visited in striped order (lane l of
+// row k reads element tile + k*256 + l: coalesced), and because the values are single bits the
+// prefix inside a row is a ballot and a popcount instead of a shuffle scan.
+template <class Flag>
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(Flag flag, uint64_t n, uint32_t *tile_tot)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint64_t i = tile0 + (uint64_t)k * kBlock + threadIdx.x;
+        cnt += (uint32_t)__popcll(__ballot((i < n && flag(i)) ? 1 : 0));
+    }
+    if (lane_id() == 0) lds[wave_id()] = cnt; // every lane of a wave holds the wave's count
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) tot += lds[w];
+        tile_tot[blockIdx.x] = tot;
+    }
+}
+
+template <class Flag, class Out>
+__global__ __launch_bounds__(kBlock) void compact_apply_kernel(Flag flag, Out out, uint64_t n,
+                                                               const uint32_t *tile_pre)
+{
+    __shared__ uint32_t cnt[kScanItems][kWavesPerBlock];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
+    const int w = wave_id();
+    bool f[kScanItems];
+    uint32_t below[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint64_t i = tile0 + (uint64_t)k * kBlock + threadIdx.x;
+        f[k] = i < n && flag(i);
+        const uint64_t m = __ballot(f[k] ? 1 : 0);
+        below[k] = (uint32_t)__popcll(m & lanemask_lt());
+        if (lane_id() == 0) cnt[k][w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t run = tile_pre[blockIdx.x]; // set flags before (row k, wave w), rows and waves in order
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        uint32_t before_wave = 0, row_total = 0;
+#pragma unroll
+        for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+            const uint32_t c = cnt[k][ww];
+            if (ww < w) before_wave += c;
+            row_total += c;
+        }
+        const uint64_t i = tile0 + (uint64_t)k * kBlock + threadIdx.x;
+        if (i < n) out(i, run + before_wave + below[k], f[k]);
+        run += row_total;
+    }
+}
+
+template <class Flag, class Out>
+static inline int device_compact(sx_ctx *ctx, uint64_t n, Flag flag, Out out, uint32_t *d_total, int kclass = SX_KC_SCAN,
+                                 uint64_t alg_bytes = 0)
+{
+    if (n == 0) {
+        if (d_total) SX_CHECK(hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
+        return 0;
+    }
+    const uint32_t ntiles = sx_div_up(n, kScanTile);
+    uint32_t *tile_tot = sx_scan_scratch(ctx, ntiles);
+    if (!tile_tot) return sx_fail_msg(ctx, SX_E_NOMEM, "scan scratch");
+    sx_launch(ctx, kclass, alg_bytes / 2, compact_count_kernel<Flag>, dim3(ntiles), dim3(kBlock), flag, n, tile_tot);
+    sx_launch(ctx, kclass, 0, scan_spine_kernel<OpAdd>, dim3(1), dim3(kBlock), tile_tot, ntiles, d_total);
+    sx_launch(ctx, kclass, alg_bytes - alg_bytes / 2, compact_apply_kernel<Flag, Out>, dim3(ntiles), dim3(kBlock), flag, out,
+              n, (const uint32_t *)tile_tot);
+    return 0;
+}
+
 // ---- common functors ------------------------------------------------------
 struct InU32 {
     const uint32_t *p;
