@@ -109,18 +109,12 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     }
     if (ti.m > 1 && !ctx->force_general) {
         // fast path: radix sort of the LMS suffixes by their first 64/b symbols (sx_lmssort.hip)
-        SX_TRY(sx_sample_flags(ctx, ti, 0xFFFFFFFFu)); // no cut points: samples == LMS positions
-        if (ti.M != ti.m) return sx_fail_msg(ctx, SX_E_INTERNAL, "LMS compaction count differs from the histogram");
-        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(ti.m) + ti.m * 5 + 1024));
+        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(ti.m) + 1024));
         sx_arena am;
         am.base = (char *)ctx->slab[SX_SLAB_M].p;
         am.cap = ctx->slab[SX_SLAB_M].cap;
-        uint32_t *pos = am.take<uint32_t>(ti.m);
-        uint8_t *is_lms = am.take<uint8_t>(ti.m);
-        if (!pos || !is_lms) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS positions");
-        SX_TRY(sx_sample_write(ctx, ti, pos, is_lms));
         int resolved = 0;
-        SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, pos, &sorted_lms, &seed_windows, &resolved));
+        SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, &sorted_lms, &seed_windows, &resolved));
         if (resolved) {
             ctx->stats.lms_path = 1;
             ctx->stats.n_samples = ti.m;

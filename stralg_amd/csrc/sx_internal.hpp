@@ -59,8 +59,8 @@ int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const 
 
 // ---- sx_lmssort.hip
 size_t sx_lms_prefix_bytes(uint64_t m);
-int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t *pos,
-                          const uint32_t **out, const void **seed_windows, int *resolved);
+int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t **out,
+                          const void **seed_windows, int *resolved);
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);

@@ -49,22 +49,40 @@ __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, ui
     return acc;
 }
 
-__global__ __launch_bounds__(kBlock) void lms_prefix_keys_kernel(const uint8_t *__restrict__ T,
-                                                                 const uint32_t *__restrict__ pos, uint64_t m,
-                                                                 uint32_t base, uint32_t C, uint32_t kbits, wnd_cfg wcfg,
-                                                                 uint64_t *__restrict__ keys,
-                                                                 uint32_t *__restrict__ vals)
+// One workgroup per classification tile (4096 text positions): the tile's LMS positions are
+// listed in LDS from the LMS bit array, then every thread turns listed positions into
+// (key, position) pairs at the tile's offset in the global LMS order.  This is the compaction of
+// the LMS positions (role of sa_is.c:203-218 place_LMS's scan) and the key generation in one pass.
+__global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__restrict__ T,
+                                                               const uint16_t *__restrict__ lmsbits,
+                                                               const uint32_t *__restrict__ tile_off, uint32_t base,
+                                                               uint32_t C, uint32_t kbits, wnd_cfg wcfg,
+                                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= m) return;
-    const uint32_t p = pos[k];
-    uint64_t key = prefix_key(T, p, base, C);
-    // The key bits above kbits are not sorted on, they just ride along: put the suffix's
-    // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
-    // this part of the text is in cache, instead of gathering it again after the sort.
-    if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
-    keys[k] = key;
-    vals[k] = p;
+    __shared__ uint32_t lds[kWavesPerBlock];
+    __shared__ uint32_t spos[kClsTile / 2 + 1]; // LMS positions are at least two apart
+    const int t = (int)threadIdx.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)t * kClsPerThread;
+    uint32_t mask = lmsbits[(uint64_t)blockIdx.x * kBlock + t];
+    uint32_t total;
+    uint32_t at = block_exclusive_scan<OpAdd>((uint32_t)__popc(mask), lds, total);
+    while (mask) {
+        const int i = __ffs(mask) - 1;
+        mask &= mask - 1u;
+        spos[at++] = (uint32_t)(p0 + i);
+    }
+    __syncthreads();
+    const uint32_t dst0 = tile_off[blockIdx.x];
+    for (uint32_t i = (uint32_t)t; i < total; i += kBlock) {
+        const uint32_t p = spos[i];
+        uint64_t key = prefix_key(T, p, base, C);
+        // The key bits above kbits are not sorted on, they just ride along: put the suffix's
+        // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
+        // this part of the text is in cache, instead of gathering it again after the sort.
+        if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
+        keys[dst0 + i] = key;
+        vals[dst0 + i] = p;
+    }
 }
 
 // members of groups of equal keys: (index in the sorted order, text position, group head index)
@@ -200,8 +218,8 @@ size_t sx_lms_prefix_bytes(uint64_t m)
 
 // Returns 0 and *resolved = 1 with *out = device array of the m LMS suffix positions in
 // suffix order; *resolved = 0 when the caller must use the general path.
-int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t *pos,
-                          const uint32_t **out, const void **seed_windows, int *resolved)
+int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t **out,
+                          const void **seed_windows, int *resolved)
 {
     *resolved = 0;
     *seed_windows = nullptr;
@@ -236,6 +254,10 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
     const dim3 block(kBlock);
 
+    // offset of every classification tile in the global order of the LMS positions
+    uint32_t *tile_lms = ti.tile_u32, *tile_off = ti.tile_u32 + 4 * (size_t)ti.ntiles;
+    SX_TRY((device_scan<OpAdd>(ctx, ti.ntiles, InU32{tile_lms}, OutExclusive{tile_off}, nullptr)));
+
     const uint64_t *ks = nullptr;
     uint32_t *vs = nullptr;
     uint32_t A = 0;
@@ -258,8 +280,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         embed = wchars >= 4;
         wcfg.CW = embed ? wchars : 0;
         kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
-        sx_launch(ctx, SX_KC_KEYS, m * (4 + 12) + ti.N, lms_prefix_keys_kernel, dim3(sx_div_up(m, kBlock)), block,
-                  ti.T, pos, m, base, C, (uint32_t)kbits, wcfg, ka, va);
+        sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
+                  (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, base, C, (uint32_t)kbits, wcfg, ka, va);
         int in_b = 0;
         SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b));
         ks = in_b ? kb : ka;
@@ -307,7 +329,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                   (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid, (const uint64_t *)key_keep,
                   (uint64_t)A, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
         // keep what is still tied
-        SX_TRY((device_scan<OpAdd>(ctx, A, InStillTied{head_new, A},
+        SX_TRY((device_compact(ctx, A, InStillTied{head_new, A},
                                    OutStillTied{apos, ap_new, head_new, apos2, ap2, head2}, d_scalar, SX_KC_DOUBLING,
                                    (uint64_t)A * 20)));
         uint32_t A2 = 0;

@@ -147,7 +147,7 @@ using namespace sx;
 int sx_name_pieces(sx_ctx *ctx, const uint64_t *ks, const uint32_t *vs, uint64_t M, sx_reduce_bufs &rb,
                    uint64_t *n_names)
 {
-    SX_TRY((device_scan<OpAdd>(ctx, M, InKeyBoundary{ks}, OutNames{vs, rb.R}, rb.d_scalar, SX_KC_NAMES,
+    SX_TRY((device_compact(ctx, M, InKeyBoundary{ks}, OutNames{vs, rb.R}, rb.d_scalar, SX_KC_NAMES,
                                M * (2 * 8 + 4 + 4))));
     uint32_t boundaries = 0;
     SX_TRY(sx_readback(ctx, rb.d_scalar, 1, &boundaries));
@@ -182,7 +182,7 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
         SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidRank{sa, rb.gid, rb.rank}, nullptr,
                                    SX_KC_DOUBLING, A * (1 + 4 + 4 + 4 + 4))));
         // b+d. drop singleton groups; build (group, rank[i+h]) keys for the rest
-        SX_TRY((device_scan<OpAdd>(ctx, A, InKeep{head, A},
+        SX_TRY((device_compact(ctx, A, InKeep{head, A},
                                    OutKeep{pos, sa, rb.gid, rb.rank, pos2, vfree, kfree, h, M, rbits},
                                    rb.d_scalar, SX_KC_DOUBLING, A * (2 + 4 + 4 + 4 + 4 + 16))));
         uint32_t A2 = 0;
@@ -220,6 +220,6 @@ int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const 
                   M, sorted_lms, d_total);
         return 0;
     }
-    return device_scan<OpAdd>(ctx, M, InIsLms{sa_r, is_lms}, OutLmsPos{sa_r, pos, sorted_lms}, d_total,
+    return device_compact(ctx, M, InIsLms{sa_r, is_lms}, OutLmsPos{sa_r, pos, sorted_lms}, d_total,
                               SX_KC_DOUBLING, M * (2 * (4 + 1) + 8));
 }
