@@ -398,6 +398,37 @@ def _verify_sa_on_device(text_u8, sa_i32, n):
     assert bool(ok.all()), "suffixes out of order"
 
 
+def test_beyond_31_bits(gpu_ctx):
+    """n = 2^31 + 12345: positions no longer fit a signed 32-bit integer (the API promises n <= 2^32 - 2)"""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs ~150 GiB of device memory")
+    n = (1 << 31) + 12345
+    text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.synth_dev(text, n, 5, 99)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    gpu_ctx.sa_build_dev(text, n, 5, sa)
+    gpu_ctx.trim()  # the verification below needs the memory
+    N = n + 1
+    assert int(sa[0]) & 0xFFFFFFFF == n
+    pos = sa.long() & 0xFFFFFFFF
+    del sa
+    rank = torch.full((N + 1,), -1, dtype=torch.int64, device="cuda")
+    rank[pos] = torch.arange(N, dtype=torch.int64, device="cuda")
+    assert bool((rank[:N] >= 0).all()), "not a permutation"
+    T = torch.zeros(N + 1, dtype=torch.uint8, device="cuda")
+    T[:n] = text
+    del text
+    step = 1 << 28
+    for s0 in range(1, N - 1, step):
+        e0 = min(N - 1, s0 + step)
+        a, b = pos[s0:e0], pos[s0 + 1:e0 + 1]
+        ca, cb = T[a], T[b]
+        ok = (ca < cb) | ((ca == cb) & (rank[a + 1] < rank[b + 1]))
+        assert bool(ok.all()), f"suffixes out of order in slots [{s0}, {e0})"
+
+
 @pytest.mark.parametrize("log2n,sigma", [(28, 5), (30, 5), (28, 256)])
 def test_full_size_properties(gpu_ctx, log2n, sigma):
     import torch
