@@ -114,14 +114,27 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     const int t = (int)threadIdx.x;
     const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
     const uint64_t r0 = tile0 + (uint64_t)t * kRows;
+    // the tile's starting counts: asked for first, needed only after the block scan
+    uint32_t pre[SIG];
+#pragma unroll
+    for (int a = 0; a < SIG; ++a)
+        pre[a] = (uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u;
     uint32_t sym[kRows];
     // per-thread symbol counts as 16-bit fields of two u64 (symbols 0-3, 4-7): a tile holds at most
     // 1024 symbols, so one 64-bit block scan replaces four 32-bit ones
     uint64_t pk[2] = {0, 0};
+    if (r0 + kRows <= N && ((uintptr_t)bwt & 7u) == 0) { // the thread's symbols in one load (kRows is 4 or 8)
+        uint64_t word;
+        if (kRows == 8) word = *reinterpret_cast<const uint64_t *>(bwt + r0);
+        else word = *reinterpret_cast<const uint32_t *>(bwt + r0);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) sym[k] = (uint32_t)(word >> (8 * k)) & 0xFFu;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) sym[k] = r0 + k < N ? (uint32_t)bwt[r0 + k] : 0xFFu;
+    }
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
-        const uint64_t i = r0 + k;
-        sym[k] = i < N ? (uint32_t)bwt[i] : 0xFFu;
         const uint64_t one = 1ull << (16u * (sym[k] & 3u));
         if (sym[k] < 4u) pk[0] += one; // static indices: the pair stays in registers
         else if (sym[k] < (uint32_t)SIG) pk[1] += one;
@@ -134,8 +147,7 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int a = 4 * h + f;
-            if (a < SIG) run[a] = (uint32_t)((ex >> (16 * f)) & 0xFFFFull) +
-                     ((uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u);
+            if (a < SIG) run[a] = (uint32_t)((ex >> (16 * f)) & 0xFFFFull) + pre[a];
         }
     }
     if (sigma == (uint32_t)SIG && (kRows * SIG) % 4 == 0) {

@@ -85,6 +85,10 @@ int sx_slab_ensure(sx_ctx *ctx, int which, size_t bytes);
 int sx_sync(sx_ctx *ctx);
 // device -> pinned host copy of `count` u32 followed by a stream sync
 int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst);
+// look-back status memory: a slab of (epoch-tagged) status words, zeroed whenever it is (re)allocated
+int sx_chain_slab(sx_ctx *ctx, int which, size_t bytes);
+// a fresh epoch for one chained launch (24 bits; every status slab is zeroed when they wrap)
+uint32_t sx_chain_next_epoch(sx_ctx *ctx);
 
 void sx_prof_begin(sx_ctx *ctx, int kclass);
 void sx_prof_end(sx_ctx *ctx, int kclass, uint64_t alg_bytes);

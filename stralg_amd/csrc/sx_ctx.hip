@@ -50,6 +50,25 @@ uint32_t *sx::sx_scan_scratch(sx_ctx *ctx, uint32_t ntiles)
     return (uint32_t *)ctx->slab[SX_SLAB_SCAN].p;
 }
 
+int sx_chain_slab(sx_ctx *ctx, int which, size_t bytes)
+{
+    const size_t before = ctx->slab[which].cap;
+    SX_TRY(sx_slab_ensure(ctx, which, bytes));
+    if (ctx->slab[which].cap != before) // new memory holds arbitrary bits: epoch 0 never matches a launch
+        SX_CHECK(hipMemsetAsync(ctx->slab[which].p, 0, ctx->slab[which].cap, ctx->stream));
+    return 0;
+}
+
+uint32_t sx_chain_next_epoch(sx_ctx *ctx)
+{
+    if (ctx->chain_epoch + 1 >= (1u << 24)) { // about to wrap: retire every old status word
+        if (ctx->slab[SX_SLAB_CHAIN].p)
+            (void)hipMemsetAsync(ctx->slab[SX_SLAB_CHAIN].p, 0, ctx->slab[SX_SLAB_CHAIN].cap, ctx->stream);
+        ctx->chain_epoch = 0;
+    }
+    return ++ctx->chain_epoch;
+}
+
 int sx_sync(sx_ctx *ctx)
 {
     SX_CHECK(hipStreamSynchronize(ctx->stream));

@@ -142,35 +142,38 @@ __device__ __forceinline__ uint64_t chain_pack(uint32_t epoch, uint32_t state, u
     return ((uint64_t)epoch << 40) | ((uint64_t)state << 38) | (uint64_t)value;
 }
 
-// Called by the thread that owns digit d of tile `tile`; returns the sum of `count`
-// over tiles [0, tile) and publishes this tile's inclusive prefix.
-__device__ __forceinline__ uint32_t chain_exclusive_prefix(uint64_t *__restrict__ status, uint32_t ndigits,
-                                                           uint32_t tile, uint32_t d, uint32_t count,
-                                                           uint32_t epoch)
+// Step 1, as early as the tile knows its counts: publish them (tile 0 publishes its inclusive
+// prefix straight away).
+__device__ __forceinline__ void chain_publish(uint64_t *__restrict__ status, uint32_t ndigits, uint32_t tile,
+                                              uint32_t d, uint32_t count, uint32_t epoch)
 {
+    uint64_t *mine = status + kChainHeader + (uint64_t)tile * ndigits + d;
+    __hip_atomic_store(mine, chain_pack(epoch, tile == 0 ? 2u : 1u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Step 2, by the same thread: the sum of `count` over tiles [0, tile), walking back over the
+// predecessors BATCH status words at a time (the tiles of a launch that start together cannot
+// see each other's inclusive prefixes yet, so walks are as long as the number of tiles in flight:
+// without the batching every step would cost a full L2 round trip); then publish the inclusive
+// prefix of this tile.
+template <int BATCH>
+__device__ __forceinline__ uint32_t chain_lookback(uint64_t *__restrict__ status, uint32_t ndigits, uint32_t tile,
+                                                   uint32_t d, uint32_t count, uint32_t epoch)
+{
+    if (tile == 0) return 0u;
     uint64_t *words = status + kChainHeader;
-    uint64_t *mine = words + (uint64_t)tile * ndigits + d;
-    if (tile == 0) {
-        __hip_atomic_store(mine, chain_pack(epoch, 2u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0u;
-    }
-    __hip_atomic_store(mine, chain_pack(epoch, 1u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Walk back over the predecessors, kChainBatch status words in flight at a time (the
-    // first wave of tiles of a launch starts together, so early walks are long: without
-    // the batching every step would cost a full L2 round trip).
-    constexpr int kChainBatch = 8;
     uint32_t prefix = 0;
     bool done = false;
     uint32_t j = tile; // predecessors still to visit: j-1, j-2, ...
     while (!done && j > 0) {
-        uint64_t w[kChainBatch];
+        uint64_t w[BATCH];
 #pragma unroll
-        for (int i = 0; i < kChainBatch; ++i) {
+        for (int i = 0; i < BATCH; ++i) {
             const uint32_t idx = j > (uint32_t)i ? j - 1u - (uint32_t)i : 0u;
             w[i] = __hip_atomic_load(words + (uint64_t)idx * ndigits + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int i = 0; i < kChainBatch; ++i) {
+        for (int i = 0; i < BATCH; ++i) {
             if (!done && j > (uint32_t)i) {
                 const uint64_t *theirs = words + (uint64_t)(j - 1u - (uint32_t)i) * ndigits + d;
                 uint64_t x = w[i];
@@ -188,10 +191,20 @@ __device__ __forceinline__ uint32_t chain_exclusive_prefix(uint64_t *__restrict_
                 if (((x >> 38) & 3ull) == 2ull) done = true;
             }
         }
-        j = j > (uint32_t)kChainBatch ? j - (uint32_t)kChainBatch : 0u;
+        j = j > (uint32_t)BATCH ? j - (uint32_t)BATCH : 0u;
     }
-    __hip_atomic_store(mine, chain_pack(epoch, 2u, prefix + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(words + (uint64_t)tile * ndigits + d, chain_pack(epoch, 2u, prefix + count), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
     return prefix;
+}
+
+// Called by the thread that owns digit d of tile `tile`: publish, walk back, publish again.
+__device__ __forceinline__ uint32_t chain_exclusive_prefix(uint64_t *__restrict__ status, uint32_t ndigits,
+                                                           uint32_t tile, uint32_t d, uint32_t count,
+                                                           uint32_t epoch)
+{
+    chain_publish(status, ndigits, tile, d, count, epoch);
+    return chain_lookback<8>(status, ndigits, tile, d, count, epoch);
 }
 
 // Wave-wide form for small digit counts: the whole wave (all 64 lanes must call) looks

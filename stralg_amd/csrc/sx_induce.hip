@@ -65,7 +65,25 @@ __global__ __launch_bounds__(kBlock) void fill_windows_kernel(const uint8_t *__r
 // the round belongs to the other.
 // (threshold: sx_ctx::chain_max_entries, default 256 tiles; SX_FLAG_CHAIN_MAX_ENTRIES)
 
-template <class WT>
+// four consecutive entries from 16-byte loads
+__device__ __forceinline__ void load_quad(const uint32_t *__restrict__ p, uint32_t (&o)[4])
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+}
+__device__ __forceinline__ void load_quad(const uint64_t *__restrict__ p, uint64_t (&o)[4])
+{
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(p), v1 = *reinterpret_cast<const uint4 *>(p + 2);
+    o[0] = pack64(v0.x, v0.y), o[1] = pack64(v0.z, v0.w), o[2] = pack64(v1.x, v1.y), o[3] = pack64(v1.z, v1.w);
+}
+
+// Only the windows are read: a stored window is empty exactly when its entry is position 0
+// (which induces nothing); every other window is refilled from the text the moment it runs
+// dry.  The counts of a tile do not depend on the order of its entries, so the tile's index
+// range is read as aligned quads (16 bytes per lane per load); the one or two quads that straddle
+// the range ends are read entry by entry.  BITS = 3 (at most 8 buckets): per-thread packed
+// counters reduced over the wave, instead of 64 lanes queueing on a handful of LDS words.
+template <class WT, int BITS>
 __global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__restrict__ srcP,
                                                               const WT *__restrict__ srcW,
                                                               const uint32_t *__restrict__ range_in, int rev,
@@ -77,20 +95,46 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__
     const uint32_t lo = range_in[0], len = range_in[1] - lo;
     if (len <= chain_max) return;
     const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const bool aligned = ((uintptr_t)srcW & 15u) == 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
         h[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t tile0 = tile * (uint32_t)kIndTile;
+        const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
+        const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
+        uint64_t packed = 0; // BITS == 3: one 8-bit counter per bucket (a thread sees at most 12 entries)
+        for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kBlock) {
+            const uint64_t e0 = q * 4u;
+            WT W[4] = {0, 0, 0, 0};
+            if (aligned && e0 >= a && e0 + 4u <= b) {
+                load_quad(srcW + e0, W);
+            } else {
 #pragma unroll
-        for (int k = 0; k < kIndItems; ++k) {
-            const uint32_t i = tile0 + (uint32_t)k * kBlock + threadIdx.x;
-            if (i < len) {
-                const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                const uint32_t p = srcP[idx];
-                if (p != 0) {
-                    const uint32_t ch = wnd_first<WT>(srcW[idx], cfg);
-                    if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                for (int e = 0; e < 4; ++e)
+                    if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
+                    const uint32_t ch = wnd_first<WT>(W[e], cfg);
+                    if (induce_accept(ch, c, mode)) {
+                        if (BITS == 3) packed += 1ull << (8u * ch);
+                        else atomicAdd(&h[ch], 1u);
+                    }
                 }
+            }
+        }
+        if (BITS == 3) {
+            uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                even += __shfl_xor(even, o, kWave);
+                odd += __shfl_xor(odd, o, kWave);
+            }
+            if (lane_id() < 8) {
+                const uint64_t src = (lane_id() & 1) ? odd : even;
+                const uint32_t v = (uint32_t)(src >> (16 * (lane_id() >> 1))) & 0xFFFFu;
+                if (v) atomicAdd(&h[lane_id()], v);
             }
         }
         __syncthreads();
@@ -140,6 +184,8 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
         for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
         __syncthreads();
+        // this tile's first destination per bucket: asked for now, needed after the ranking
+        const uint32_t pre = t < (int)nkeys ? offs[(uint64_t)t * stride + tile] : 0u;
         const uint32_t wave0 = tile * (uint32_t)kIndTile + (uint32_t)w * (kWave * kIndItems);
         uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
         WT wnd[kIndItems];
@@ -154,8 +200,8 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
             if (i < len) {
                 const uint32_t idx = lo + (rev ? len - 1u - i : i);
                 const uint32_t p = srcP[idx];
+                const WT ww = srcW[idx];
                 if (p != 0) {
-                    const WT ww = srcW[idx];
                     const uint32_t ch = wnd_first<WT>(ww, cfg);
                     ok[k] = induce_accept(ch, c, mode);
                     dig[k] = ch;
@@ -176,7 +222,6 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
                 wcount[ww][d] = sum;
                 sum += x;
             }
-            const uint32_t pre = d < nkeys ? offs[(uint64_t)d * stride + tile] : 0u;
             gpos[d] = dir > 0 ? base_d + pre : base_d - 1u - pre;
         }
         __syncthreads();
@@ -534,11 +579,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     sx_ctx *ctx = st.ctx;
     uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
     if (grid > 4096) grid = 4096; // tiles are handed out by ticket: any grid size is correct
-    if (ctx->chain_epoch + 1 >= (1u << 24)) { // 24-bit epochs are about to wrap: retire every old status word
-        (void)hipMemsetAsync(st.status, 0, ctx->slab[SX_SLAB_CHAIN].cap, ctx->stream);
-        ctx->chain_epoch = 0;
-    }
-    ++ctx->chain_epoch;
+    const uint32_t epoch = sx_chain_next_epoch(ctx);
     uint32_t *rin = st.ranges + 2 * range_slot;
     uint32_t *rout = out_slot >= 0 ? st.ranges + 2 * out_slot : nullptr;
     const uint64_t eb = (uint64_t)tiles_bound * kIndTile * (4 + sizeof(WT));
@@ -550,8 +591,12 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     const uint32_t chain_max = both ? st.chain_max : ~0u;
     if (both) {
         // the round may be a large one: queue the three-launch form as well
-        sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT>, dim3(grid), dim3(kBlock), srcP, srcW,
-                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
+        if (st.small_alphabet)
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
+        else
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
         if (st.small_alphabet)
@@ -567,11 +612,11 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
-                  ctx->chain_epoch, st.tickets + range_slot, chain_max);
+                  epoch, st.tickets + range_slot, chain_max);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 8>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
-                  ctx->chain_epoch, st.tickets + range_slot, chain_max);
+                  epoch, st.tickets + range_slot, chain_max);
     st.par ^= 1;
     ctx->stats.induce_rounds++;
 }
@@ -684,15 +729,9 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.stride = sx_div_up(largest, kIndTile) + 1;
     st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
     if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
-    const bool fresh = ctx->slab[SX_SLAB_CHAIN].cap < status_words * 8;
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_CHAIN, status_words * 8));
+    SX_TRY(sx_chain_slab(ctx, SX_SLAB_CHAIN, status_words * 8));
     st.status = (uint64_t *)ctx->slab[SX_SLAB_CHAIN].p;
-    if (fresh) { // new memory holds arbitrary bits: start clean
-        SX_CHECK(hipMemsetAsync(st.status, 0, ctx->slab[SX_SLAB_CHAIN].cap, ctx->stream));
-        ctx->chain_epoch = 0;
-    } else {
-        SX_CHECK(hipMemsetAsync(st.status, 0, sizeof(uint64_t), ctx->stream)); // the time-out word
-    }
+    SX_CHECK(hipMemsetAsync(st.status, 0, sizeof(uint64_t), ctx->stream)); // the time-out word
 
     // windows of the sorted LMS suffixes: the only systematic text access of both passes, unless
     // they already came along with the sort keys (sx_lmssort.hip)
