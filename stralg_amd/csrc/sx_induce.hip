@@ -242,6 +242,151 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
     }
 }
 
+// The scatter for at most 8 buckets (DNA, and every alphabet of up to 7 symbols): the ranking of
+// the general kernel above costs ~100 vector instructions per entry (a match over the wave per
+// item), which is what bounds it, not memory.  Here every thread owns 8 consecutive entries of
+// the scan order and counts its own buckets in 8-bit fields of one register pair; the fields,
+// widened to 16 bits, are prefix-summed over the workgroup two 64-bit words at a time, and an
+// entry's slot in the tile's output is (entries of its bucket in earlier threads) + (its rank
+// inside the thread).  The output is staged in LDS in bucket order so that each bucket's run
+// leaves as one contiguous block.  MODE fixes the scan direction and the accept test at compile time.
+template <class WT, int MODE>
+__global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, uint32_t c,
+    wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs, uint32_t stride,
+    const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ SA, WT *__restrict__ WN, uint32_t nkeys,
+    uint32_t chain_max)
+{
+    constexpr bool kRev = MODE == MODE_S_FROM_S || MODE == MODE_S_FROM_L; // the S pass scans right to left
+    constexpr uint64_t kField16 = 0x00FF00FF00FF00FFull;
+    __shared__ uint64_t wsum[2][kWavesPerBlock];
+    __shared__ uint64_t sbase[2];  // first slot of every bucket in the staged output, 16-bit fields (even, odd buckets)
+    __shared__ uint32_t gadj[8];   // destination of staged slot i of bucket d: gadj[d] + i (L pass), gadj[d] - i (S pass)
+    __shared__ uint32_t sP[kIndTile];
+    __shared__ WT sW[kIndTile];
+    __shared__ uint8_t sD[kIndTile];
+    __shared__ uint16_t refill[kIndTile]; // staged slots whose window ran dry
+    __shared__ uint32_t nrefill;
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= chain_max) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const uint32_t base_d = t < (int)nkeys ? cursor_cur[t] : 0u;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        // this tile's first destination per bucket: asked for now, needed after the scan
+        const uint32_t pre = t < (int)nkeys ? offs[(uint64_t)t * stride + tile] : 0u;
+        if (t == 0) nrefill = 0;
+        const uint32_t i0 = tile * (uint32_t)kIndTile + (uint32_t)t * kIndItems; // the thread's first entry, scan order
+        uint32_t P[kIndItems];
+        WT W[kIndItems];
+        if (i0 + kIndItems <= len) { // the 8 entries are contiguous in memory: two 16-byte loads per array (4-byte aligned)
+            const uint32_t first = kRev ? lo + len - i0 - kIndItems : lo + i0;
+            uint32_t Pm[kIndItems];
+            WT Wm[kIndItems];
+            __builtin_memcpy(Pm, srcP + first, sizeof(Pm));
+            __builtin_memcpy(Wm, srcW + first, sizeof(Wm));
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                P[k] = Pm[kRev ? kIndItems - 1 - k : k];
+                W[k] = Wm[kRev ? kIndItems - 1 - k : k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                const uint32_t i = i0 + (uint32_t)k;
+                const uint32_t idx = i < len ? (kRev ? lo + len - 1u - i : lo + i) : lo;
+                P[k] = i < len ? srcP[idx] : 0u;
+                W[k] = i < len ? srcW[idx] : (WT)0;
+            }
+        }
+        uint32_t rnk[kIndItems], dig[kIndItems];
+        bool ok[kIndItems];
+        uint64_t cnt = 0; // 8-bit count per bucket of this thread's accepted entries
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t ch = wnd_first<WT>(W[k], cfg) & 7u;
+            ok[k] = P[k] != 0 && induce_accept(ch, c, MODE);
+            dig[k] = ch;
+            rnk[k] = (uint32_t)(cnt >> (8u * ch)) & 0xFFu;
+            cnt += (uint64_t)(ok[k] ? 1u : 0u) << (8u * ch);
+        }
+        // exclusive prefix over the threads, both words at once
+        uint64_t inc0 = cnt & kField16, inc1 = (cnt >> 8) & kField16;
+        const uint64_t own0 = inc0, own1 = inc1;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint64_t a = __shfl_up(inc0, (unsigned)d, kWave), b = __shfl_up(inc1, (unsigned)d, kWave);
+            if (lane >= d) inc0 += a, inc1 += b;
+        }
+        if (lane == kWave - 1) wsum[0][w] = inc0, wsum[1][w] = inc1;
+        __syncthreads();
+        uint64_t ex0 = inc0 - own0, ex1 = inc1 - own1, tot0 = 0, tot1 = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) {
+            const uint64_t x0 = wsum[0][i], x1 = wsum[1][i];
+            if (i < w) ex0 += x0, ex1 += x1;
+            tot0 += x0, tot1 += x1;
+        }
+        if (t < 8) { // bucket t: its first staged slot and where that slot lands in SA
+            uint32_t first_slot = 0;
+            for (int d = 0; d < t; ++d) first_slot += (uint32_t)(((d & 1) ? tot1 : tot0) >> (16 * (d >> 1))) & 0xFFFFu;
+            const uint32_t g = kRev ? base_d - 1u - pre : base_d + pre;
+            gadj[t] = kRev ? g + first_slot : g - first_slot;
+        }
+        if (t == 0) { // the same first slots as two words of 16-bit fields (even buckets, odd buckets)
+            uint64_t even = 0, odd = 0;
+            uint32_t run = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                if (d & 1) odd |= (uint64_t)run << (16 * (d >> 1));
+                else even |= (uint64_t)run << (16 * (d >> 1));
+                run += (uint32_t)(((d & 1) ? tot1 : tot0) >> (16 * (d >> 1))) & 0xFFFFu;
+            }
+            sbase[0] = even, sbase[1] = odd;
+        }
+        __syncthreads();
+        ex0 += sbase[0];
+        ex1 += sbase[1];
+        const uint32_t produced = (uint32_t)((tot0 & 0xFFFFu) + ((tot0 >> 16) & 0xFFFFu) + ((tot0 >> 32) & 0xFFFFu) + (tot0 >> 48) +
+                                             (tot1 & 0xFFFFu) + ((tot1 >> 16) & 0xFFFFu) + ((tot1 >> 32) & 0xFFFFu) + (tot1 >> 48));
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            if (ok[k]) {
+                const uint32_t d = dig[k];
+                const uint32_t slot = ((uint32_t)(((d & 1u) ? ex1 : ex0) >> (16u * (d >> 1))) & 0xFFFFu) + rnk[k];
+                const uint32_t j = P[k] - 1u;
+                const WT nw = wnd_pop<WT>(W[k], cfg);
+                sP[slot] = j;
+                sW[slot] = nw;
+                sD[slot] = (uint8_t)d;
+                if (j != 0 && wnd_count<WT>(nw) == 0) refill[atomicAdd(&nrefill, 1u)] = (uint16_t)slot;
+            }
+        }
+        __syncthreads();
+        // windows that ran dry go back to the text: the round's only random access, taken by as many
+        // threads at once as there are such entries
+        const uint32_t nre = nrefill;
+        if (nre) { // uniform
+            for (uint32_t r = (uint32_t)t; r < nre; r += kBlock) {
+                const uint32_t slot = refill[r];
+                sW[slot] = wnd_fill<WT>(T, sP[slot], cfg);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kBlock;
+            if (i < produced) {
+                const uint32_t g = gadj[sD[i]];
+                const uint32_t dst = kRev ? g - i : g + i;
+                SA[dst] = sP[i];
+                WN[dst] = sW[i];
+            }
+        }
+        __syncthreads(); // LDS is reused by the next tile
+    }
+}
+
 // ---- one round = one launch -----------------------------------------------------------
 // Stable multi-way split of the entries in range_in (read from device memory, so rounds
 // can be queued without the host knowing their sizes): entry p with window w induces
@@ -599,11 +744,19 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
-        if (st.small_alphabet)
-            sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
-                      st.SA, st.WN, st.nk, chain_max);
-        else
+        if (st.small_alphabet) {
+#define SX_SCATTER_SMALL(M)                                                                                            \
+    sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_small_kernel<WT, M>, dim3(grid), dim3(kBlock), srcP, srcW, \
+              (const uint32_t *)rin, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, st.SA, st.WN, st.nk,   \
+              chain_max)
+            switch (mode) { // mode fixes the scan direction (rev) and the side the buckets grow to (dir)
+            case MODE_L_FROM_L: SX_SCATTER_SMALL(MODE_L_FROM_L); break;
+            case MODE_L_FROM_LMS: SX_SCATTER_SMALL(MODE_L_FROM_LMS); break;
+            case MODE_S_FROM_S: SX_SCATTER_SMALL(MODE_S_FROM_S); break;
+            default: SX_SCATTER_SMALL(MODE_S_FROM_L); break;
+            }
+#undef SX_SCATTER_SMALL
+        } else
             sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
                       st.SA, st.WN, st.nk, chain_max);
