@@ -305,7 +305,7 @@ __device__ __forceinline__ void load_bytes32(const uint8_t *__restrict__ T, uint
 __device__ __forceinline__ uint32_t block_scan_row_inplace(uint32_t *__restrict__ row, uint64_t count,
                                                            uint32_t *lds)
 {
-    constexpr int kPer = 8;
+    constexpr int kPer = 32; // every thread's loads of one step are in flight together
     uint32_t carry = 0;
     for (uint64_t start = 0; start < count; start += (uint64_t)kBlock * kPer) { // uniform trip count
         const uint64_t i0 = start + (uint64_t)threadIdx.x * kPer;

@@ -96,13 +96,54 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__
     if (len <= chain_max) return;
     const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
     const bool aligned = ((uintptr_t)srcW & 15u) == 0;
+    if (BITS == 3) {
+        // a wave per tile, all of the tile's quads in flight at once, no LDS and no barrier
+        constexpr int kQuads = kIndTile / 4 / kWave + 1; // the tile's range may start inside a quad
+        const int lane = lane_id();
+        for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave_id(); tile < ntiles; tile += gridDim.x * kWavesPerBlock) {
+            const uint32_t tile0 = tile * (uint32_t)kIndTile;
+            const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
+            const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
+            WT W[kQuads][4];
+#pragma unroll
+            for (int k = 0; k < kQuads; ++k) {
+                const uint64_t e0 = ((uint64_t)(a >> 2) + (uint64_t)lane + (uint64_t)k * kWave) * 4u;
+                W[k][0] = W[k][1] = W[k][2] = W[k][3] = 0;
+                if (aligned && e0 >= a && e0 + 4u <= b) {
+                    load_quad(srcW + e0, W[k]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e0 + e >= a && e0 + e < b) W[k][e] = srcW[e0 + e];
+                }
+            }
+            uint64_t packed = 0; // one 8-bit counter per bucket (a lane sees at most 4 * kQuads entries)
+#pragma unroll
+            for (int k = 0; k < kQuads; ++k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t ch = wnd_first<WT>(W[k][e], cfg) & 7u;
+                    const bool ok = wnd_count<WT>(W[k][e]) != 0 && induce_accept(ch, c, mode);
+                    packed += (uint64_t)(ok ? 1u : 0u) << (8u * ch);
+                }
+            }
+            uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                even += __shfl_xor(even, o, kWave);
+                odd += __shfl_xor(odd, o, kWave);
+            }
+            if ((uint32_t)lane < nkeys && lane < 8)
+                hist[(uint64_t)lane * stride + tile] = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
+        }
+        return;
+    }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
         h[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t tile0 = tile * (uint32_t)kIndTile;
         const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
         const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
-        uint64_t packed = 0; // BITS == 3: one 8-bit counter per bucket (a thread sees at most 12 entries)
         for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kBlock) {
             const uint64_t e0 = q * 4u;
             WT W[4] = {0, 0, 0, 0};
@@ -117,24 +158,8 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__
             for (int e = 0; e < 4; ++e) {
                 if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
                     const uint32_t ch = wnd_first<WT>(W[e], cfg);
-                    if (induce_accept(ch, c, mode)) {
-                        if (BITS == 3) packed += 1ull << (8u * ch);
-                        else atomicAdd(&h[ch], 1u);
-                    }
+                    if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
                 }
-            }
-        }
-        if (BITS == 3) {
-            uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                even += __shfl_xor(even, o, kWave);
-                odd += __shfl_xor(odd, o, kWave);
-            }
-            if (lane_id() < 8) {
-                const uint64_t src = (lane_id() & 1) ? odd : even;
-                const uint32_t v = (uint32_t)(src >> (16 * (lane_id() >> 1))) & 0xFFFFu;
-                if (v) atomicAdd(&h[lane_id()], v);
             }
         }
         __syncthreads();

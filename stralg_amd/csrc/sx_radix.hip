@@ -5,9 +5,14 @@
 // stralg/skew.c:53-99: count, prefix sum, stable scatter) and for the
 // reduced-string suffix sort.
 //
-// Per pass, three launches:
-//   radix_hist     tile digit counts -> hist[digit][tile]           (reads keys)
-//   device_scan    exclusive sum over hist in digit-major order
+// Per pass:
+//   radix_hist     tile digit counts -> hist[tile][digit]            (reads keys)
+//   radix_colsum / radix_bases / radix_apply
+//                  hist[tile][digit] <- first output index of (digit, tile): a prefix sum
+//                  down every digit column (tiles in chunks of kRadixChunk), digits stacked in
+//                  order.  The table stays tile-major so that every kernel touches whole
+//                  1 KiB rows; a digit-major table costs a 64-byte sector per 4-byte count
+//                  on both sides, a quarter of the pass's traffic.
 //   radix_scatter  wave-striped load, ballot-based stable ranking, tile
 //                  re-ordered in LDS so that each digit's run leaves the CU
 //                  as contiguous stores.
@@ -43,14 +48,73 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__re
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+constexpr uint32_t kRadixChunk = 256; // tiles per chunk of the column sums
+constexpr int kColBatch = 16;         // independent loads in flight per thread
+
+// column sums of one chunk of tiles: sums[chunk][digit]
+__global__ __launch_bounds__(kBlock) void radix_colsum_kernel(const uint32_t *__restrict__ hist, uint32_t ntiles,
+                                                              uint32_t *__restrict__ sums)
+{
+    const uint32_t t0 = blockIdx.x * kRadixChunk;
+    const uint32_t t1 = t0 + kRadixChunk < ntiles ? t0 + kRadixChunk : ntiles;
+    uint32_t s = 0;
+    for (uint32_t tb = t0; tb < t1; tb += kColBatch) {
+        uint32_t x[kColBatch];
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) s += x[i];
+    }
+    sums[(uint64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// one workgroup: sums[chunk][digit] <- entries of the digit in earlier chunks; digit_base[digit] <- keys with a smaller digit
+__global__ __launch_bounds__(kBlock) void radix_bases_kernel(uint32_t *__restrict__ sums, uint32_t nchunks,
+                                                             uint32_t *__restrict__ digit_base)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    uint32_t run = 0;
+    for (uint32_t cb = 0; cb < nchunks; cb += kColBatch) {
+        uint32_t x[kColBatch];
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) x[i] = cb + i < nchunks ? sums[(uint64_t)(cb + i) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) {
+            if (cb + i < nchunks) sums[(uint64_t)(cb + i) * 256 + threadIdx.x] = run;
+            run += x[i];
+        }
+    }
+    uint32_t tot;
+    digit_base[threadIdx.x] = block_exclusive_scan<OpAdd>(run, lds, tot);
+}
+
+// hist[tile][digit] <- first output index of the tile's keys with that digit
+__global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restrict__ hist, uint32_t ntiles,
+                                                             const uint32_t *__restrict__ sums,
+                                                             const uint32_t *__restrict__ digit_base)
+{
+    const uint32_t t0 = blockIdx.x * kRadixChunk;
+    const uint32_t t1 = t0 + kRadixChunk < ntiles ? t0 + kRadixChunk : ntiles;
+    uint32_t run = sums[(uint64_t)blockIdx.x * 256 + threadIdx.x] + digit_base[threadIdx.x];
+    for (uint32_t tb = t0; tb < t1; tb += kColBatch) {
+        uint32_t x[kColBatch];
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) {
+            if (tb + i < t1) hist[(uint64_t)(tb + i) * 256 + threadIdx.x] = run;
+            run += x[i];
+        }
+    }
 }
 
 // (second launch bound: workgroups per CU to plan registers for; 129 VGPRs would leave only 3)
 __global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
-    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
-    uint32_t ntiles)
+    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256]; // per-wave digit counters, then wave bases
     __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
@@ -59,6 +123,7 @@ __global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kerne
     __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
 
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t first_out = offs[(uint64_t)blockIdx.x * 256 + t]; // asked for now, needed after the ranking
     for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
     __syncthreads();
 
@@ -90,7 +155,7 @@ __global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kerne
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan<OpAdd>(s, scan_lds, tot);
         dbase[d] = ex;
-        goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - ex;
+        goff[d] = first_out - ex;
     }
     __syncthreads();
     // A large tile keeps the runs per digit long (a tile of 4096 keys with uniformly random
@@ -147,9 +212,10 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
     if (n == 0 || end_bit <= begin_bit) return 0;
     if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
     const uint32_t ntiles = sx_div_up(n, kRadixTile);
-    const uint64_t hist_n = (uint64_t)256 * ntiles;
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, hist_n * sizeof(uint32_t)));
+    const uint32_t nchunks = sx_div_up(ntiles, kRadixChunk);
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t)));
     uint32_t *hist = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
+    uint32_t *sums = hist + (size_t)ntiles * 256, *digit_base = sums + (size_t)nchunks * 256;
     uint64_t *kin = ka, *kout = kb;
     uint32_t *vin = va, *vout = vb;
     int flips = 0;
@@ -158,11 +224,14 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
         const uint32_t mask = (1u << bits) - 1u;
         sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kBlock),
                   (const uint64_t *)kin, n, shift, mask, hist, ntiles);
-        SX_TRY((device_scan<OpAdd>(ctx, hist_n, InU32{hist}, OutExclusive{hist}, nullptr, SX_KC_SCAN,
-                                   hist_n * 12)));
+        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 1024, radix_colsum_kernel, dim3(nchunks), dim3(kBlock),
+                  (const uint32_t *)hist, ntiles, sums);
+        sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks * 2048, radix_bases_kernel, dim3(1), dim3(kBlock), sums, nchunks,
+                  digit_base);
+        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 2048, radix_apply_kernel, dim3(nchunks), dim3(kBlock), hist, ntiles,
+                  (const uint32_t *)sums, (const uint32_t *)digit_base);
         sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(ntiles), dim3(kBlock),
-                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask,
-                  (const uint32_t *)hist, ntiles);
+                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
         ++flips;
