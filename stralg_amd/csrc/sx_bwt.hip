@@ -70,6 +70,47 @@ __global__ __launch_bounds__(kBlock) void bwt_count_kernel(const uint8_t *__rest
     if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+// The same for sigma <= 8 (tiles of kBlock * PER rows, PER = 4 or 8): a thread takes its PER symbols in one
+// load and counts them in 8-bit fields of one register pair; 64 lanes adding to five hot LDS words would queue.
+template <int PER>
+__global__ __launch_bounds__(kBlock) void bwt_count_small_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
+                                                                 uint32_t sigma, uint32_t *__restrict__ tilehist,
+                                                                 uint32_t ntiles)
+{
+    __shared__ uint32_t h[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t r0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * PER;
+    uint32_t sym[PER];
+    if (r0 + PER <= N && ((uintptr_t)bwt & 7u) == 0) {
+        uint64_t word;
+        if (PER == 8) word = *reinterpret_cast<const uint64_t *>(bwt + r0);
+        else word = *reinterpret_cast<const uint32_t *>(bwt + r0);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) sym[k] = (uint32_t)(word >> (8 * k)) & 0xFFu;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) sym[k] = r0 + k < N ? (uint32_t)bwt[r0 + k] : 0xFFu;
+    }
+    uint64_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (sym[k] < 8u) packed += 1ull << (8u * sym[k]); // a symbol >= sigma is caught by the totals check
+    uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        even += __shfl_xor(even, o, kWave);
+        odd += __shfl_xor(odd, o, kWave);
+    }
+    const int lane = lane_id();
+    if (lane < 8) {
+        const uint32_t v = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
+        if (v) atomicAdd(&h[lane], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
 // The tile counts [sigma][ntiles] are scanned as one flat array (device_scan); the prefix of
 // (symbol a, tile t) inside its row is flat[a*ntiles + t] - flat[a*ntiles], and the symbol
 // totals -- hence the C table (bwt.c:35-45) -- are differences of the row starts.
@@ -250,7 +291,13 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     uint32_t *totals = ar.take<uint32_t>(256 + 16); // per-symbol totals, then the grand total
     if (!bwt || !tilehist || !totals) return sx_fail_msg(ctx, SX_E_INTERNAL, "bwt: arena too small");
 
-    if (d_bwt_in)
+    if (d_bwt_in && small && tile_rows == 8 * kBlock)
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<8>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
+                  tilehist, ntiles);
+    else if (d_bwt_in && small && tile_rows == 4 * kBlock)
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<4>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
+                  tilehist, ntiles);
+    else if (d_bwt_in)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(ntiles), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
                   tilehist, ntiles);
     else

@@ -697,10 +697,29 @@ template <class WT>
 __global__ __launch_bounds__(kBlock) void bwt_from_windows_kernel(const WT *__restrict__ WN, uint64_t N, wnd_cfg cfg,
                                                                   uint8_t *__restrict__ bwt)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < N) {
-        const WT w = WN[i];
-        bwt[i] = wnd_count<WT>(w) == 0 ? (uint8_t)0 : (uint8_t)wnd_first<WT>(w, cfg);
+    // 16 slots per thread: 16-byte loads of the windows, one 16-byte store of the symbols
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u;
+    if (i0 >= N) return;
+    if (i0 + 16u <= N && (((uintptr_t)WN | (uintptr_t)bwt) & 15u) == 0) {
+        uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            WT w[4];
+            load_quad(WN + i0 + 4 * q, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t b = wnd_count<WT>(w[e]) == 0 ? 0u : wnd_first<WT>(w[e], cfg);
+                out[q] |= (b & 0xFFu) << (8 * e);
+            }
+        }
+        uint4 v;
+        v.x = out[0], v.y = out[1], v.z = out[2], v.w = out[3];
+        *reinterpret_cast<uint4 *>(bwt + i0) = v;
+    } else {
+        for (uint64_t i = i0; i < N && i < i0 + 16u; ++i) {
+            const WT w = WN[i];
+            bwt[i] = wnd_count<WT>(w) == 0 ? (uint8_t)0 : (uint8_t)wnd_first<WT>(w, cfg);
+        }
     }
 }
 
@@ -967,7 +986,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     }
     // the windows now hold text[SA[i]-1] for every slot: the BWT for free (bwt.c:13-20)
     if (bwt_out)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N * (sizeof(WT) + 1), bwt_from_windows_kernel<WT>, dim3(sx_div_up(N, kBlock)),
+        sx_launch(ctx, SX_KC_BWT_GATHER, N * (sizeof(WT) + 1), bwt_from_windows_kernel<WT>, dim3(sx_div_up(N, kBlock * 16)),
                   dim3(kBlock), (const WT *)st.WN, N, cfg, bwt_out);
     return 0;
 }
