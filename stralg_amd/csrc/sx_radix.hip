@@ -25,30 +25,37 @@
 
 namespace sx {
 
+// Tile shape (tools/sortbench.sh, 3e8 pairs, 40 key bits, ms for the whole sort): 256 threads x 16
+// keys 15.4; 512 x 8 15.3; 512 x 12 14.4; 512 x 16 13.5; 512 x 20 18.3; 1024 x 16 14.8.  What counts
+// is the run a digit leaves the tile with: 8192 keys over 256 digits = 256-byte key runs.
 #ifndef SX_RADIX_ITEMS
 #define SX_RADIX_ITEMS 16
 #endif
 constexpr int kRadixItems = SX_RADIX_ITEMS;
 #ifndef SX_RADIX_MINWAVES
-#define SX_RADIX_MINWAVES 4
+#define SX_RADIX_MINWAVES 1
 #endif
-constexpr int kRadixTile = kBlock * kRadixItems;
+#ifndef SX_RADIX_THREADS
+#define SX_RADIX_THREADS 512
+#endif
+constexpr int kRT = SX_RADIX_THREADS, kRW = kRT / kWave;
+constexpr int kRadixTile = kRT * kRadixItems;
 
-__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
+__global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
                                                             int shift, uint32_t mask,
                                                             uint32_t *__restrict__ hist, uint32_t ntiles)
 {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile;
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
-        const uint64_t i = base + (uint64_t)k * kBlock + threadIdx.x;
+        const uint64_t i = base + (uint64_t)k * kRT + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < 256) hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
 constexpr uint32_t kRadixChunk = 256; // tiles per chunk of the column sums
@@ -111,20 +118,20 @@ __global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restric
     }
 }
 
-// (second launch bound: workgroups per CU to plan registers for; 129 VGPRs would leave only 3)
-__global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kernel(
+// (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
+__global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
     uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs)
 {
-    __shared__ uint32_t wcount[kWavesPerBlock][256]; // per-wave digit counters, then wave bases
+    __shared__ uint32_t wcount[kRW][256]; // per-wave digit counters, then wave bases
     __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
     __shared__ uint32_t goff[256];                   // global offset of the digit minus dbase
-    __shared__ uint32_t scan_lds[kWavesPerBlock];
+    __shared__ uint32_t scan_lds[kRW];
     __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
 
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint32_t first_out = offs[(uint64_t)blockIdx.x * 256 + t]; // asked for now, needed after the ranking
-    for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+    const uint32_t first_out = t < 256 ? offs[(uint64_t)blockIdx.x * 256 + t] : 0u; // asked for now, needed after the ranking
+    for (int i = t; i < kRW * 256; i += kRT) (&wcount[0][0])[i] = 0;
     __syncthreads();
 
     const uint64_t tile0 = (uint64_t)blockIdx.x * kRadixTile;
@@ -144,23 +151,30 @@ __global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kerne
     }
     __syncthreads();
     {
-        const int d = t; // kBlock == 256 digits
+        const int d = t & 255; // one thread per digit (threads 256.. of a wider workgroup only take part in the scan)
         uint32_t s = 0;
+        if (t < 256) {
 #pragma unroll
-        for (int ww = 0; ww < kWavesPerBlock; ++ww) {
-            const uint32_t x = wcount[ww][d];
-            wcount[ww][d] = s;
-            s += x;
+            for (int ww = 0; ww < kRW; ++ww) {
+                const uint32_t x = wcount[ww][d];
+                wcount[ww][d] = s;
+                s += x;
+            }
         }
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan<OpAdd>(s, scan_lds, tot);
-        dbase[d] = ex;
-        goff[d] = first_out - ex;
+        const uint32_t inc = wave_inclusive_scan<OpAdd>(s);
+        if (lane == kWave - 1) scan_lds[w] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
+        const uint32_t ex = base + inc - s;
+        if (t < 256) {
+            dbase[d] = ex;
+            goff[d] = first_out - ex;
+        }
     }
     __syncthreads();
-    // A large tile keeps the runs per digit long (a tile of 4096 keys with uniformly random
-    // digits still leaves only 16 keys = 128 bytes per digit), so the LDS image is used
-    // twice, for the keys and then for the values, instead of holding both.
+    // A large tile keeps the runs per digit long, so the LDS image is used twice, for the keys
+    // and then for the values, instead of holding both.
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kerne
     uint32_t dstv[kRadixItems]; // destinations of the slots this thread copies out
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
-        const uint32_t i = (uint32_t)t + (uint32_t)k * kBlock;
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
         dstv[k] = 0;
         if (i < cnt) {
             const uint64_t kk = skey[i];
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(kBlock, SX_RADIX_MINWAVES) void radix_scatter_kerne
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
-        const uint32_t i = (uint32_t)t + (uint32_t)k * kBlock;
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
         if (i < cnt) vout[dstv[k]] = sval[i];
     }
 }
@@ -222,7 +236,7 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
         const uint32_t mask = (1u << bits) - 1u;
-        sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kBlock),
+        sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kRT),
                   (const uint64_t *)kin, n, shift, mask, hist, ntiles);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 1024, radix_colsum_kernel, dim3(nchunks), dim3(kBlock),
                   (const uint32_t *)hist, ntiles, sums);
@@ -230,7 +244,7 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
                   digit_base);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 2048, radix_apply_kernel, dim3(nchunks), dim3(kBlock), hist, ntiles,
                   (const uint32_t *)sums, (const uint32_t *)digit_base);
-        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(ntiles), dim3(kBlock),
+        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(ntiles), dim3(kRT),
                   (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
