@@ -32,20 +32,56 @@ namespace sx {
 // smallest digit, and no bits are wasted when the alphabet is not a power of two
 // (DNA + sentinel: base 5, 17 symbols in 40 bits).  Three aligned 16-byte loads when
 // C <= 32 (statically indexed: no scratch), byte loads otherwise.
-__device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, uint32_t base,
-                                               uint32_t C)
+// A 64-bit multiply per symbol would cost more than everything else in the kernel, so the
+// symbols are taken G at a time with base^G <= 2^24: inside a group the Horner steps are
+// 24-bit multiply-adds, and the 64-bit accumulator is touched once per group (DNA: G = 10,
+// two groups for 17 symbols).  G is one of four compile-time sizes so that the group ends
+// are static; the last group is the short one.
+struct pkey_cfg {
+    uint32_t base, C;
+    uint32_t G;    // 10, 6, 4 or 3: the largest of these with base^G <= 2^24
+    uint32_t powG; // base^G
+    uint32_t powR; // base^(C mod G)
+};
+static inline pkey_cfg pkey_make(uint32_t base, uint32_t C)
+{
+    pkey_cfg k{base, C, base <= 5 ? 10u : (base <= 16 ? 6u : (base <= 64 ? 4u : 3u)), 1, 1};
+    for (uint32_t i = 0; i < k.G; ++i) k.powG *= base;
+    for (uint32_t i = 0; i < C % k.G; ++i) k.powR *= base;
+    return k;
+}
+template <int G>
+__device__ __forceinline__ uint64_t prefix_key_grouped(const uint64_t (&q)[4], const pkey_cfg &kc)
 {
     uint64_t acc = 0;
-    if (C <= 32) {
+    uint32_t g = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < 32; ++s) {
+        if (s < kc.C) { // uniform
+            g = __umul24(g, kc.base) + (uint32_t)((q[s >> 3] >> (8u * (s & 7u))) & 0xFFull);
+            if ((s + 1) % G == 0) { // static
+                acc = acc * kc.powG + g;
+                g = 0;
+            }
+        }
+    }
+    if (kc.C % G) acc = acc * kc.powR + g; // uniform
+    return acc;
+}
+__device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, const pkey_cfg &kc)
+{
+    if (kc.C <= 32) {
         uint64_t q[4];
         load_bytes32(T, p, q);
-#pragma unroll
-        for (uint32_t s = 0; s < 32; ++s) {
-            if (s < C) acc = acc * base + ((q[s >> 3] >> (8u * (s & 7u))) & 0xFFull);
+        switch (kc.G) { // uniform
+        case 10: return prefix_key_grouped<10>(q, kc);
+        case 6: return prefix_key_grouped<6>(q, kc);
+        case 4: return prefix_key_grouped<4>(q, kc);
+        default: return prefix_key_grouped<3>(q, kc);
         }
-    } else {
-        for (uint32_t s = 0; s < C; ++s) acc = acc * base + (uint64_t)T[p + s];
     }
+    uint64_t acc = 0;
+    for (uint32_t s = 0; s < kc.C; ++s) acc = acc * kc.base + (uint64_t)T[p + s];
     return acc;
 }
 
@@ -55,8 +91,8 @@ __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, ui
 // the LMS positions (role of sa_is.c:203-218 place_LMS's scan) and the key generation in one pass.
 __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__restrict__ T,
                                                                const uint16_t *__restrict__ lmsbits,
-                                                               const uint32_t *__restrict__ tile_off, uint32_t base,
-                                                               uint32_t C, uint32_t kbits, wnd_cfg wcfg,
+                                                               const uint32_t *__restrict__ tile_off, pkey_cfg kc,
+                                                               uint32_t kbits, wnd_cfg wcfg,
                                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
@@ -75,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
     const uint32_t dst0 = tile_off[blockIdx.x];
     for (uint32_t i = (uint32_t)t; i < total; i += kBlock) {
         const uint32_t p = spos[i];
-        uint64_t key = prefix_key(T, p, base, C);
+        uint64_t key = prefix_key(T, p, kc);
         // The key bits above kbits are not sorted on, they just ride along: put the suffix's
         // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
         // this part of the text is in cache, instead of gathering it again after the sort.
@@ -125,7 +161,7 @@ struct OutActKey {
     const uint8_t *T;
     const uint32_t *ap;
     uint64_t n, skip;
-    uint32_t base, C;
+    pkey_cfg kc;
     uint32_t *agid;
     uint64_t *key_keep, *key_sort;
     uint32_t *order;
@@ -134,7 +170,7 @@ struct OutActKey {
         agid[t] = (excl > v ? excl : v) - 1u;
         const uint64_t q = (uint64_t)ap[t] + skip;
         // q > n cannot happen inside a tie (a key holding the sentinel is unique); stay in bounds anyway
-        const uint64_t k = q <= n ? prefix_key(T, q, base, C) : 0ull;
+        const uint64_t k = q <= n ? prefix_key(T, q, kc) : 0ull;
         key_keep[t] = k;
         key_sort[t] = k;
         order[t] = (uint32_t)t;
@@ -281,7 +317,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         wcfg.CW = embed ? wchars : 0;
         kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
         sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
-                  (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, base, C, (uint32_t)kbits, wcfg, ka, va);
+                  (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va);
         int in_b = 0;
         SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b));
         ks = in_b ? kb : ka;
@@ -314,7 +350,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         const uint32_t gbits = (uint32_t)(sx_bitlen(A) > 0 ? sx_bitlen(A) : 1);
         // group ids and the next C symbols of every tied suffix
         SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head},
-                                   OutActKey{ti.T, ap, ti.n, (uint64_t)C + (uint64_t)Cmax * (round - 1), base, Cmax, agid, key_keep, rk_a, ord_a},
+                                   OutActKey{ti.T, ap, ti.n, (uint64_t)C + (uint64_t)Cmax * (round - 1), pkey_make(base, Cmax), agid, key_keep, rk_a, ord_a},
                                    nullptr, SX_KC_DOUBLING, (uint64_t)A * 32)));
         // order by (group, next key), LSD: stable sort by next key, then stable sort by group
         int f = 0;

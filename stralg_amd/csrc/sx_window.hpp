@@ -36,11 +36,21 @@ __device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p
     uint64_t lo, hi;
     load_bytes16(T, (uint64_t)(p - cnt), lo, hi);
     WT acc = 0;
+    if (cnt == c.CW) { // everywhere but at the very start of the text: the loop bound is uniform
 #pragma unroll
-    for (uint32_t i = 0; i < 15; ++i) {
-        if (i < cnt) {
-            const uint64_t byte = ((i < 8 ? lo : hi) >> (8u * (i & 7u))) & 0xFFull;
-            acc = (acc << c.B) | (WT)(byte - 1u); // ends with text[p-1] in the lowest field
+        for (uint32_t i = 0; i < 15; ++i) {
+            if (i < c.CW) {
+                const uint64_t byte = ((i < 8 ? lo : hi) >> (8u * (i & 7u))) & 0xFFull;
+                acc = (acc << c.B) | (WT)(byte - 1u); // ends with text[p-1] in the lowest field
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 15; ++i) {
+            if (i < cnt) {
+                const uint64_t byte = ((i < 8 ? lo : hi) >> (8u * (i & 7u))) & 0xFFull;
+                acc = (acc << c.B) | (WT)(byte - 1u);
+            }
         }
     }
     return (acc << kCntBits) | (WT)cnt;
