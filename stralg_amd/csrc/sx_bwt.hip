@@ -21,7 +21,7 @@ namespace sx {
 constexpr int kSmallSigma = 8;      // register-vector O kernel for sigma <= 8
 // rows per thread: 8 for sigma <= 5 (DNA + sentinel: 2048-row tiles, 40 KiB of LDS), 4 up to sigma 8
 template <int SIG> struct small_cfg {
-    static constexpr int rows = SIG <= 5 ? 8 : 4;
+    static constexpr int rows = 4;
     static constexpr int tile = kBlock * rows;
 };
 constexpr int kWideTile = 64;       // rows per workgroup of the wide-alphabet O kernel
@@ -70,22 +70,24 @@ __global__ __launch_bounds__(kBlock) void bwt_count_kernel(const uint8_t *__rest
     if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// The same for sigma <= 8 (tiles of kBlock * PER rows, PER = 4 or 8): a thread takes its PER symbols in one
-// load and counts them in 8-bit fields of one register pair; 64 lanes adding to five hot LDS words would queue.
-template <int PER>
+// The same for sigma <= 8: a workgroup covers kBlock * 8 rows = SPLIT tiles (whole waves per tile); a thread
+// takes its 8 symbols in one load and counts them in 8-bit fields of one register pair; 64 lanes adding to
+// five hot LDS words would queue.
+template <int SPLIT>
 __global__ __launch_bounds__(kBlock) void bwt_count_small_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
                                                                  uint32_t sigma, uint32_t *__restrict__ tilehist,
                                                                  uint32_t ntiles)
 {
-    __shared__ uint32_t h[8];
-    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    constexpr int PER = 8;
+    static_assert(kWavesPerBlock % SPLIT == 0, "whole waves per tile");
+    __shared__ uint32_t h[SPLIT][8];
+    if (threadIdx.x < SPLIT * 8) (&h[0][0])[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t r0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * PER;
+    const int part = (int)threadIdx.x / (kBlock / SPLIT); // which of the workgroup's tiles
     uint32_t sym[PER];
     if (r0 + PER <= N && ((uintptr_t)bwt & 7u) == 0) {
-        uint64_t word;
-        if (PER == 8) word = *reinterpret_cast<const uint64_t *>(bwt + r0);
-        else word = *reinterpret_cast<const uint32_t *>(bwt + r0);
+        const uint64_t word = *reinterpret_cast<const uint64_t *>(bwt + r0);
 #pragma unroll
         for (int k = 0; k < PER; ++k) sym[k] = (uint32_t)(word >> (8 * k)) & 0xFFu;
     } else {
@@ -105,10 +107,12 @@ __global__ __launch_bounds__(kBlock) void bwt_count_small_kernel(const uint8_t *
     const int lane = lane_id();
     if (lane < 8) {
         const uint32_t v = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
-        if (v) atomicAdd(&h[lane], v);
+        if (v) atomicAdd(&h[part][lane], v);
     }
     __syncthreads();
-    if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    const uint32_t a = threadIdx.x & 7u, which = threadIdx.x >> 3;
+    const uint64_t tile = (uint64_t)blockIdx.x * SPLIT + which;
+    if (which < (uint32_t)SPLIT && a < sigma && tile < ntiles) tilehist[(uint64_t)a * ntiles + tile] = h[which][a];
 }
 
 // The tile counts [sigma][ntiles] are scanned as one flat array (device_scan); the prefix of
@@ -137,7 +141,8 @@ __device__ __forceinline__ void store_rows(const uint32_t *__restrict__ rows, ui
     const uint32_t nvec = nwords >> 2;
     const uint4 *src4 = reinterpret_cast<const uint4 *>(rows);
     uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
-    for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) dst4[i] = src4[i];
+    // written once, never read by this kernel: streaming stores keep the rows out of L2's way
+    for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) stream_store16(dst4 + i, src4[i]);
     for (uint32_t i = (nvec << 2) + threadIdx.x; i < nwords; i += kBlock) dst[i] = rows[i];
 }
 
@@ -292,11 +297,11 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     if (!bwt || !tilehist || !totals) return sx_fail_msg(ctx, SX_E_INTERNAL, "bwt: arena too small");
 
     if (d_bwt_in && small && tile_rows == 8 * kBlock)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<8>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<1>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
                   tilehist, ntiles);
     else if (d_bwt_in && small && tile_rows == 4 * kBlock)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<4>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
-                  tilehist, ntiles);
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<2>, dim3(sx_div_up(ntiles, 2)), dim3(kBlock), d_bwt_in, N,
+                  sigma, tilehist, ntiles);
     else if (d_bwt_in)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(ntiles), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
                   tilehist, ntiles);

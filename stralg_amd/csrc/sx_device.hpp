@@ -258,6 +258,14 @@ __device__ __forceinline__ uint32_t chain_exclusive_prefix_wave(uint64_t *__rest
     return prefix;
 }
 
+// 16-byte store of data this kernel will not read again (streaming: no L2 allocation)
+typedef unsigned int sx_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store16(uint4 *dst, uint4 v)
+{
+    const sx_v4u x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<sx_v4u *>(dst));
+}
+
 // ---- unaligned byte windows of the text from aligned 16-byte loads ------------------
 // (the text buffer is 256-byte aligned and padded, so the chunk after the last
 // byte wanted is always readable)

@@ -117,6 +117,9 @@ static inline int __all(int pred) { unsigned long long live; const unsigned long
 template <class T> static inline unsigned long long emu_bits(T v) { unsigned long long b = 0; static_assert(sizeof(T) <= 8, ""); memcpy(&b, &v, sizeof(T)); return b; }
 template <class T> static inline T emu_unbits(unsigned long long b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define ext_vector_type(n) vector_size((n) * 4) /* g++ spelling of clang's 4-byte-element vectors */
+#define __builtin_nontemporal_load(p) (*(p))
 static inline unsigned int __umul24(unsigned int a, unsigned int b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 template <class T> static inline T __shfl(T var, int src, int width = 64)
 {
