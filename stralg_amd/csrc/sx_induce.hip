@@ -771,7 +771,6 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     const uint32_t epoch = sx_chain_next_epoch(ctx);
     uint32_t *rin = st.ranges + 2 * range_slot;
     uint32_t *rout = out_slot >= 0 ? st.ranges + 2 * out_slot : nullptr;
-    const uint64_t eb = (uint64_t)tiles_bound * kIndTile * (4 + sizeof(WT));
     const uint32_t *cur = st.cursor[st.par];
     uint32_t *nxt = st.cursor[st.par ^ 1];
     // tiles_likely: what the round is expected to need (decides which forms are queued);
@@ -781,16 +780,16 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     if (both) {
         // the round may be a large one: queue the three-launch form as well
         if (st.small_alphabet)
-            sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
         else
-            sx_launch(ctx, SX_KC_INDUCE_GATHER, eb, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
         if (st.small_alphabet) {
 #define SX_SCATTER_SMALL(M)                                                                                            \
-    sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_small_kernel<WT, M>, dim3(grid), dim3(kBlock), srcP, srcW, \
+    sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_small_kernel<WT, M>, dim3(grid), dim3(kBlock), srcP, srcW, \
               (const uint32_t *)rin, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, st.SA, st.WN, st.nk,   \
               chain_max)
             switch (mode) { // mode fixes the scan direction (rev) and the side the buckets grow to (dir)
@@ -801,7 +800,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
             }
 #undef SX_SCATTER_SMALL
         } else
-            sx_launch(ctx, SX_KC_INDUCE_SCATTER, eb * 2, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
+            sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
                       st.SA, st.WN, st.nk, chain_max);
     }
@@ -983,6 +982,18 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         uint32_t timed_out[2] = {0, 0};
         SX_TRY(sx_readback(ctx, (const uint32_t *)st.status, 2, timed_out));
         if (timed_out[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a look-back wait timed out");
+    }
+    if (ctx->prof_on) {
+        // Algorithmic bytes of the two passes (the launches themselves were queued with bounds, not
+        // sizes): the L pass scans every L-type entry and every LMS seed, the S pass every entry but
+        // the sentinel's; every suffix is written once.  The counting launches read the windows, the
+        // scatter launches the (position, window) pairs; the few entries that went through the chained
+        // rounds are booked here too.
+        uint64_t n_l = 0;
+        for (uint32_t c = 0; c < nk; ++c) n_l += ti.h_l[c];
+        const uint64_t scanned = n_l + ti.m + (N - 1);
+        ctx->kstat[SX_KC_INDUCE_GATHER].alg_bytes += scanned * sizeof(WT);
+        ctx->kstat[SX_KC_INDUCE_SCATTER].alg_bytes += (scanned + N) * (4 + sizeof(WT));
     }
     // the windows now hold text[SA[i]-1] for every slot: the BWT for free (bwt.c:13-20)
     if (bwt_out)
