@@ -36,21 +36,23 @@ __global__ __launch_bounds__(kBlock) void bwt_gather_kernel(const uint8_t *__res
                                                             uint32_t *__restrict__ tilehist, uint32_t ntiles)
 {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t tile0 = (uint64_t)blockIdx.x * tile_rows;
-    for (uint32_t r = threadIdx.x; r < tile_rows; r += kBlock) {
-        const uint64_t i = tile0 + r;
-        if (i < N) {
-            const uint32_t p = SA[i];
-            // an entry outside [0, n] (a malformed sa) must not fault: count it as symbol 255
-            const uint32_t b = p == 0 ? 0u : ((uint64_t)p < N ? (uint32_t)T[p - 1u] : 255u);
-            bwt[i] = (uint8_t)b;
-            atomicAdd(&h[b], 1u);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // (a grid of ntiles workgroups can exceed the launch limit)
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t tile0 = (uint64_t)tile * tile_rows;
+        for (uint32_t r = threadIdx.x; r < tile_rows; r += kBlock) {
+            const uint64_t i = tile0 + r;
+            if (i < N) {
+                const uint32_t p = SA[i];
+                // an entry outside [0, n] (a malformed sa) must not fault: count it as symbol 255
+                const uint32_t b = p == 0 ? 0u : ((uint64_t)p < N ? (uint32_t)T[p - 1u] : 255u);
+                bwt[i] = (uint8_t)b;
+                atomicAdd(&h[b], 1u);
+            }
         }
+        __syncthreads();
+        if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
     }
-    __syncthreads();
-    if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
 // per-tile symbol counts of a BWT that is already in memory (fused SA+BWT build)
@@ -59,15 +61,17 @@ __global__ __launch_bounds__(kBlock) void bwt_count_kernel(const uint8_t *__rest
                                                            uint32_t *__restrict__ tilehist, uint32_t ntiles)
 {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t tile0 = (uint64_t)blockIdx.x * tile_rows;
-    for (uint32_t r = threadIdx.x; r < tile_rows; r += kBlock) {
-        const uint64_t i = tile0 + r;
-        if (i < N) atomicAdd(&h[bwt[i]], 1u);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t tile0 = (uint64_t)tile * tile_rows;
+        for (uint32_t r = threadIdx.x; r < tile_rows; r += kBlock) {
+            const uint64_t i = tile0 + r;
+            if (i < N) atomicAdd(&h[bwt[i]], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
     }
-    __syncthreads();
-    if (threadIdx.x < sigma) tilehist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
 // The same for sigma <= 8: a workgroup covers kBlock * 8 rows = SPLIT tiles (whole waves per tile); a thread
@@ -248,26 +252,29 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
 {
     __shared__ __attribute__((aligned(16))) uint32_t rows[kWideTile * kMaxSigmaO];
     const int t = (int)threadIdx.x;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kWideTile;
-    for (uint32_t i = (uint32_t)t; i < (uint32_t)kWideTile * sigma; i += kBlock) rows[i] = 0;
-    __syncthreads();
-    if (t + 1 < kWideTile) {
-        const uint64_t i = tile0 + t;
-        if (i < N) rows[(uint32_t)(t + 1) * sigma + bwt[i]] = 1; // one writer per row
-    }
-    __syncthreads();
-    if ((uint32_t)t < sigma) {
-        uint32_t run = tilepre[(uint64_t)t * ntiles + blockIdx.x] - tilepre[(uint64_t)t * ntiles];
-        for (int r = 0; r < kWideTile; ++r) {
-            run += rows[(uint32_t)r * sigma + t];
-            rows[(uint32_t)r * sigma + t] = run;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t tile0 = (uint64_t)tile * kWideTile;
+        for (uint32_t i = (uint32_t)t; i < (uint32_t)kWideTile * sigma; i += kBlock) rows[i] = 0;
+        __syncthreads();
+        if (t + 1 < kWideTile) {
+            const uint64_t i = tile0 + t;
+            if (i < N) rows[(uint32_t)(t + 1) * sigma + bwt[i]] = 1; // one writer per row
         }
+        __syncthreads();
+        if ((uint32_t)t < sigma) {
+            uint32_t run = tilepre[(uint64_t)t * ntiles + tile] - tilepre[(uint64_t)t * ntiles];
+            for (int r = 0; r < kWideTile; ++r) {
+                run += rows[(uint32_t)r * sigma + t];
+                rows[(uint32_t)r * sigma + t] = run;
+            }
+        }
+        __syncthreads();
+        const uint64_t rows_left = N + 1 - tile0;
+        const uint32_t nrows = rows_left < (uint64_t)kWideTile ? (uint32_t)rows_left : (uint32_t)kWideTile;
+        const uint32_t nwords = nrows * sigma;
+        store_rows(rows, o_out + tile0 * sigma, nwords);
+        __syncthreads(); // rows[] is reused by the next tile
     }
-    __syncthreads();
-    const uint64_t rows_left = N + 1 - tile0;
-    const uint32_t nrows = rows_left < (uint64_t)kWideTile ? (uint32_t)rows_left : (uint32_t)kWideTile;
-    const uint32_t nwords = nrows * sigma;
-    store_rows(rows, o_out + tile0 * sigma, nwords);
 }
 
 } // namespace sx
@@ -285,6 +292,7 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     const bool small = sigma <= kSmallSigma;
     const uint32_t tile_rows = small ? (sigma <= 5 ? small_cfg<5>::tile : small_cfg<8>::tile) : kWideTile;
     const uint32_t ntiles = sx_div_up(N + 1, tile_rows);
+    const uint32_t loop_grid = ntiles < (1u << 22) ? ntiles : (1u << 22); // kernels that loop over their tiles
     const size_t need = (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 1024 + 4096;
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, need));
     sx_arena ar;
@@ -303,10 +311,10 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<2>, dim3(sx_div_up(ntiles, 2)), dim3(kBlock), d_bwt_in, N,
                   sigma, tilehist, ntiles);
     else if (d_bwt_in)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(ntiles), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(loop_grid), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
                   tilehist, ntiles);
     else
-        sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_gather_kernel, dim3(ntiles), dim3(kBlock), d_text, d_sa, N,
+        sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_gather_kernel, dim3(loop_grid), dim3(kBlock), d_text, d_sa, N,
                   tile_rows, sigma, bwt_own, tilehist, ntiles);
     const uint64_t flat_n = (uint64_t)sigma * ntiles;
     SX_TRY((device_scan<OpAdd>(ctx, flat_n, InU32{tilehist}, OutExclusive{tilehist}, totals + 256, SX_KC_SCAN,
@@ -328,7 +336,7 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
             sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<8>, dim3(ntiles), dim3(kBlock), bwt, N, sigma,
                       (const uint32_t *)tilehist, ntiles, d_o);
         else
-            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_wide_kernel, dim3(ntiles), dim3(kBlock), bwt, N, sigma,
+            sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_wide_kernel, dim3(loop_grid), dim3(kBlock), bwt, N, sigma,
                       (const uint32_t *)tilehist, ntiles, d_o);
     }
     return 0;

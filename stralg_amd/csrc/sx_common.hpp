@@ -73,6 +73,9 @@ struct sx_ctx {
     int64_t chain_max_override = -1; // SX_FLAG_CHAIN_MAX_ENTRIES; -1 = choose by alphabet size
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int prof_on = 0;
+    // first launch that the runtime refused (a bad grid, ...): reported by the next sx_sync / sx_readback
+    hipError_t launch_err = hipSuccess;
+    int launch_err_class = 0;
     std::vector<sx_event_pair> ev_used;
     std::vector<sx_event_pair> ev_free;
     sx_kernel_stat kstat[SX_KC_COUNT];
@@ -101,6 +104,8 @@ static inline void sx_launch(sx_ctx *ctx, int kclass, uint64_t alg_bytes, void (
 {
     if (ctx->prof_on) sx_prof_begin(ctx, kclass);
     hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && ctx->launch_err == hipSuccess) ctx->launch_err = e, ctx->launch_err_class = kclass;
     if (ctx->prof_on) sx_prof_end(ctx, kclass, alg_bytes);
 }
 

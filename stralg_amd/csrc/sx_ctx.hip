@@ -69,9 +69,19 @@ uint32_t sx_chain_next_epoch(sx_ctx *ctx)
     return ++ctx->chain_epoch;
 }
 
+static int launch_error(sx_ctx *ctx)
+{
+    const hipError_t e = ctx->launch_err;
+    ctx->launch_err = hipSuccess;
+    snprintf(ctx->err, sizeof ctx->err, "a %s kernel launch failed: %s", sx_kernel_class_name(ctx->launch_err_class),
+             hipGetErrorString(e));
+    return (int)e;
+}
+
 int sx_sync(sx_ctx *ctx)
 {
     SX_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->launch_err != hipSuccess) return launch_error(ctx);
     return 0;
 }
 
@@ -80,6 +90,7 @@ int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_ds
     if (count * sizeof(uint32_t) > 4096) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
     SX_CHECK(hipMemcpyAsync(ctx->h_pin, d_src, count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SX_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->launch_err != hipSuccess) return launch_error(ctx);
     memcpy(h_dst, ctx->h_pin, count * sizeof(uint32_t));
     return 0;
 }

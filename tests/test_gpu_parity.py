@@ -467,3 +467,30 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
         idx = (sa.long() - 1).clamp(min=0)
         want_b = torch.where(sa == 0, torch.zeros_like(bw), text[idx.clamp(max=n - 1)])
         assert bool((bw == want_b).all())
+
+
+def test_wide_tables_beyond_launch_limit(gpu_ctx):
+    """sigma > 8 tables at N = 2^30 + 1: one workgroup per 64-row tile would be 2^24 + 1 workgroups of 256
+    threads, more threads than a launch can hold (the kernels loop over tiles instead).  The O rows are checked
+    through the one-hot property, the C table against a bincount."""
+    import torch
+    sigma, N = 9, (1 << 30) + 1
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    bw = torch.randint(1, sigma, (N,), dtype=torch.uint8, device="cuda", generator=g)
+    bw[12345] = 0
+    c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
+    o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
+    gpu_ctx.bwt_tables_from_bwt_dev(bw, N, sigma, c, o)
+    counts = torch.bincount(bw[: 1 << 28].long(), minlength=sigma)
+    for s in range(1 << 28, N, 1 << 28):
+        counts += torch.bincount(bw[s: min(N, s + (1 << 28))].long(), minlength=sigma)
+    assert bool((c.long() == torch.cumsum(counts, 0) - counts).all())
+    o = o.view(N + 1, sigma)
+    assert bool((o[0] == 0).all()) and bool((o[N].long() == counts).all())
+    step = 1 << 24
+    for s in range(0, N, step):
+        e = min(N, s + step)
+        d = o[s + 1: e + 1] - o[s: e]
+        onehot = torch.nn.functional.one_hot(bw[s:e].long(), sigma).to(torch.int32)
+        assert bool((d == onehot).all())
