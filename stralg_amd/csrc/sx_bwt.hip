@@ -24,7 +24,6 @@ template <int SIG> struct small_cfg {
     static constexpr int rows = 4;
     static constexpr int tile = kBlock * rows;
 };
-constexpr int kWideTile = 64;       // rows per workgroup of the wide-alphabet O kernel
 constexpr int kMaxSigmaO = 128;     // stralg/remap.h:14-18
 
 // bwt symbols + per-tile symbol counts.  tile_rows rows per workgroup; row N
@@ -243,37 +242,61 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     store_rows(rows, o_out + tile0 * sigma, nwords);
 }
 
-// O rows for 8 < sigma <= 128: 64 rows per workgroup; symbols mark a +1 in the
-// row after them, one thread per symbol column then accumulates down the rows.
+// O rows for 8 < sigma <= 128.  A tile is RG groups of 64 rows (RG = 4, 2, 1 for sigma <= 32, 64, 128: about
+// 32 KiB of rows in LDS); wave w takes row group w % RG and the columns a with a % (4 / RG) == w / RG.  With one
+// row per lane, the running count of column a at the lane's row is a ballot away:
+//   O[r][a] = (count before the tile) + (count in the row groups above) + popcount(ballot(sym == a) & lanes below)
+// The LDS row stride is made odd so that 64 lanes writing one column do not share a bank.
+__device__ __forceinline__ uint32_t wide_row_groups(uint32_t sigma) { return sigma <= 32 ? 4u : (sigma <= 64 ? 2u : 1u); }
+
 __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
                                                              uint32_t sigma,
                                                              const uint32_t *__restrict__ tilepre,
                                                              uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t rows[kWideTile * kMaxSigmaO];
-    const int t = (int)threadIdx.x;
+    constexpr uint32_t kRowWords = 64 * (kMaxSigmaO + 1); // every (RG, sigma) pair fits: 4*64*33, 2*64*65, 64*129
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kRowWords];
+    __shared__ uint32_t gtot[4][kMaxSigmaO]; // symbol counts of every row group
+    __shared__ uint32_t pre[kMaxSigmaO];     // symbol counts before the tile
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t RG = wide_row_groups(sigma), CP = kWavesPerBlock / RG;
+    const uint32_t rg = (uint32_t)w % RG, cp = (uint32_t)w / RG;
+    const uint32_t tile_rows = RG * kWave;
+    const uint32_t stride = sigma | 1u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t tile0 = (uint64_t)tile * kWideTile;
-        for (uint32_t i = (uint32_t)t; i < (uint32_t)kWideTile * sigma; i += kBlock) rows[i] = 0;
-        __syncthreads();
-        if (t + 1 < kWideTile) {
-            const uint64_t i = tile0 + t;
-            if (i < N) rows[(uint32_t)(t + 1) * sigma + bwt[i]] = 1; // one writer per row
+        const uint64_t tile0 = (uint64_t)tile * tile_rows;
+        // row r of the table counts the symbols before position r: the lane's own symbol is not in its row
+        const uint64_t i = tile0 + (uint64_t)rg * kWave + lane;
+        const uint32_t sym = i < N ? (uint32_t)bwt[i] : 0xFFFFu;
+        if ((uint32_t)t < sigma) pre[t] = tilepre[(uint64_t)t * ntiles + tile] - tilepre[(uint64_t)t * ntiles];
+        for (uint32_t a = cp; a < sigma; a += CP) { // uniform per wave
+            const uint64_t m = __ballot(sym == a ? 1 : 0);
+            if (lane == 0) gtot[rg][a] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if ((uint32_t)t < sigma) {
-            uint32_t run = tilepre[(uint64_t)t * ntiles + tile] - tilepre[(uint64_t)t * ntiles];
-            for (int r = 0; r < kWideTile; ++r) {
-                run += rows[(uint32_t)r * sigma + t];
-                rows[(uint32_t)r * sigma + t] = run;
-            }
+        for (uint32_t a = cp; a < sigma; a += CP) {
+            uint32_t base = pre[a];
+            for (uint32_t g = 0; g < rg; ++g) base += gtot[g][a];
+            const uint64_t m = __ballot(sym == a ? 1 : 0);
+            rows[(rg * kWave + (uint32_t)lane) * stride + a] = base + (uint32_t)__popcll(m & lanemask_lt());
         }
         __syncthreads();
         const uint64_t rows_left = N + 1 - tile0;
-        const uint32_t nrows = rows_left < (uint64_t)kWideTile ? (uint32_t)rows_left : (uint32_t)kWideTile;
-        const uint32_t nwords = nrows * sigma;
-        store_rows(rows, o_out + tile0 * sigma, nwords);
-        __syncthreads(); // rows[] is reused by the next tile
+        const uint32_t nrows = rows_left < (uint64_t)tile_rows ? (uint32_t)rows_left : tile_rows;
+        uint32_t *dst = o_out + tile0 * sigma;
+        if (stride == sigma) {
+            store_rows(rows, dst, nrows * sigma);
+        } else { // skip the pad word of every row
+            const uint32_t nwords = nrows * sigma;
+            uint32_t r = (uint32_t)t / sigma, a = (uint32_t)t % sigma;
+            const uint32_t dr = kBlock / sigma, da = kBlock % sigma;
+            for (uint32_t idx = (uint32_t)t; idx < nwords; idx += kBlock) {
+                dst[idx] = rows[r * stride + a];
+                r += dr, a += da;
+                if (a >= sigma) a -= sigma, ++r;
+            }
+        }
+        __syncthreads(); // rows[] and gtot[] are reused by the next tile
     }
 }
 
@@ -290,7 +313,8 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     if (d_o && sigma > kMaxSigmaO)
         return sx_fail_msg(ctx, SX_E_ARG, "the O table is defined for sigma <= 128 (stralg/remap.h:14-18)");
     const bool small = sigma <= kSmallSigma;
-    const uint32_t tile_rows = small ? (sigma <= 5 ? small_cfg<5>::tile : small_cfg<8>::tile) : kWideTile;
+    const uint32_t tile_rows =
+        small ? (sigma <= 5 ? small_cfg<5>::tile : small_cfg<8>::tile) : (sigma <= 32 ? 256u : (sigma <= 64 ? 128u : 64u));
     const uint32_t ntiles = sx_div_up(N + 1, tile_rows);
     const uint32_t loop_grid = ntiles < (1u << 22) ? ntiles : (1u << 22); // kernels that loop over their tiles
     const size_t need = (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 1024 + 4096;

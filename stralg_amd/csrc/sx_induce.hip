@@ -799,7 +799,11 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
             default: SX_SCATTER_SMALL(MODE_S_FROM_L); break;
             }
 #undef SX_SCATTER_SMALL
-        } else
+        } else if (st.nk <= 32) // five ballots per match instead of eight
+            sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 5>, dim3(grid), dim3(kBlock), srcP, srcW,
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
+                      st.SA, st.WN, st.nk, chain_max);
+        else
             sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
                       st.SA, st.WN, st.nk, chain_max);
@@ -807,6 +811,10 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     uint32_t cgrid = grid > 1024 ? 1024 : grid;
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
+                  epoch, st.tickets + range_slot, chain_max);
+    else if (st.nk <= 32)
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 5>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
                   epoch, st.tickets + range_slot, chain_max);
     else
