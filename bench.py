@@ -43,8 +43,9 @@ def cpu_baseline(log2_sample, sigma, seed):
     oracle.c_table(xs, sigma)
     oracle.o_table(xs, sas, sigma)
     t3 = time.perf_counter()
-    return {
-        "value": round((n + 1) / (t1 - t0) / 1e6, 3),
+    port = (n + 1) / (t1 - t0) / 1e6
+    out = {
+        "value": round(port, 3),
         "unit": "Msuffixes/s",
         "cores": 1,
         "kind": "port",
@@ -54,6 +55,21 @@ def cpu_baseline(log2_sample, sigma, seed):
         "host_cpus": os.cpu_count(),
         "levels": levels[:6],
     }
+    from oracle import pyoracle
+    if pyoracle.have_ref():
+        # the unmodified reference (oracle/_ref, built from the reference's sources by oracle/Makefile): its own
+        # sa_is_construction on the same sample is the baseline proper; the port's rate stays in the text
+        ref = pyoracle._Ref()
+        t4 = time.perf_counter()
+        sa_ref = ref.sa_is(x, sigma)
+        t5 = time.perf_counter()
+        if not (sa_ref == sa).all():
+            raise RuntimeError("reference and oracle disagree on the baseline sample")
+        out["value"] = round((n + 1) / (t5 - t4) / 1e6, 3)
+        out["kind"] = "reference"
+        out["sample"] = (f"the reference's sa_is_construction on the first 2^{log2_sample} symbols of the same stream "
+                         f"({t5 - t4:.1f} s; the oracle port: {port:.1f} Msuffixes/s); " + out["sample"].split("; ", 1)[1])
+    return out
 
 
 def pmc_traffic(log2n, sigma, tables, klass):
