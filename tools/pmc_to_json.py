@@ -3,7 +3,7 @@ HBM bytes per launch for every kernel class of bench.py, corrected as the MI355X
 HBM section prescribes (FETCH_SIZE counts half of wide streaming reads on gfx950 -> x2;
 WRITE_SIZE is exact; both counters are in KiB).
 
-    python tools/pmc_to_json.py gpurun_out/prof "2^30 sigma=5" profiles/pmc_traffic.json
+    python tools/pmc_to_json.py gpurun_out/prof "log2n=30 sigma=5 tables=1" profiles/pmc_traffic.json
 """
 import csv
 import glob
