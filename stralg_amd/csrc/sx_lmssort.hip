@@ -121,36 +121,118 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
     }
 }
 
-// members of groups of equal keys: (index in the sorted order, text position, group head index)
-struct InTied {
-    const uint64_t *ks;
-    uint64_t m, kmask; // kmask: the sorted-on bits (the rest of a key is payload)
-    __device__ __forceinline__ uint32_t operator()(uint64_t j) const
-    {
-        const uint64_t k = ks[j] & kmask;
-        const bool eq_prev = j > 0 && (ks[j - 1] & kmask) == k;
-        const bool eq_next = j + 1 < m && (ks[j + 1] & kmask) == k;
-        return (eq_prev || eq_next) ? 1u : 0u;
+// Members of groups of equal keys -> (index in the sorted order, text position, group head flag), compacted in
+// order; the window of every sorted slot is lifted out of the key's payload bits on the way.  One launch: a
+// thread takes 8 consecutive keys (16-byte loads) and their two neighbours, tiles take tickets, and the number
+// of tied members in earlier tiles comes from the chained look-back of sx_device.hpp (one status word per tile,
+// a whole wave looking back 64 tiles a step), so the sorted keys are read once.
+// A tile is kTiedSub sub-tiles of 2048 keys taken one after the other: with thousands of tiles in flight a
+// look-back walks over most of them (a hop to another XCD's status word costs microseconds), so a tile has to
+// carry enough traffic (8192 keys: 147 KB) to hide a walk of tens of microseconds.
+constexpr int kTiedItems = 8, kTiedSub = 4;
+constexpr int kTiedSubTile = kBlock * kTiedItems, kTiedTile = kTiedSubTile * kTiedSub;
+__global__ __launch_bounds__(kBlock) void tied_compact_kernel(const uint64_t *__restrict__ ks,
+                                                              const uint32_t *__restrict__ vs, uint64_t m, uint64_t kmask,
+                                                              uint32_t kbits, uint32_t *__restrict__ apos,
+                                                              uint32_t *__restrict__ ap, uint8_t *__restrict__ ahead,
+                                                              uint32_t cap, uint32_t *__restrict__ seedw,
+                                                              uint64_t *__restrict__ status, uint32_t epoch)
+{
+    __shared__ uint64_t lds[kWavesPerBlock];
+    __shared__ uint32_t s_tile, s_prefix;
+    const int t = (int)threadIdx.x;
+    // header words of the status buffer: [0] time-out flag, [1] ticket counter, [2] total (written by the last tile)
+    const uint32_t ntiles = (uint32_t)((m + kTiedTile - 1) / kTiedTile);
+    for (;;) { // workgroups keep taking tiles: the grid bounds how many tiles, hence look-back hops, are in flight
+    if (t == 0) s_tile = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(status + 1), 1ull);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= ntiles) break; // uniform
+    uint32_t fmask = 0, hmask = 0; // tied / group head, bit 8 s + i = key i of this thread in sub-tile s
+    uint64_t counts = 0;           // tied keys of this thread per sub-tile, 16-bit fields
+#pragma unroll
+    for (int sub = 0; sub < kTiedSub; ++sub) {
+        const uint64_t j0 = (uint64_t)tile * kTiedTile + (uint64_t)sub * kTiedSubTile + (uint64_t)t * kTiedItems;
+        uint64_t raw[kTiedItems];
+        if (j0 + kTiedItems <= m && ((uintptr_t)ks & 15u) == 0) {
+#pragma unroll
+            for (int q = 0; q < kTiedItems / 2; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ks + j0 + 2 * q);
+                raw[2 * q] = pack64(v.x, v.y);
+                raw[2 * q + 1] = pack64(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kTiedItems; ++i) raw[i] = j0 + i < m ? ks[j0 + i] : 0ull;
+        }
+        const bool has_prev = j0 > 0 && j0 <= m, has_next = j0 + kTiedItems < m;
+        const uint64_t kprev = has_prev ? ks[j0 - 1] & kmask : 0ull, knext = has_next ? ks[j0 + kTiedItems] & kmask : 0ull;
+        uint32_t f = 0, h = 0;
+#pragma unroll
+        for (int i = 0; i < kTiedItems; ++i) {
+            const uint64_t k = raw[i] & kmask;
+            const bool valid = j0 + i < m;
+            const bool eq_prev = valid && (i > 0 ? (raw[i > 0 ? i - 1 : 0] & kmask) == k : (has_prev && kprev == k));
+            const bool eq_next =
+                valid && (i + 1 < kTiedItems ? (j0 + i + 1 < m && (raw[i + 1 < kTiedItems ? i + 1 : i] & kmask) == k)
+                                             : (has_next && knext == k));
+            if (eq_prev || eq_next) f |= 1u << i;
+            if (!eq_prev) h |= 1u << i;
+        }
+        fmask |= f << (8 * sub);
+        hmask |= h << (8 * sub);
+        counts |= (uint64_t)__popc(f) << (16 * sub);
+        if (seedw) {
+            if (j0 + kTiedItems <= m && ((uintptr_t)seedw & 15u) == 0) {
+#pragma unroll
+                for (int q = 0; q < kTiedItems / 4; ++q) {
+                    uint4 v;
+                    v.x = (uint32_t)(raw[4 * q] >> kbits), v.y = (uint32_t)(raw[4 * q + 1] >> kbits);
+                    v.z = (uint32_t)(raw[4 * q + 2] >> kbits), v.w = (uint32_t)(raw[4 * q + 3] >> kbits);
+                    *reinterpret_cast<uint4 *>(seedw + j0 + 4 * q) = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kTiedItems; ++i)
+                    if (j0 + i < m) seedw[j0 + i] = (uint32_t)(raw[i] >> kbits);
+            }
+        }
     }
-};
-struct OutTied {
-    const uint64_t *ks;
-    const uint32_t *vs;
-    uint32_t *apos, *ap;
-    uint8_t *ahead;
-    uint32_t cap;
-    uint64_t kmask;
-    uint32_t *seedw; // optional: window of every sorted slot, taken from the key's payload bits
-    uint32_t kbits;
-    __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const
-    {
-        if (seedw) seedw[j] = (uint32_t)(ks[j] >> kbits);
-        if (!v || excl >= cap) return;
-        apos[excl] = (uint32_t)j;
-        ap[excl] = vs[j];
-        ahead[excl] = (j == 0 || (ks[j - 1] & kmask) != (ks[j] & kmask)) ? 1 : 0;
+    // tied keys before this thread inside each sub-tile (one packed scan), and per sub-tile in all
+    uint64_t tot;
+    const uint64_t ex = block_exclusive_sum64(counts, lds, tot);
+    uint32_t tile_total = 0;
+#pragma unroll
+    for (int sub = 0; sub < kTiedSub; ++sub) tile_total += (uint32_t)(tot >> (16 * sub)) & 0xFFFFu;
+    if (wave_id() == 0) { // tied members in earlier tiles
+        const uint32_t before = chain_exclusive_prefix_wave(status, 1u, tile, 0u, tile_total, epoch);
+        if (t == 0) s_prefix = before;
     }
-};
+    __syncthreads();
+    if (fmask) {
+        uint32_t sub_base = s_prefix;
+#pragma unroll
+        for (int sub = 0; sub < kTiedSub; ++sub) {
+            const uint64_t j0 = (uint64_t)tile * kTiedTile + (uint64_t)sub * kTiedSubTile + (uint64_t)t * kTiedItems;
+            uint32_t slot = sub_base + ((uint32_t)(ex >> (16 * sub)) & 0xFFFFu);
+#pragma unroll
+            for (int i = 0; i < kTiedItems; ++i) {
+                if ((fmask >> (8 * sub + i)) & 1u) {
+                    if (slot < cap) {
+                        apos[slot] = (uint32_t)(j0 + i);
+                        ap[slot] = vs[j0 + i];
+                        ahead[slot] = (uint8_t)((hmask >> (8 * sub + i)) & 1u);
+                    }
+                    ++slot;
+                }
+            }
+            sub_base += (uint32_t)(tot >> (16 * sub)) & 0xFFFFu;
+        }
+    }
+    if (t == 0 && tile + 1 == ntiles) status[2] = (uint64_t)(s_prefix + tile_total); // the last tile
+    __syncthreads(); // s_tile and s_prefix are rewritten by the next round
+    }
+}
 
 // group id of an active element = index (in the active list) of its group's first member
 struct InActHead {
@@ -323,10 +405,19 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         ks = in_b ? kb : ka;
         vs = in_b ? vb : va;
         // members of groups with equal keys
-        SX_TRY((device_compact(ctx, m, InTied{ks, m, kmask},
-                                   OutTied{ks, vs, apos, ap, head, cap, kmask, embed ? seedw : nullptr, (uint32_t)kbits}, d_scalar,
-                                   SX_KC_NAMES, m * 16)));
-        SX_TRY(sx_readback(ctx, d_scalar, 1, &A));
+        {
+            const uint32_t tiles = sx_div_up(m, kTiedTile);
+            const uint32_t tied_grid = 2048; // measured at m = 3.1e8: 256 workgroups 3.4 ms, 512 2.2, 1024-2048 1.8, one per tile 2.2
+            SX_TRY(sx_chain_slab(ctx, SX_SLAB_CHAIN, ((size_t)tiles + kChainHeader) * sizeof(uint64_t)));
+            uint64_t *status = (uint64_t *)ctx->slab[SX_SLAB_CHAIN].p;
+            SX_CHECK(hipMemsetAsync(status, 0, kChainHeader * sizeof(uint64_t), ctx->stream));
+            sx_launch(ctx, SX_KC_NAMES, m * 16, tied_compact_kernel, dim3(tiles < tied_grid ? tiles : tied_grid), block, ks, (const uint32_t *)vs, m, kmask,
+                      (uint32_t)kbits, apos, ap, head, cap, embed ? seedw : nullptr, status, sx_chain_next_epoch(ctx));
+            uint32_t hdr[6];
+            SX_TRY(sx_readback(ctx, (const uint32_t *)status, 6, hdr));
+            if (hdr[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "tie detection: a look-back wait timed out");
+            A = hdr[4];
+        }
         ctx->stats.n_names = m - A; // suffixes told apart by the first sort
         ctx->stats.key_slots = C;
         ctx->stats.key_bits = (uint32_t)kbits;
