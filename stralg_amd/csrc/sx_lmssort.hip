@@ -294,6 +294,66 @@ __global__ __launch_bounds__(kBlock) void refine_write_kernel(const uint32_t *__
     head_new[t] = head ? 1 : 0;
 }
 
+// The same refinement for groups of at most kSmallGroup members (on random text all of them: mostly two suffixes
+// sharing a prefix), by the thread of the group's head: next keys, a sorting network, write-back.  Larger groups are only
+// counted; if there are any, the round is redone by the sorting path above (nothing this kernel reads is
+// overwritten by it).
+constexpr int kSmallGroup = 8;
+__global__ __launch_bounds__(kBlock) void refine_small_groups_kernel(
+    const uint8_t *__restrict__ T, uint64_t n, const uint32_t *__restrict__ ap, const uint32_t *__restrict__ apos,
+    const uint8_t *__restrict__ head, uint64_t A, uint64_t skip, pkey_cfg kc, uint32_t *__restrict__ vals_sorted,
+    uint32_t *__restrict__ ap_new, uint8_t *__restrict__ head_new, uint32_t *__restrict__ seedw, wnd_cfg wcfg,
+    uint32_t *__restrict__ large)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= A || !head[t]) return;
+    int size = 1;
+    while (size <= kSmallGroup && t + size < A && !head[t + size]) ++size;
+    if (size > kSmallGroup) {
+        atomicAdd(large, 1u);
+        return;
+    }
+    uint32_t p[kSmallGroup];
+    uint64_t k[kSmallGroup];
+#pragma unroll
+    for (int i = 0; i < kSmallGroup; ++i) {
+        p[i] = 0;
+        k[i] = ~0ull; // padding sorts last
+        if (i < size) {
+            p[i] = ap[t + i];
+            const uint64_t q = (uint64_t)p[i] + skip;
+            k[i] = q <= n ? prefix_key(T, q, kc) : 0ull;
+        }
+    }
+#define SX_CSWAP(a, b)                                                                                                 \
+    if (k[b] < k[a]) {                                                                                                 \
+        const uint64_t tk = k[a];                                                                                      \
+        k[a] = k[b], k[b] = tk;                                                                                        \
+        const uint32_t tp = p[a];                                                                                      \
+        p[a] = p[b], p[b] = tp;                                                                                        \
+    }
+    // Batcher's odd-even merge sort for 8 (19 exchanges); groups of at most 4 only need the first three layers
+    SX_CSWAP(0, 1) SX_CSWAP(2, 3) SX_CSWAP(4, 5) SX_CSWAP(6, 7)
+    SX_CSWAP(0, 2) SX_CSWAP(1, 3) SX_CSWAP(4, 6) SX_CSWAP(5, 7)
+    SX_CSWAP(1, 2) SX_CSWAP(5, 6)
+    if (size > 4) {
+        SX_CSWAP(0, 4) SX_CSWAP(1, 5) SX_CSWAP(2, 6) SX_CSWAP(3, 7)
+        SX_CSWAP(2, 4) SX_CSWAP(3, 5)
+        SX_CSWAP(1, 2) SX_CSWAP(3, 4) SX_CSWAP(5, 6)
+    }
+#undef SX_CSWAP
+#pragma unroll
+    for (int i = 0; i < kSmallGroup; ++i) {
+        if (i < size) {
+            const uint32_t slot = apos[t + i];
+            vals_sorted[slot] = p[i];
+            if (seedw) seedw[slot] = p[i] ? wnd_fill<uint32_t>(T, p[i], wcfg) : 0u;
+            ap_new[t + i] = p[i];
+            head_new[t + i] = (i == 0 || k[i] != k[i > 0 ? i - 1 : 0]) ? 1 : 0;
+        }
+    }
+}
+
 struct InStillTied {
     const uint8_t *head;
     uint64_t A;
@@ -439,9 +499,18 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         if (round > 4) return 0; // still tied after C + 4 Cmax symbols: general path
         ctx->stats.doubling_rounds++;
         const uint32_t gbits = (uint32_t)(sx_bitlen(A) > 0 ? sx_bitlen(A) : 1);
+        const uint64_t skip = (uint64_t)C + (uint64_t)Cmax * (round - 1);
+        // groups of up to eight members: settled by their head's thread
+        uint32_t large = 0;
+        SX_CHECK(hipMemsetAsync(d_scalar + 1, 0, sizeof(uint32_t), ctx->stream));
+        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_small_groups_kernel, dim3(sx_div_up(A, kBlock)), block, ti.T,
+                  ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip,
+                  pkey_make(base, Cmax), vs, ap_new, head_new, embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
+        SX_TRY(sx_readback(ctx, d_scalar + 1, 1, &large));
+        if (large) {
         // group ids and the next C symbols of every tied suffix
         SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head},
-                                   OutActKey{ti.T, ap, ti.n, (uint64_t)C + (uint64_t)Cmax * (round - 1), pkey_make(base, Cmax), agid, key_keep, rk_a, ord_a},
+                                   OutActKey{ti.T, ap, ti.n, skip, pkey_make(base, Cmax), agid, key_keep, rk_a, ord_a},
                                    nullptr, SX_KC_DOUBLING, (uint64_t)A * 32)));
         // order by (group, next key), LSD: stable sort by next key, then stable sort by group
         int f = 0;
@@ -455,6 +524,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 40, refine_write_kernel, dim3(sx_div_up(A, kBlock)), block, order,
                   (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid, (const uint64_t *)key_keep,
                   (uint64_t)A, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
+        }
         // keep what is still tied
         SX_TRY((device_compact(ctx, A, InStillTied{head_new, A},
                                    OutStillTied{apos, ap_new, head_new, apos2, ap2, head2}, d_scalar, SX_KC_DOUBLING,
