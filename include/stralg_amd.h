@@ -30,7 +30,8 @@ enum {
     SX_OK = 0,
     SX_E_ARG = -1,     /* malformed argument (symbol >= alphabet_size, interior 0, n too large) */
     SX_E_NOMEM = -2,   /* host allocation failed */
-    SX_E_INTERNAL = -3 /* a device-side invariant did not hold */
+    SX_E_INTERNAL = -3, /* a device-side invariant did not hold */
+    SX_E_MALFORMED = -4 /* a FASTA image that ends inside a header line (bioinf/fasta.c:121-124 MALFORMED_FILE) */
 };
 
 /* Kernel classes for the in-library HIP-event profiler (bench.py roofline). */
@@ -137,6 +138,24 @@ int sx_sa_inverse_lcp(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint
 int sx_bwt_exact_search_dev(sx_ctx *ctx, const uint32_t *d_c_table, const uint32_t *d_o_table, uint64_t N,
                             uint32_t sigma, const uint8_t *d_patterns, const uint32_t *d_offsets, uint32_t count,
                             uint32_t *d_l_out, uint32_t *d_r_out);
+
+/* ---- FASTA ingest and remap on the device ---------------- */
+/* bioinf/fasta.c:92-135 load_fasta_records' packing of a file image in device memory into
+ * "name\0sequence\0name\0sequence\0..." (file order; the reference's record list is the reverse).
+ * d_packed_out: file_len + 1 bytes.  d_term_out (optional, term_cap entries): positions of the
+ * terminators in the packed image, so record r has its name at (r ? term[2r-1] + 1 : 0), its
+ * sequence at term[2r] + 1 and seq_len = term[2r+1] - term[2r] - 1.  file_len < 2^31 - 1.
+ * Returns SX_E_MALFORMED where the reference reports MALFORMED_FILE. */
+int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uint8_t *d_packed_out,
+                      uint64_t *packed_len_out, uint32_t *d_term_out, uint64_t term_cap, uint32_t *n_records_out);
+/* the same with host buffers (staged through the context) */
+int sx_fasta_pack(sx_ctx *ctx, const uint8_t *file, uint64_t file_len, uint8_t *packed_out, uint64_t *packed_len_out,
+                  uint32_t *term_out, uint64_t term_cap, uint32_t *n_records_out);
+/* stralg/remap.c:8-31,102-114 build_remap_table + remap: d_out[0..n) = dense order-preserving codes 1..k of
+ * d_in, d_out[n] = 0; table_out (host, 256 entries, optional): code of every byte value, -1 for absent ones;
+ * *alphabet_size_out = k + 1.  Fails when more than 127 distinct symbols occur (remap.h:14-18). */
+int sx_remap_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out, int16_t *table_out,
+                 uint32_t *alphabet_size_out);
 
 /* ---- measurement ------------------------------------------------------------ */
 int sx_profile_enable(sx_ctx *ctx, int on);       /* bracket every launch with HIP events */

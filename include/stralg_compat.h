@@ -108,6 +108,38 @@ void init_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_tab
 bool next_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_exact_match *match);
 void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter);
 
+/* ---- FASTA records (bioinf/fasta.h:10-49, stralg/error.h:7-21) --------------------------------
+ * load_fasta_records reads the file and packs it on the GPU (sx_fasta_pack: the reference's in-place
+ * packing loop as scan + compaction); names and sequences point into one buffer owned by the records
+ * object, the iterator walks the records in reverse file order (fasta.c:131-134), sequences keep
+ * their original symbols (build_complete_table remaps). */
+enum error_codes {
+    NO_ERROR,
+    CANNOT_OPEN_FILE,
+    MALFORMED_FILE,
+    SUFFIX_ARRAYS_DIFFER,
+    REMAP_TABLES_DIFFER,
+    BWT_TABLES_DIFFER,
+    MALFORMED_CIGAR
+};
+struct fasta_records;
+struct fasta_record_impl;
+struct fasta_record {
+    const char *name;
+    const uint8_t *seq;
+    uint32_t seq_len;
+};
+struct fasta_iter {
+    struct fasta_record_impl *rec;
+};
+struct fasta_records *load_fasta_records(const char *fname, enum error_codes *err);
+void free_fasta_records(struct fasta_records *file);
+uint32_t number_of_fasta_records(struct fasta_records *records);
+bool lookup_fasta_record_by_name(struct fasta_records *file, const char *name, struct fasta_record *record);
+void init_fasta_iter(struct fasta_iter *iter, struct fasta_records *file);
+bool next_fasta_record(struct fasta_iter *iter, struct fasta_record *rec);
+void dealloc_fasta_iter(struct fasta_iter *iter);
+
 /* ---- additions (not in the reference) --------------------------------------- */
 /* GPU used by the calling thread's constructors (default: $STRALG_AMD_DEVICE or 0).
  * One context per host thread, so N threads can farm records over N GPUs
@@ -119,6 +151,11 @@ void stralg_amd_release(void);
  * one host thread per device; out[k] receives build_complete_table(strings[k], ...). */
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out);
+/* The loop of bwt_readmapper.c:54-62 over a whole FASTA file: out[k] = build_complete_table of the k-th
+ * record in ITERATION order (reverse file order), records farmed over the devices; returns the number of
+ * records (out needs number_of_fasta_records(records) slots), or a negative value on failure. */
+int stralg_amd_fasta_tables_batch(struct fasta_records *records, bool include_reverse, const int *devices,
+                                  int n_devices, struct bwt_table **out);
 
 #ifdef __cplusplus
 }

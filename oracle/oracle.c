@@ -371,6 +371,67 @@ uint32_t oracle_remap(const uint8_t *in, size_t n, uint8_t *out, int16_t table_o
     return next;
 }
 
+/* ---- FASTA ingest --------------------------------------------------------------- */
+
+/* isspace() in the C locale, which is what the reference's pack_seq sees */
+static int fasta_space(uint8_t c)
+{
+    return c == ' ' || (c >= '\t' && c <= '\r');
+}
+
+int oracle_fasta_pack(const uint8_t *file, size_t len, uint8_t *packed_out, size_t *packed_len, uint32_t *n_records)
+{
+    /* the reference works on the NUL-terminated image load_file returns (io.c:15-18): a NUL inside the file ends it */
+    size_t end = 0;
+    while (end < len && file[end] != 0)
+        ++end;
+#define AT(i) ((i) < end ? file[i] : (uint8_t)0)
+    size_t front = 0, pack = 0;
+    uint32_t recs = 0;
+    int have_front = 1;
+    while (have_front) { /* fasta.c:117-134 */
+        /* pack_name, fasta.c:26-48 */
+        for (;;) {
+            while (AT(front) == '>' || AT(front) == ' ' || AT(front) == '\t')
+                ++front;
+            if (AT(front) == 0 || AT(front) == '\n')
+                break;
+            packed_out[pack++] = AT(front);
+            ++front;
+        }
+        /* The reference packs in place: when nothing has been dropped yet (a first header line without '>',
+         * ' ' or '\t'), the terminator it writes here lands on the very newline it examines next, and the
+         * file is taken to end inside the header (fasta.c:41-44 after :39). */
+        const int clobbered = pack == front;
+        packed_out[pack++] = 0;
+        if (AT(front) == 0 || clobbered) { /* the file ends inside a header line: fasta.c:121-124 */
+            *packed_len = pack;
+            *n_records = recs;
+            return 1;
+        }
+        ++front;
+        /* pack_seq, fasta.c:50-70 */
+        for (;;) {
+            while (AT(front) && fasta_space(AT(front)))
+                ++front;
+            if (AT(front) == 0 || AT(front) == '>')
+                break;
+            packed_out[pack++] = AT(front);
+            ++front;
+        }
+        packed_out[pack++] = 0;
+        if (AT(front) == 0)
+            have_front = 0;
+        else
+            ++front;
+        ++recs;
+    }
+#undef AT
+    *packed_len = pack;
+    *n_records = recs;
+    return 0;
+}
+
 /* ---- extended suffix array, exact search ------------------------------------------ */
 
 void oracle_inverse(const uint32_t *sa, size_t N, uint32_t *inv_out)

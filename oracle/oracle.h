@@ -58,6 +58,13 @@ void oracle_o_table(const uint8_t *text, const uint32_t *sa, size_t N, uint32_t 
  * more than 127 distinct symbols are present (remap.h:14-18). */
 uint32_t oracle_remap(const uint8_t *in, size_t n, uint8_t *out, int16_t table_out[256]);
 
+/* bioinf/fasta.c:26-70,92-135 load_fasta_records' in-place packing, out of place: the image
+ * "name\0sequence\0name\0sequence\0..." in file order (the reference's record list is this in
+ * reverse).  A header line loses every '>', ' ' and '\t'; a sequence loses all white space and
+ * ends at the next '>' wherever it stands.  packed_out needs len + 1 bytes.  Returns 0, or 1 for
+ * a file that ends inside a header line (MALFORMED_FILE; what was packed so far is reported). */
+int oracle_fasta_pack(const uint8_t *file, size_t len, uint8_t *packed_out, size_t *packed_len, uint32_t *n_records);
+
 /* stralg/suffix_array.c:53-60 compute_inverse: inv[sa[i]] = i. */
 void oracle_inverse(const uint32_t *sa, size_t N, uint32_t *inv_out);
 

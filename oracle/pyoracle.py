@@ -164,6 +164,28 @@ def remap(raw):
     return out[:n].copy(), int(sigma), table
 
 
+def fasta_pack(data):
+    """bioinf/fasta.c packing: returns (malformed, packed image bytes, [(name, sequence), ...] in file order)."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+    out = np.zeros(buf.size + 2, dtype=np.uint8)
+    plen = C.c_size_t(0)
+    nrec = C.c_uint32(0)
+    lib = _lib()
+    lib.oracle_fasta_pack.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_uint32)]
+    lib.oracle_fasta_pack.restype = C.c_int
+    src = buf if buf.size else np.zeros(1, np.uint8)
+    bad = lib.oracle_fasta_pack(_u8(src), buf.size, _u8(out), C.byref(plen), C.byref(nrec))
+    packed = out[:plen.value].tobytes()
+    return bool(bad), packed, fasta_records_of(packed, nrec.value)
+
+
+def fasta_records_of(packed, n_records):
+    """split a packed image into its (name, sequence) pairs"""
+    parts = packed.split(b"\0")
+    return [(parts[2 * r], parts[2 * r + 1]) for r in range(n_records)]
+
+
 def check_sa(text, sa):
     buf, n = _text(text)
     sa = np.ascontiguousarray(sa, dtype=np.uint32)
@@ -259,6 +281,46 @@ class _Ref:
     def qsort(self, text):
         buf, _ = _text(text)
         return self._sa(self.lib.qsort_sa_construction, buf)
+
+    def fasta(self, data):
+        """load_fasta_records on a temporary file: (error code, [(name, sequence), ...] in ITERATION order,
+        i.e. the reverse of the file order, bioinf/fasta.c:131-134)."""
+        import tempfile
+
+        class _Rec(C.Structure):
+            _fields_ = [("name", C.c_char_p), ("seq", C.POINTER(C.c_uint8)), ("seq_len", C.c_uint32)]
+
+        class _Iter(C.Structure):
+            _fields_ = [("rec", C.c_void_p)]
+
+        lib = self.lib
+        lib.load_fasta_records.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        lib.load_fasta_records.restype = C.c_void_p
+        lib.free_fasta_records.argtypes = [C.c_void_p]
+        lib.init_fasta_iter.argtypes = [C.POINTER(_Iter), C.c_void_p]
+        lib.next_fasta_record.argtypes = [C.POINTER(_Iter), C.POINTER(_Rec)]
+        lib.next_fasta_record.restype = C.c_bool
+        with tempfile.NamedTemporaryFile(suffix=".fa") as f:
+            f.write(bytes(data))
+            f.flush()
+            err = C.c_int(0)
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            saved = os.dup(2)
+            os.dup2(devnull, 2)  # the loader reports every record on stderr
+            try:
+                h = lib.load_fasta_records(f.name.encode(), C.byref(err))
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+                os.close(devnull)
+        if not h:
+            return err.value, []
+        it, rec, out = _Iter(), _Rec(), []
+        lib.init_fasta_iter(C.byref(it), h)
+        while lib.next_fasta_record(C.byref(it), C.byref(rec)):
+            out.append((rec.name, bytes(bytearray(rec.seq[i] for i in range(rec.seq_len)))))
+        lib.free_fasta_records(h)
+        return err.value, out
 
     def remap_string(self, raw):
         buf, n = _text(raw)

@@ -132,6 +132,38 @@ class Context:
                                                      _ptr(d_offsets), count, _ptr(d_l), _ptr(d_r)),
                     "sx_bwt_exact_search_dev")
 
+    # ---- FASTA ingest and remap ------------------------------
+    def fasta_pack_dev(self, d_file, file_len, d_packed, d_term=None, term_cap=0):
+        """bioinf/fasta.c load_fasta_records' packing on the device: returns (packed_len, n_records); raises
+        StralgAmdError (code SX_E_MALFORMED = -4) where the reference reports MALFORMED_FILE."""
+        plen, nrec = C.c_uint64(0), C.c_uint32(0)
+        self._check(self.lib.sx_fasta_pack_dev(self.h, _ptr(d_file), file_len, _ptr(d_packed), C.byref(plen), _ptr(d_term),
+                                               term_cap, C.byref(nrec)), "sx_fasta_pack_dev")
+        return int(plen.value), int(nrec.value)
+
+    def remap_dev(self, d_in, n, d_out):
+        """stralg/remap.c on the device: d_out[0..n) dense codes, d_out[n] = 0; returns (alphabet_size, table[256])."""
+        table = np.zeros(256, dtype=np.int16)
+        sigma = C.c_uint32(0)
+        self._check(self.lib.sx_remap_dev(self.h, _ptr(d_in), n, _ptr(d_out), table.ctypes.data_as(C.POINTER(C.c_int16)),
+                                          C.byref(sigma)), "sx_remap_dev")
+        return int(sigma.value), table
+
+    def fasta_records(self, data):
+        """sx_fasta_pack (host buffers): [(name, sequence), ...] in file order from the bytes of a FASTA file"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        packed = np.zeros(buf.size + 1, dtype=np.uint8)
+        term = np.zeros(buf.size + 2, dtype=np.uint32)
+        plen, nrec = C.c_uint64(0), C.c_uint32(0)
+        self._check(self.lib.sx_fasta_pack(self.h, _ptr(buf) if buf.size else None, buf.size, _ptr(packed), C.byref(plen),
+                                           _ptr(term), term.size, C.byref(nrec)), "sx_fasta_pack")
+        out = []
+        for r in range(nrec.value):
+            n0 = 0 if r == 0 else int(term[2 * r - 1]) + 1
+            s0 = int(term[2 * r]) + 1
+            out.append((packed[n0:int(term[2 * r])].tobytes(), packed[s0:int(term[2 * r + 1])].tobytes()))
+        return out
+
     # ---- primitives (kernel-level tests) ------------------------------------------
     def prim_sort_pairs_dev(self, ka, va, kb, vb, n, begin_bit, end_bit):
         flag = C.c_int(0)

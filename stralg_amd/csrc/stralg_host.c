@@ -350,6 +350,102 @@ bool next_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_exa
 
 void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter) { (void)iter; }
 
+/* ---- FASTA records (bioinf/fasta.c:92-222) ------------------------------------------------ */
+
+struct fasta_record_impl {
+    const char *name;
+    const uint8_t *seq;
+    uint32_t seq_len;
+    uint32_t no_records;
+    struct fasta_record_impl *next;
+};
+struct fasta_records {
+    uint8_t *buffer; /* the packed image: name\0sequence\0... in file order */
+    struct fasta_record_impl *recs, *storage;
+};
+
+struct fasta_records *load_fasta_records(const char *fname, enum error_codes *err)
+{
+    if (err) *err = NO_ERROR;
+    FILE *f = fopen(fname, "rb");
+    if (!f) {
+        if (err) *err = CANNOT_OPEN_FILE;
+        return NULL;
+    }
+    fseek(f, 0, SEEK_END);
+    const long fsize = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t *image = malloc((size_t)fsize + 1);
+    uint8_t *packed = malloc((size_t)fsize + 2);
+    uint32_t *term = malloc(((size_t)fsize + 2) * sizeof *term);
+    if (!image || !packed || !term) die("load_fasta_records: out of memory", -2, NULL);
+    if (fsize && fread(image, (size_t)fsize, 1, f) != 1) die("load_fasta_records: read failed", -1, NULL);
+    fclose(f);
+    sx_ctx *ctx = thread_ctx();
+    uint64_t packed_len = 0;
+    uint32_t n = 0;
+    const int rc = sx_fasta_pack(ctx, image, (uint64_t)fsize, packed, &packed_len, term, (uint64_t)fsize + 2, &n);
+    free(image);
+    if (rc == SX_E_MALFORMED) {
+        free(packed);
+        free(term);
+        if (err) *err = MALFORMED_FILE;
+        return NULL;
+    }
+    if (rc != 0) die("load_fasta_records", rc, ctx);
+    struct fasta_records *recs = malloc(sizeof *recs);
+    recs->buffer = packed;
+    recs->storage = malloc((n ? n : 1) * sizeof *recs->storage);
+    recs->recs = NULL;
+    for (uint32_t r = 0; r < n; ++r) { /* file order; every record is put in front of the list (fasta.c:127-131) */
+        struct fasta_record_impl *rec = &recs->storage[r];
+        rec->name = (const char *)(packed + (r ? term[2 * r - 1] + 1 : 0));
+        rec->seq = packed + term[2 * r] + 1;
+        rec->seq_len = term[2 * r + 1] - term[2 * r] - 1;
+        rec->no_records = r + 1;
+        rec->next = recs->recs;
+        recs->recs = rec;
+    }
+    free(term);
+    return recs;
+}
+
+void free_fasta_records(struct fasta_records *file)
+{
+    free(file->buffer);
+    free(file->storage);
+    free(file);
+}
+
+uint32_t number_of_fasta_records(struct fasta_records *records) { return records->recs->no_records; }
+
+bool lookup_fasta_record_by_name(struct fasta_records *file, const char *name, struct fasta_record *record)
+{
+    for (struct fasta_record_impl *rec = file->recs; rec; rec = rec->next) {
+        if (strcmp(rec->name, name) == 0) {
+            record->name = rec->name;
+            record->seq = rec->seq;
+            record->seq_len = rec->seq_len;
+            return true;
+        }
+    }
+    return false;
+}
+
+void init_fasta_iter(struct fasta_iter *iter, struct fasta_records *file) { iter->rec = file->recs; }
+
+bool next_fasta_record(struct fasta_iter *iter, struct fasta_record *rec)
+{
+    if (!iter->rec) return false;
+    rec->name = iter->rec->name;
+    rec->seq = iter->rec->seq;
+    rec->seq_len = iter->rec->seq_len;
+    iter->rec = iter->rec->next;
+    return true;
+}
+
+void dealloc_fasta_iter(struct fasta_iter *iter) { (void)iter; }
+
 /* ---- batch farm: independent records, one host thread per GPU ------------------------ */
 
 struct farm_job {
@@ -389,4 +485,18 @@ int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, b
     free(jobs);
     free(threads);
     return 0;
+}
+
+int stralg_amd_fasta_tables_batch(struct fasta_records *records, bool include_reverse, const int *devices,
+                                  int n_devices, struct bwt_table **out)
+{
+    if (!records || !out) return -1;
+    const uint32_t n = records->recs ? records->recs->no_records : 0;
+    const uint8_t **strings = malloc((n ? n : 1) * sizeof *strings);
+    if (!strings) return -2;
+    uint32_t k = 0;
+    for (struct fasta_record_impl *rec = records->recs; rec; rec = rec->next) strings[k++] = rec->seq;
+    const int rc = stralg_amd_build_tables_batch(strings, n, include_reverse, devices, n_devices, out);
+    free(strings);
+    return rc < 0 ? rc : (int)n;
 }

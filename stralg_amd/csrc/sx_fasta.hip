@@ -1,0 +1,268 @@
+// sx_fasta.hip -- FASTA ingest and symbol remap on the device.
+//
+// bioinf/fasta.c:92-135 load_fasta_records packs the file image in place into
+// "name\0sequence\0name\0sequence\0...": a header line loses every '>', ' ' and '\t' and ends at
+// its newline (fasta.c:26-48); a sequence loses all white space and ends at the next '>',
+// wherever it stands, or at the end of the file (fasta.c:50-70).  Whether a byte belongs to a
+// header or to a sequence depends only on the last '\n' or '>' before it ('\n' -> sequence,
+// '>' -> header, none -> header), so the sequential packing loop becomes
+//   1. a max-scan carrying (position, kind) of the last such byte -> a code per byte
+//      (drop / keep / header terminator / sequence terminator),
+//   2. a stream compaction of the kept bytes and terminators -> the packed image,
+//   3. a compaction of the terminator positions -> the record table (terminators alternate
+//      header, sequence, header, ...).
+// stralg/remap.c:8-31,102-114 (build table from the symbols present, relabel) is a presence
+// histogram, a 256-entry table built on the host, and a streaming lookup.
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_scan.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+__device__ __forceinline__ bool fasta_space(uint32_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+// position of the first NUL byte (the reference reads a C string: io.c:15-18)
+__global__ __launch_bounds__(kBlock) void fasta_first_nul_kernel(const uint8_t *__restrict__ file, uint64_t len,
+                                                                 uint32_t *__restrict__ first)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (uint64_t)gridDim.x * kBlock)
+        if (file[i] == 0) atomicMin(first, (uint32_t)i);
+}
+
+// byte i of the image, with the terminating NUL the reference's buffer holds at `end`
+struct FastaIn {
+    const uint8_t *file;
+    uint64_t end;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        const uint32_t b = i < end ? file[i] : 0u;
+        if (b == '\n') return ((uint32_t)(i + 1) << 1) | 1u;
+        if (b == '>') return (uint32_t)(i + 1) << 1;
+        return 0u;
+    }
+};
+enum { FA_DROP = 0, FA_KEEP = 1, FA_NAME_END = 2, FA_SEQ_END = 3 };
+struct FastaCode {
+    const uint8_t *file;
+    uint64_t end;
+    uint8_t *code;
+    uint32_t *flags; // [0] set: the image ends inside a header line; [1] position of the first header terminator
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t last, uint32_t) const
+    {
+        const uint32_t b = i < end ? file[i] : 0u;
+        const bool in_seq = last != 0 && (last & 1u);
+        uint32_t c;
+        if (in_seq) {
+            c = (b == '>' || i >= end) ? FA_SEQ_END : (fasta_space(b) ? FA_DROP : FA_KEEP);
+        } else if (i >= end) {
+            c = FA_DROP;
+            atomicOr(&flags[0], 1u);
+        } else if (b == '\n') {
+            c = FA_NAME_END;
+            atomicMin(&flags[1], (uint32_t)i);
+        } else {
+            c = (b == '>' || b == ' ' || b == '\t') ? FA_DROP : FA_KEEP;
+        }
+        code[i] = (uint8_t)c;
+    }
+};
+struct FastaEmit {
+    const uint8_t *code;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return code[i] != FA_DROP ? 1u : 0u; }
+};
+struct FastaWrite {
+    const uint8_t *file, *code;
+    uint8_t *packed;
+    uint32_t *scal; // [2] position of the first header terminator in the file -> [0] its position in the packed image
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t dst, uint32_t f) const
+    {
+        if (!f) return;
+        packed[dst] = code[i] == FA_KEEP ? file[i] : (uint8_t)0;
+        if (code[i] == FA_NAME_END && (uint32_t)i == scal[2]) scal[0] = dst;
+    }
+};
+struct FastaIsTerm {
+    const uint8_t *packed;
+    __device__ __forceinline__ uint32_t operator()(uint64_t j) const { return packed[j] == 0 ? 1u : 0u; }
+};
+struct FastaTermOut {
+    uint32_t *term;
+    uint64_t cap;
+    __device__ __forceinline__ void operator()(uint64_t j, uint32_t dst, uint32_t f) const
+    {
+        if (f && dst < cap) term[dst] = (uint32_t)j;
+    }
+};
+
+// which byte values occur: 256 flags as 8 words
+__global__ __launch_bounds__(kBlock) void remap_present_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                               uint32_t *__restrict__ present)
+{
+    __shared__ uint32_t seen[8];
+    if (threadIdx.x < 8) seen[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool aligned = ((uintptr_t)in & 15u) == 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q * 16 < n; q += (uint64_t)gridDim.x * kBlock) {
+        if (aligned && q * 16 + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + q * 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) // static register indices
+                    if ((b >> 5) == (uint32_t)s) mine[s] |= 1u << (b & 31u);
+            }
+        } else {
+            for (uint64_t i = q * 16; i < n && i < q * 16 + 16; ++i) {
+                const uint32_t b = in[i];
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if ((b >> 5) == (uint32_t)s) mine[s] |= 1u << (b & 31u);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (mine[s]) atomicOr(&seen[s], mine[s]);
+    __syncthreads();
+    if (threadIdx.x < 8 && seen[threadIdx.x]) atomicOr(&present[threadIdx.x], seen[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kBlock) void remap_apply_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                                             const uint8_t *__restrict__ table,
+                                                             uint8_t *__restrict__ out)
+{
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = table[threadIdx.x];
+    __syncthreads();
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q * 16 < n; q += (uint64_t)gridDim.x * kBlock) {
+        if (aligned && q * 16 + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + q * 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = (uint32_t)lut[w[k] & 0xFFu] | ((uint32_t)lut[(w[k] >> 8) & 0xFFu] << 8) |
+                       ((uint32_t)lut[(w[k] >> 16) & 0xFFu] << 16) | ((uint32_t)lut[w[k] >> 24] << 24);
+            uint4 r;
+            r.x = o[0], r.y = o[1], r.z = o[2], r.w = o[3];
+            *reinterpret_cast<uint4 *>(out + q * 16) = r;
+        } else {
+            for (uint64_t i = q * 16; i < n && i < q * 16 + 16; ++i) out[i] = lut[in[i]];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = 0; // the terminator remap() appends (remap.c:113)
+}
+
+} // namespace sx
+
+using namespace sx;
+
+extern "C" {
+
+int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uint8_t *d_packed_out,
+                      uint64_t *packed_len_out, uint32_t *d_term_out, uint64_t term_cap, uint32_t *n_records_out)
+{
+    if (!ctx || !d_packed_out || !packed_len_out || !n_records_out || (file_len && !d_file)) return SX_E_ARG;
+    if (file_len >= 0x7FFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "FASTA image must be shorter than 2^31 - 1 bytes");
+    SX_CHECK(hipSetDevice(ctx->device));
+    *packed_len_out = 0;
+    *n_records_out = 0;
+    // scratch: one code per byte (+ the virtual terminator) and four scalars
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, file_len + 1 + 256 + 64));
+    uint32_t *scal = (uint32_t *)ctx->slab[SX_SLAB_N].p; // [0] first NUL, [1] malformed, [2] first header end, [3] totals
+    uint8_t *code = (uint8_t *)ctx->slab[SX_SLAB_N].p + 256;
+    const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+    SX_CHECK(hipMemcpyAsync(scal, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t first_nul = 0xFFFFFFFFu;
+    if (file_len) {
+        uint32_t grid = sx_div_up(file_len, kBlock * 16);
+        if (grid > 4096) grid = 4096;
+        sx_launch(ctx, SX_KC_MISC, file_len, fasta_first_nul_kernel, dim3(grid), dim3(kBlock), d_file, file_len, scal);
+        SX_TRY(sx_readback(ctx, scal, 1, &first_nul));
+    }
+    const uint64_t end = first_nul < file_len ? first_nul : file_len;
+    const uint64_t span = end + 1; // with the terminating NUL of the reference's buffer
+    SX_TRY((device_scan<OpMax>(ctx, span, FastaIn{d_file, end}, FastaCode{d_file, end, code, scal + 1}, nullptr, SX_KC_MISC,
+                               span * 3)));
+    SX_TRY((device_compact(ctx, span, FastaEmit{code}, FastaWrite{d_file, code, d_packed_out, scal}, scal + 3, SX_KC_MISC, span * 3)));
+    uint32_t h[4];
+    SX_TRY(sx_readback(ctx, scal, 4, h));
+    const uint64_t packed_len = h[3];
+    *packed_len_out = packed_len;
+    uint32_t n_term = 0;
+    if (packed_len) {
+        SX_TRY((device_compact(ctx, packed_len, FastaIsTerm{d_packed_out}, FastaTermOut{d_term_out, d_term_out ? term_cap : 0},
+                               scal + 3, SX_KC_MISC, packed_len * 2)));
+        SX_TRY(sx_readback(ctx, scal + 3, 1, &n_term));
+    }
+    *n_records_out = n_term / 2;
+    // MALFORMED_FILE (fasta.c:121-124): the image ends inside a header line -- or, because the reference packs in
+    // place, the first header line had nothing to drop, so that its terminator overwrote the newline being examined
+    const bool clobbered = h[2] != 0xFFFFFFFFu && h[0] == h[2];
+    if (h[1] || clobbered) return sx_fail_msg(ctx, SX_E_MALFORMED, "FASTA image ends inside a header line");
+    return 0;
+}
+
+int sx_fasta_pack(sx_ctx *ctx, const uint8_t *file, uint64_t file_len, uint8_t *packed_out, uint64_t *packed_len_out,
+                  uint32_t *term_out, uint64_t term_cap, uint32_t *n_records_out)
+{
+    if (!ctx || !packed_out || !packed_len_out || !n_records_out || (file_len && !file)) return SX_E_ARG;
+    if (file_len >= 0x7FFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "FASTA image must be shorter than 2^31 - 1 bytes");
+    SX_CHECK(hipSetDevice(ctx->device));
+    const size_t file_b = (file_len + 256) & ~(size_t)255, term_b = (term_out ? term_cap * 4 + 255 : 0) & ~(size_t)255;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, 2 * file_b + term_b + 1024));
+    uint8_t *d_file = (uint8_t *)ctx->slab[SX_SLAB_IO].p, *d_packed = d_file + file_b;
+    uint32_t *d_term = term_out ? (uint32_t *)(d_packed + file_b) : nullptr;
+    if (file_len) SX_CHECK(hipMemcpyAsync(d_file, file, file_len, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = sx_fasta_pack_dev(ctx, d_file, file_len, d_packed, packed_len_out, d_term, term_cap, n_records_out);
+    if (rc != 0 && rc != SX_E_MALFORMED) return rc;
+    if (*packed_len_out) SX_CHECK(hipMemcpyAsync(packed_out, d_packed, *packed_len_out, hipMemcpyDeviceToHost, ctx->stream));
+    if (term_out) {
+        const uint64_t nt = 2ull * *n_records_out < term_cap ? 2ull * *n_records_out : term_cap;
+        if (nt) SX_CHECK(hipMemcpyAsync(term_out, d_term, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SX_TRY(sx_sync(ctx));
+    return rc;
+}
+
+int sx_remap_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out, int16_t *table_out,
+                 uint32_t *alphabet_size_out)
+{
+    if (!ctx || !d_out || !alphabet_size_out || (n && !d_in)) return SX_E_ARG;
+    SX_CHECK(hipSetDevice(ctx->device));
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SCAN, 1024));
+    uint32_t *present = (uint32_t *)ctx->slab[SX_SLAB_SCAN].p;
+    uint8_t *lut = (uint8_t *)(present + 64);
+    SX_CHECK(hipMemsetAsync(present, 0, 8 * sizeof(uint32_t), ctx->stream));
+    uint32_t grid = sx_div_up(n ? n : 1, kBlock * 64);
+    if (grid > 2048) grid = 2048;
+    if (n) sx_launch(ctx, SX_KC_MISC, n, remap_present_kernel, dim3(grid), dim3(kBlock), d_in, n, present);
+    uint32_t h[8];
+    SX_TRY(sx_readback(ctx, present, 8, h));
+    // remap.c:8-31: symbols in increasing order get 1, 2, ...; 0 stays the sentinel
+    uint8_t table[256];
+    int16_t t16[256];
+    uint32_t next = 1;
+    table[0] = 0;
+    t16[0] = 0;
+    for (int c = 1; c < 256; ++c) {
+        const bool seen = (h[c >> 5] >> (c & 31)) & 1u;
+        t16[c] = seen ? (int16_t)next : (int16_t)-1;
+        table[c] = seen ? (uint8_t)next : (uint8_t)0;
+        if (seen) ++next;
+    }
+    if (table_out) memcpy(table_out, t16, sizeof t16);
+    *alphabet_size_out = next;
+    if (h[0] & 1u) return sx_fail_msg(ctx, SX_E_ARG, "remap: the input holds the sentinel symbol 0");
+    if (next > 128) return sx_fail_msg(ctx, SX_E_ARG, "remap: more than 127 distinct symbols (stralg/remap.h:14-18)");
+    SX_CHECK(hipMemcpyAsync(lut, table, 256, hipMemcpyHostToDevice, ctx->stream));
+    sx_launch(ctx, SX_KC_MISC, 2 * n, remap_apply_kernel, dim3(grid), dim3(kBlock), d_in, n, (const uint8_t *)lut, d_out);
+    return sx_sync(ctx);
+}
+
+} // extern "C"

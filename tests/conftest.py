@@ -33,6 +33,37 @@ def golden():
     return golden_cases()
 
 
+def fasta_cases():
+    """name -> dict(file bytes, err, packed image bytes, records) from tests/golden/golden_fasta.npz."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_fasta.npz"))
+    cases = {}
+    for key in z.files:
+        name, field = key.rsplit("/", 1)
+        cases.setdefault(name, {})[field] = z[key]
+    return {k: dict(file=v["file"].tobytes(), err=int(v["err"][0]), packed=v["packed"].tobytes(), records=int(v["records"][0]))
+            for k, v in cases.items()}
+
+
+@pytest.fixture(scope="session")
+def golden_fasta():
+    return fasta_cases()
+
+
+def check_fasta(records_of, cases):
+    """records_of(file bytes) -> [(name, seq)] or raises an error carrying SX_E_MALFORMED (-4)"""
+    from oracle import pyoracle
+    for name, c in cases.items():
+        want = pyoracle.fasta_records_of(c["packed"], c["records"])
+        try:
+            got = records_of(c["file"])
+            assert c["err"] == 0, (name, "should be malformed")
+            assert got == want, name
+        except Exception as e:  # noqa: BLE001 -- the binding's own error type
+            if isinstance(e, AssertionError):
+                raise
+            assert c["err"] == 2 and "-4" in str(e), (name, e)
+
+
 @pytest.fixture(scope="session")
 def emu_ctx():
     """Context on the CPU execution harness build of the kernel sources (tests/emu).

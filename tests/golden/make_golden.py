@@ -131,6 +131,37 @@ def main():
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_next.npz"), **nxt)
     print(f"{len(nxt)} arrays -> golden_next.npz")
 
+    # ---- FASTA ingest: the reference's load_fasta_records on its own test data
+    # (tests/bioinf/test-data/ref.fa, malformed.fa: fasta_test.c:13-79) and on small edge cases
+    fa = {}
+    fasta_inputs = {
+        "ref/ref.fa": open(os.path.join(REF_TESTS, "bioinf", "test-data", "ref.fa"), "rb").read(),
+        "ref/malformed.fa": open(os.path.join(REF_TESTS, "bioinf", "test-data", "malformed.fa"), "rb").read(),
+        "edge/empty": b"", "edge/only-gt": b">", "edge/header-only": b">a\n", "edge/no-final-newline": b">a\nAC",
+        "edge/no-gt-first-line": b"ACGT\nAC\n", "edge/spaces-and-gt-in-header": b"> x y >z\tw\nAC GT\n",
+        "edge/gt-mid-line": b">a\nAC>b\nGT\n", "edge/crlf": b">a\r\nAC\r\nGT\r\n>b\r\nTT",
+        "edge/empty-sequences": b">a\n>b\n\n\n>c\n \t\n", "edge/nul-inside": b">a\nAC\0GT\n>b\nTT\n",
+        "edge/ends-in-header": b">a\nACGT\n>b", "edge/blank-lines": b"\n\n>a\n\nAC\n\n\nGT\n\n",
+    }
+    frng = np.random.default_rng(11)
+    letters = np.frombuffer(b">> \t\n\n\rACGTNacgt xy", dtype=np.uint8)
+    for k in range(24):
+        fasta_inputs[f"rand/{k}"] = bytes(frng.choice(letters, size=int(frng.integers(0, 200))))
+    lines = []
+    for k in range(7):  # a well-formed multi-record file with 60-column lines
+        seq = bytes(frng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(frng.integers(1, 5000))))
+        lines.append(b">chr%d some description\n" % k + b"\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + b"\n")
+    fasta_inputs["struct/seven-records"] = b"".join(lines)
+    for name, data in fasta_inputs.items():
+        err, recs = ref.fasta(data)
+        fa[name + "/file"] = np.frombuffer(data, dtype=np.uint8)
+        fa[name + "/err"] = np.array([err], dtype=np.int32)  # stralg/error.h: 0 NO_ERROR, 2 MALFORMED_FILE
+        # the packed image in file order (the iterator yields the records in reverse, fasta.c:131-134)
+        fa[name + "/packed"] = np.frombuffer(b"".join(n + b"\0" + q + b"\0" for n, q in recs[::-1]), dtype=np.uint8)
+        fa[name + "/records"] = np.array([len(recs)], dtype=np.uint32)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_fasta.npz"), **fa)
+    print(f"{len(fasta_inputs)} FASTA cases -> golden_fasta.npz")
+
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz")
     np.savez_compressed(out, **cases)
     names = sorted({k.rsplit("/", 1)[0] for k in cases})

@@ -3,6 +3,7 @@ oracle and the golden vectors.  This checks kernel logic (ballot ranking, tile
 carries, scans) where there is no GPU; the `-m gpu` tests repeat the parity checks
 on hardware through the product library."""
 import numpy as np
+import pytest
 
 import oracle
 
@@ -117,6 +118,24 @@ def test_next_rows(emu_ctx, golden):
         emu_ctx.bwt_exact_search_dev(np.ascontiguousarray(c["c"]), np.ascontiguousarray(c["o"]), c["sa"].size, c["sigma"],
                                      pats, offs, lr.shape[0], l, r)
         assert (l == lr[:, 0]).all() and (r == lr[:, 1]).all(), name
+
+
+def test_fasta_ingest_and_remap(emu_ctx, golden_fasta):
+    """FASTA packing (scan + compaction) and remap kernels against the reference's vectors"""
+    from conftest import check_fasta
+    check_fasta(emu_ctx.fasta_records, golden_fasta)
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 15, 16, 17, 4097, 70001):
+        x = rng.choice(np.frombuffer(b"ACGTNRYKM-", dtype=np.uint8), size=n).astype(np.uint8)
+        out = np.full(n + 1, 99, dtype=np.uint8)
+        sigma, table = emu_ctx.remap_dev(x if n else None, n, out)
+        want, want_sigma, want_table = oracle.remap(x) if n else (np.zeros(0, np.uint8), 1, None)
+        assert sigma == want_sigma and (out[:n] == want).all() and out[n] == 0, n
+        if n:
+            assert (table == want_table).all()
+    with pytest.raises(Exception):  # more than 127 distinct symbols (remap.h:14-18)
+        x = np.arange(1, 200, dtype=np.uint8)
+        emu_ctx.remap_dev(x, x.size, np.zeros(x.size + 1, np.uint8))
 
 
 def test_primitives(emu_ctx):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
+from oracle import pyoracle
 from stralg_amd.synth import synth
 
 pytestmark = pytest.mark.gpu
@@ -494,3 +495,111 @@ def test_wide_tables_beyond_launch_limit(gpu_ctx):
         d = o[s + 1: e + 1] - o[s: e]
         onehot = torch.nn.functional.one_hot(bw[s:e].long(), sigma).to(torch.int32)
         assert bool((d == onehot).all())
+
+
+# ---- FASTA ingest and remap ---------------------------------------
+
+def test_fasta_golden(gpu_ctx, golden_fasta):
+    from conftest import check_fasta
+    check_fasta(gpu_ctx.fasta_records, golden_fasta)
+
+
+def test_fasta_reference_named_c_api(gpu_ctx, golden_fasta, tmp_path):
+    """load_fasta_records and friends (bioinf/fasta.h) as the reference's fasta_test.c drives them"""
+    class Rec(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("seq", C.POINTER(C.c_uint8)), ("seq_len", C.c_uint32)]
+
+    class It(C.Structure):
+        _fields_ = [("rec", C.c_void_p)]
+
+    lib = gpu_ctx.lib
+    lib.load_fasta_records.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    lib.load_fasta_records.restype = C.c_void_p
+    lib.free_fasta_records.argtypes = [C.c_void_p]
+    lib.number_of_fasta_records.argtypes = [C.c_void_p]
+    lib.number_of_fasta_records.restype = C.c_uint32
+    lib.lookup_fasta_record_by_name.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Rec)]
+    lib.lookup_fasta_record_by_name.restype = C.c_bool
+    lib.init_fasta_iter.argtypes = [C.POINTER(It), C.c_void_p]
+    lib.next_fasta_record.argtypes = [C.POINTER(It), C.POINTER(Rec)]
+    lib.next_fasta_record.restype = C.c_bool
+    good = tmp_path / "ref.fa"
+    good.write_bytes(golden_fasta["ref/ref.fa"]["file"])
+    err = C.c_int(-1)
+    h = lib.load_fasta_records(str(good).encode(), C.byref(err))
+    assert h and err.value == 0 and lib.number_of_fasta_records(h) == 5  # fasta_test.c:24,53
+    it, rec, seen = It(), Rec(), []
+    lib.init_fasta_iter(C.byref(it), h)
+    while lib.next_fasta_record(C.byref(it), C.byref(rec)):
+        seen.append((rec.name, bytes(bytearray(rec.seq[i] for i in range(rec.seq_len)))))
+    want = pyoracle.fasta_records_of(golden_fasta["ref/ref.fa"]["packed"], 5)
+    assert seen == want[::-1]  # reverse file order (fasta.c:131-134; fasta-test-expected.txt starts with ref5)
+    assert lib.lookup_fasta_record_by_name(h, b"ref2", C.byref(rec)) and rec.seq_len == 111  # fasta_test.c:57-66
+    assert not lib.lookup_fasta_record_by_name(h, b"noname", C.byref(rec))
+    lib.free_fasta_records(h)
+    assert not lib.load_fasta_records(b"no such file", C.byref(err)) and err.value == 1  # CANNOT_OPEN_FILE
+    bad = tmp_path / "malformed.fa"
+    bad.write_bytes(golden_fasta["ref/malformed.fa"]["file"])
+    assert not lib.load_fasta_records(str(bad).encode(), C.byref(err)) and err.value == 2  # MALFORMED_FILE
+    assert not lib.load_fasta_records(str(bad).encode(), None)
+
+
+def test_fasta_to_tables_on_device(gpu_ctx):
+    """a FASTA image that never leaves the GPU: pack, per record remap + suffix array + BWT + C/O, each checked
+    against the oracle working from the file on the host"""
+    import torch
+    rng = np.random.default_rng(21)
+    parts, seqs = [], []
+    for k, (n, letters) in enumerate(((50_000, b"ACGT"), (1, b"A"), (200_003, b"ACGTN"), (30_000, b"ACDEFGHIKLMNPQRSTVWY"))):
+        seq = bytes(rng.choice(np.frombuffer(letters, dtype=np.uint8), size=n))
+        seqs.append(seq)
+        parts.append(b">rec%d description\n" % k + b"\n".join(seq[i:i + 60] for i in range(0, n, 60)) + b"\n")
+    data = b"".join(parts)
+    bad, packed_want, recs_want = pyoracle.fasta_pack(data)
+    assert not bad and [s for _, s in recs_want] == seqs
+    d_file = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    d_packed = torch.zeros(len(data) + 1, dtype=torch.uint8, device="cuda")
+    d_term = torch.zeros(len(data) + 2, dtype=torch.int32, device="cuda")
+    plen, nrec = gpu_ctx.fasta_pack_dev(d_file, len(data), d_packed, d_term, d_term.numel())
+    assert nrec == 4 and d_packed[:plen].cpu().numpy().tobytes() == packed_want
+    term = d_term[: 2 * nrec].cpu().numpy().view(np.uint32)
+    for r in range(nrec):
+        s0, n = int(term[2 * r]) + 1, int(term[2 * r + 1]) - int(term[2 * r]) - 1
+        assert n == len(seqs[r])
+        d_sym = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+        sigma, table = gpu_ctx.remap_dev(d_packed[s0:], n, d_sym)
+        sym_want, sigma_want, table_want = oracle.remap(np.frombuffer(seqs[r], dtype=np.uint8))
+        assert sigma == sigma_want and (table == table_want).all()
+        assert (d_sym[:n].cpu().numpy() == sym_want).all() and int(d_sym[n]) == 0
+        N = n + 1
+        sa = torch.empty(N, dtype=torch.int32, device="cuda")
+        bw = torch.empty(N, dtype=torch.uint8, device="cuda")
+        c = torch.empty(sigma, dtype=torch.int32, device="cuda")
+        o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
+        gpu_ctx.sa_bwt_build_dev(d_sym, n, sigma, sa, bw)
+        gpu_ctx.bwt_tables_from_bwt_dev(bw, N, sigma, c, o)
+        sa_want = oracle.sa_is(sym_want, sigma)
+        assert (sa.cpu().numpy().view(np.uint32) == sa_want).all(), r
+        assert (c.cpu().numpy().view(np.uint32) == oracle.c_table(sym_want, sigma)).all()
+        assert (o.cpu().numpy().view(np.uint32) == oracle.o_table(sym_want, sa_want, sigma).ravel()).all()
+
+
+def test_fasta_large_image(gpu_ctx):
+    """64 MiB of sequence in 60-column lines: the packed image against the oracle's"""
+    import torch
+    rng = np.random.default_rng(4)
+    parts = []
+    for k in range(3):
+        n = (20 << 20) + 12345 * k
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+        full = n // 60
+        lines = np.concatenate([seq[: full * 60].reshape(full, 60), np.full((full, 1), ord("\n"), dtype=np.uint8)], axis=1)
+        parts.append(b">chr%d\n" % k + lines.tobytes() + seq[full * 60:].tobytes() + b"\n")
+    data = b"".join(parts)
+    bad, packed_want, recs = pyoracle.fasta_pack(data)
+    assert not bad and len(recs) == 3
+    d_file = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    d_packed = torch.zeros(len(data) + 1, dtype=torch.uint8, device="cuda")
+    plen, nrec = gpu_ctx.fasta_pack_dev(d_file, len(data), d_packed)
+    assert nrec == 3 and plen == len(packed_want)
+    assert d_packed[:plen].cpu().numpy().tobytes() == packed_want

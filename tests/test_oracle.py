@@ -65,6 +65,17 @@ def test_next_rows_golden(golden):
     assert n_lcp >= 8 and n_search > 200
 
 
+def test_fasta_packing_golden(golden_fasta):
+    """oracle_fasta_pack against the reference's load_fasta_records on its own test files and edge cases"""
+    from oracle import pyoracle
+    for name, c in golden_fasta.items():
+        bad, packed, recs = pyoracle.fasta_pack(c["file"])
+        assert bad == (c["err"] == 2), name
+        if not bad:
+            assert packed == c["packed"] and len(recs) == c["records"], name
+    assert golden_fasta["ref/ref.fa"]["records"] == 5 and golden_fasta["ref/malformed.fa"]["err"] == 2  # fasta_test.c:53,76
+
+
 def test_naive_agrees():
     rng = np.random.default_rng(5)
     for sigma in (2, 4, 17):
@@ -89,6 +100,22 @@ def test_synth_streams_agree():
 
 
 @pytest.mark.skipif(not oracle.have_ref(), reason="reference library not built here")
+def test_fasta_against_reference_build():
+    from oracle import pyoracle
+    if not pyoracle.have_ref():
+        pytest.skip("oracle/_ref not built (no reference checkout)")
+    ref = pyoracle._Ref()
+    rng = np.random.default_rng(3)
+    letters = np.frombuffer(b">> \t\n\n\rACGTNacgt xy", dtype=np.uint8)
+    for k in range(400):
+        data = bytes(rng.choice(letters, size=int(rng.integers(0, 120))))
+        err, recs = ref.fasta(data)
+        bad, _, mine = pyoracle.fasta_pack(data)
+        assert bad == (err == 2), data
+        if not bad:
+            assert recs[::-1] == mine, data
+
+
 def test_against_reference_build():
     ref = oracle.ref()
     rng = np.random.default_rng(11)
