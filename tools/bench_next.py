@@ -29,3 +29,24 @@ for _ in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.bwt_exact_search_dev(c, o, N, sigma, pats, offs, q, l, r); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 hits = int(((r - l) > 0).sum())
 print(f"exact search, {q} patterns x {m} symbols over 2^{log2n}: {dt*1e3:.1f} ms = {q/dt/1e6:.1f} Mpatterns/s ({q*m*2/dt/1e9:.2f} G table look-ups/s), {hits} found")
+# FASTA ingest + remap on the device: a 1 GiB image (8 records, 60-column lines) from raw bytes to remapped symbols
+del o, pats, idx
+rng = np.random.default_rng(1)
+rec_n = (1 << 27) - 4096
+seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=rec_n)
+full = rec_n // 60
+body = np.concatenate([seq[: full * 60].reshape(full, 60), np.full((full, 1), 10, dtype=np.uint8)], axis=1).tobytes() + seq[full * 60:].tobytes() + b"\n"
+data = b"".join(b">chr%d\n" % k + body for k in range(8))
+d_file = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+d_packed = torch.empty(len(data) + 1, dtype=torch.uint8, device="cuda")
+d_term = torch.empty(64, dtype=torch.int32, device="cuda")
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); plen, nrec = ctx.fasta_pack_dev(d_file, len(data), d_packed, d_term, 64); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+term = d_term[: 2 * nrec].cpu().numpy()
+s0 = int(term[0]) + 1; rn = int(term[1]) - int(term[0]) - 1
+d_sym = torch.empty(rn + 1, dtype=torch.uint8, device="cuda")
+for _ in range(2):
+    torch.cuda.synchronize(); t1 = time.perf_counter(); sg, _ = ctx.remap_dev(d_packed[s0:], rn, d_sym); torch.cuda.synchronize(); dr = time.perf_counter() - t1
+print(f"FASTA pack, {len(data)/2**30:.2f} GiB image, {nrec} records: {dt*1e3:.1f} ms = {len(data)/dt/1e9:.0f} GB/s of file; remap of one {rn/2**20:.0f} Mi record (sigma {sg}): {dr*1e3:.2f} ms")
+t0 = time.perf_counter(); oracle.pyoracle.fasta_pack(data[: 1 << 26]); dt = time.perf_counter() - t0
+print(f"oracle fasta packing on the first 64 MiB: {dt*1e3:.0f} ms = {(1<<26)/dt/1e9:.2f} GB/s (1 core)")
