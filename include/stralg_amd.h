@@ -139,6 +139,17 @@ int sx_bwt_exact_search_dev(sx_ctx *ctx, const uint32_t *d_c_table, const uint32
                             uint32_t sigma, const uint8_t *d_patterns, const uint32_t *d_offsets, uint32_t count,
                             uint32_t *d_l_out, uint32_t *d_r_out);
 
+/* ---- streaming download (serialisation without a host copy of the tables) ---- */
+/* sink(user, section, data, bytes): consecutive chunks of one section after the other; data is only valid
+ * during the call; a non-zero return aborts the build. */
+typedef int (*sx_sink_fn)(void *user, int section, const void *data, size_t bytes);
+enum { SX_SECTION_SA = 0, SX_SECTION_C = 1, SX_SECTION_O = 2 };
+/* sx_build_tables, but the suffix array (when want_sa), the C table and the O table leave the device through
+ * `sink` in 32 MiB chunks from pinned staging memory, in this order (the order of stralg/serialise.c:7-18 around
+ * the remap table); the copy of a chunk overlaps the sink's work on the previous one. */
+int sx_build_tables_stream(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma, int want_sa, sx_sink_fn sink,
+                           void *user);
+
 /* ---- FASTA ingest and remap on the device ---------------- */
 /* bioinf/fasta.c:92-135 load_fasta_records' packing of a file image in device memory into
  * "name\0sequence\0name\0sequence\0..." (file order; the reference's record list is the reverse).

@@ -18,6 +18,7 @@
 #include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -108,6 +109,23 @@ void init_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_tab
 bool next_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_exact_match *match);
 void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter);
 
+/* ---- index serialisation: the reference's file format (stralg/serialise.h:8-23, string_utils.h,
+ * suffix_array.h, remap.h, bwt.h write_ / read_ pairs) ------------------------------------------- */
+void write_string_len(FILE *f, const uint8_t *str, uint32_t len); /* string_utils.c:48-52 */
+void write_string(FILE *f, const uint8_t *str);                   /* string_utils.c:62-66: length includes the NUL */
+uint8_t *read_string_len(FILE *f, uint32_t *len);                 /* string_utils.c:73-82 */
+uint8_t *read_string(FILE *f);
+void write_suffix_array(FILE *f, const struct suffix_array *sa);  /* suffix_array.c:238-241 */
+struct suffix_array *read_suffix_array(FILE *f, uint8_t *string); /* suffix_array.c:250-258 */
+void write_remap_table(FILE *f, const struct remap_table *table); /* remap.c:168-173 */
+struct remap_table *read_remap_table(FILE *f);                    /* remap.c:184-191 */
+void write_bwt_table(FILE *f, const struct bwt_table *bwt_table); /* bwt.c:425-441 */
+struct bwt_table *read_bwt_table(FILE *f, struct suffix_array *sa, struct remap_table *remap_table); /* bwt.c:453-492 */
+void write_complete_bwt_info(FILE *f, const struct bwt_table *bwt_table); /* serialise.c:7-18 */
+void write_complete_bwt_info_fname(const char *fname, const struct bwt_table *bwt_table);
+struct bwt_table *read_complete_bwt_info(FILE *f);                /* serialise.c:29-39 */
+struct bwt_table *read_complete_bwt_info_fname(const char *fname);
+
 /* ---- FASTA records (bioinf/fasta.h:10-49, stralg/error.h:7-21) --------------------------------
  * load_fasta_records reads the file and packs it on the GPU (sx_fasta_pack: the reference's in-place
  * packing loop as scan + compaction); names and sequences point into one buffer owned by the records
@@ -151,6 +169,10 @@ void stralg_amd_release(void);
  * one host thread per device; out[k] receives build_complete_table(strings[k], ...). */
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out);
+/* build_complete_table(string, include_reverse) followed by write_complete_bwt_info(f, table), byte for byte,
+ * but the suffix array and the O tables stream from the GPU into the file in 32 MiB chunks: no host copy of
+ * the tables (20 GiB per GiB of DNA).  Returns 0, or a negative / HIP error code. */
+int stralg_amd_write_complete_bwt_info_stream(FILE *f, const uint8_t *string, bool include_reverse);
 /* The loop of bwt_readmapper.c:54-62 over a whole FASTA file: out[k] = build_complete_table of the k-th
  * record in ITERATION order (reverse file order), records farmed over the devices; returns the number of
  * records (out needs number_of_fasta_records(records) slots), or a negative value on failure. */

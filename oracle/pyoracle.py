@@ -322,6 +322,20 @@ class _Ref:
         lib.free_fasta_records(h)
         return err.value, out
 
+    def serialise(self, raw, include_reverse=True):
+        """bytes of write_complete_bwt_info(build_complete_table(raw, include_reverse)) (stralg/serialise.c:7-18)"""
+        import tempfile
+        lib = self.lib
+        lib.write_complete_bwt_info_fname.argtypes = [C.c_char_p, C.POINTER(_RefBwt)]
+        lib.write_complete_bwt_info_fname.restype = None
+        buf, _ = _text(raw)
+        t = lib.build_complete_table(_u8(buf), include_reverse)
+        with tempfile.NamedTemporaryFile(suffix=".bwt") as f:
+            lib.write_complete_bwt_info_fname(f.name.encode(), t)
+            data = open(f.name, "rb").read()
+        lib.completely_free_bwt_table(t)
+        return data
+
     def remap_string(self, raw):
         buf, n = _text(raw)
         out = np.zeros(n + 1, dtype=np.uint8)

@@ -62,6 +62,7 @@ def load(path=None):
         "sx_sa_lcp_dev": (C.c_int, [vp, u8p, u32p, C.c_uint64, u32p, u32p]),
         "sx_sa_inverse_lcp": (C.c_int, [vp, u8p, u32p, C.c_uint64, u32p, u32p]),
         "sx_bwt_exact_search_dev": (C.c_int, [vp, u32p, u32p, C.c_uint64, C.c_uint32, u8p, u32p, C.c_uint32, u32p, u32p]),
+        "sx_build_tables_stream": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
         "sx_fasta_pack_dev": (C.c_int, [vp, u8p, C.c_uint64, u8p, C.POINTER(C.c_uint64), u32p, C.c_uint64,
                                         C.POINTER(C.c_uint32)]),
         "sx_fasta_pack": (C.c_int, [vp, u8p, C.c_uint64, u8p, C.POINTER(C.c_uint64), u32p, C.c_uint64,
@@ -95,6 +96,6 @@ def load(path=None):
 EXPORTS = ["sx_device_count", "sx_ctx_create", "sx_ctx_destroy", "sx_last_error", "sx_ctx_trim", "sx_ctx_set_flag",
            "sx_sa_build", "sx_sa_build_dev", "sx_sa_bwt_build_dev", "sx_bwt_tables", "sx_bwt_tables_dev",
            "sx_bwt_tables_from_bwt_dev", "sx_build_tables", "sx_sa_inverse_dev", "sx_sa_lcp_dev", "sx_sa_inverse_lcp",
-           "sx_bwt_exact_search_dev", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_profile_enable",
+           "sx_bwt_exact_search_dev", "sx_build_tables_stream", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_profile_enable",
            "sx_profile_reset", "sx_profile_read", "sx_kernel_class_name", "sx_last_stats",
            "sx_synth_dev", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]

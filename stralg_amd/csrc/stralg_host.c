@@ -350,6 +350,171 @@ bool next_bwt_exact_match_iter(struct bwt_exact_match_iter *iter, struct bwt_exa
 
 void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter) { (void)iter; }
 
+/* ---- index serialisation (stralg/serialise.c:7-39, string_utils.c:48-96, suffix_array.c:238-258,
+ *      remap.c:168-187, bwt.c:425-487).  The byte format is the reference's; lengths that it
+ *      computes in 32 bits (o_table_length) are computed in size_t. ------------------------------ */
+
+void write_string_len(FILE *f, const uint8_t *str, uint32_t len)
+{
+    fwrite(&len, sizeof len, 1, f);
+    fwrite(str, 1, len, f);
+}
+
+void write_string(FILE *f, const uint8_t *str) { write_string_len(f, str, (uint32_t)strlen((const char *)str) + 1); }
+
+uint8_t *read_string_len(FILE *f, uint32_t *len)
+{
+    uint32_t str_len = 0;
+    if (fread(&str_len, sizeof str_len, 1, f) != 1) str_len = 0;
+    *len = str_len;
+    uint8_t *str = malloc((size_t)str_len + 1);
+    if (str_len && fread(str, 1, str_len, f) != str_len) memset(str, 0, str_len);
+    str[str_len] = 0;
+    return str;
+}
+
+uint8_t *read_string(FILE *f)
+{
+    uint32_t dummy;
+    return read_string_len(f, &dummy);
+}
+
+void write_suffix_array(FILE *f, const struct suffix_array *sa) { fwrite(sa->array, sizeof *sa->array, sa->length, f); }
+
+struct suffix_array *read_suffix_array(FILE *f, uint8_t *string)
+{
+    struct suffix_array *sa = allocate_sa_(string);
+    if (fread(sa->array, sizeof *sa->array, sa->length, f) != sa->length) memset(sa->array, 0, sizeof *sa->array * sa->length);
+    return sa;
+}
+
+void write_remap_table(FILE *f, const struct remap_table *table) { fwrite(table, sizeof *table, 1, f); }
+
+struct remap_table *read_remap_table(FILE *f)
+{
+    struct remap_table *table = malloc(sizeof *table);
+    if (fread(table, sizeof *table, 1, f) != 1) memset(table, 0, sizeof *table);
+    return table;
+}
+
+void write_bwt_table(FILE *f, const struct bwt_table *bwt_table)
+{
+    const size_t sigma = bwt_table->remap_table->alphabet_size;
+    const size_t o_words = sigma * ((size_t)bwt_table->sa->length + 1);
+    fwrite(bwt_table->c_table, sizeof *bwt_table->c_table, sigma, f);
+    fwrite(bwt_table->o_table, sizeof *bwt_table->o_table, o_words, f);
+    const bool has_ro_table = bwt_table->ro_table != NULL;
+    fwrite(&has_ro_table, sizeof has_ro_table, 1, f);
+    if (has_ro_table) fwrite(bwt_table->ro_table, sizeof *bwt_table->ro_table, o_words, f);
+}
+
+struct bwt_table *read_bwt_table(FILE *f, struct suffix_array *sa, struct remap_table *remap_table)
+{
+    struct bwt_table *table = malloc(sizeof *table);
+    table->remap_table = remap_table;
+    table->sa = sa;
+    const size_t sigma = remap_table->alphabet_size, rows = (size_t)sa->length + 1, o_words = sigma * rows;
+    table->c_table = malloc(sigma * sizeof *table->c_table);
+    table->o_table = malloc(o_words * sizeof *table->o_table);
+    bool ok = fread(table->c_table, sizeof *table->c_table, sigma, f) == sigma;
+    ok = ok && fread(table->o_table, sizeof *table->o_table, o_words, f) == o_words;
+    table->o_indices = row_pointers(table->o_table, rows, (uint32_t)sigma);
+    table->ro_table = NULL;
+    table->ro_indices = NULL;
+    bool has_ro_table = false;
+    if (!ok || fread(&has_ro_table, sizeof has_ro_table, 1, f) != 1) has_ro_table = false;
+    if (has_ro_table) {
+        table->ro_table = malloc(o_words * sizeof *table->ro_table);
+        if (fread(table->ro_table, sizeof *table->ro_table, o_words, f) != o_words) memset(table->ro_table, 0, o_words * 4);
+        table->ro_indices = row_pointers(table->ro_table, rows, (uint32_t)sigma);
+    }
+    return table;
+}
+
+void write_complete_bwt_info(FILE *f, const struct bwt_table *bwt_table)
+{
+    const struct suffix_array *sa = bwt_table->sa;
+    write_string_len(f, sa->string, sa->length - 1);
+    write_suffix_array(f, sa);
+    write_remap_table(f, bwt_table->remap_table);
+    write_bwt_table(f, bwt_table);
+}
+
+void write_complete_bwt_info_fname(const char *fname, const struct bwt_table *bwt_table)
+{
+    FILE *f = fopen(fname, "wb");
+    write_complete_bwt_info(f, bwt_table);
+    fclose(f);
+}
+
+struct bwt_table *read_complete_bwt_info(FILE *f)
+{
+    uint32_t str_len;
+    uint8_t *str = read_string_len(f, &str_len);
+    struct suffix_array *sa = read_suffix_array(f, str);
+    struct remap_table *remap_table = read_remap_table(f);
+    return read_bwt_table(f, sa, remap_table);
+}
+
+struct bwt_table *read_complete_bwt_info_fname(const char *fname)
+{
+    FILE *f = fopen(fname, "rb");
+    struct bwt_table *res = read_complete_bwt_info(f);
+    fclose(f);
+    return res;
+}
+
+/* build_complete_table + write_complete_bwt_info without the tables ever existing on the host: the suffix
+ * array and the O tables stream from the GPU into the file in 32 MiB chunks (sx_build_tables_stream). */
+struct stream_sink {
+    FILE *f;
+    const struct remap_table *remap_table; /* written between the suffix array and the C table; NULL: reverse pass */
+    bool remap_written, failed;
+};
+
+static int stream_to_file(void *user, int section, const void *data, size_t bytes)
+{
+    struct stream_sink *s = user;
+    if (!s->remap_table && section != SX_SECTION_O) return 0; /* the reverse pass contributes its O table only */
+    if (s->remap_table && section != SX_SECTION_SA && !s->remap_written) {
+        write_remap_table(s->f, s->remap_table);
+        s->remap_written = true;
+    }
+    if (fwrite(data, 1, bytes, s->f) != bytes) s->failed = true;
+    return s->failed ? -1 : 0;
+}
+
+int stralg_amd_write_complete_bwt_info_stream(FILE *f, const uint8_t *string, bool include_reverse)
+{
+    const size_t n = strlen((const char *)string);
+    struct remap_table *remap_table = alloc_remap_table(string);
+    if (remap_table->alphabet_size > 128) {
+        free_remap_table(remap_table);
+        return -1;
+    }
+    uint8_t *remapped = malloc(n + 1);
+    remap(remapped, string, remap_table);
+    write_string_len(f, remapped, (uint32_t)n);
+    sx_ctx *ctx = thread_ctx();
+    struct stream_sink sink = {f, remap_table, false, false};
+    int rc = sx_build_tables_stream(ctx, remapped, n, remap_table->alphabet_size, 1, stream_to_file, &sink);
+    if (rc == 0) {
+        const bool has_ro_table = include_reverse;
+        fwrite(&has_ro_table, sizeof has_ro_table, 1, f);
+        if (include_reverse) {
+            uint8_t *rev = malloc(n + 1);
+            for (size_t i = 0; i < n; ++i) rev[i] = remapped[n - 1 - i];
+            rev[n] = 0;
+            struct stream_sink rsink = {f, NULL, false, false};
+            rc = sx_build_tables_stream(ctx, rev, n, remap_table->alphabet_size, 0, stream_to_file, &rsink);
+            free(rev);
+        }
+    }
+    free(remapped);
+    free_remap_table(remap_table);
+    return rc;
+}
+
 /* ---- FASTA records (bioinf/fasta.c:92-222) ------------------------------------------------ */
 
 struct fasta_record_impl {

@@ -248,6 +248,65 @@ int sx_build_tables(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma
     return sx_sync(ctx);
 }
 
+// device -> sink in chunks through two pinned staging buffers: the copy of chunk k+1 runs while the sink
+// (typically fwrite) consumes chunk k; nothing of the array's size exists on the host
+static int stream_out(sx_ctx *ctx, int section, const void *d_src, size_t bytes, sx_sink_fn sink, void *user)
+{
+    constexpr size_t kChunk = (size_t)32 << 20;
+    if (!ctx->h_stage[0]) {
+        for (int b = 0; b < 2; ++b)
+            if (hipHostMalloc((void **)&ctx->h_stage[b], kChunk, hipHostMallocDefault) != hipSuccess)
+                return sx_fail_msg(ctx, SX_E_NOMEM, "pinned staging buffers");
+    }
+    const char *src = (const char *)d_src;
+    size_t off = 0, pending = 0;
+    int cur = 0;
+    if (bytes) {
+        pending = bytes < kChunk ? bytes : kChunk;
+        SX_CHECK(hipMemcpyAsync(ctx->h_stage[0], src, pending, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    while (pending) {
+        SX_CHECK(hipStreamSynchronize(ctx->stream));
+        const size_t have = pending;
+        off += have;
+        const size_t next = bytes - off < kChunk ? bytes - off : kChunk;
+        if (next) SX_CHECK(hipMemcpyAsync(ctx->h_stage[cur ^ 1], src + off, next, hipMemcpyDeviceToHost, ctx->stream));
+        if (sink(user, section, ctx->h_stage[cur], have) != 0) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return sx_fail_msg(ctx, SX_E_ARG, "the sink refused a chunk");
+        }
+        pending = next;
+        cur ^= 1;
+    }
+    return 0;
+}
+
+int sx_build_tables_stream(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma, int want_sa, sx_sink_fn sink,
+                           void *user)
+{
+    if (!ctx || (n && !text) || !sink) return SX_E_ARG;
+    if (n > 0xFFFFFFFEull) return sx_fail_msg(ctx, SX_E_ARG, "n must be at most 2^32 - 2");
+    if (sigma < 1 || sigma > 128) return sx_fail_msg(ctx, SX_E_ARG, "sigma must be in [1, 128] for the O table");
+    SX_CHECK(hipSetDevice(ctx->device));
+    const uint64_t N = n + 1;
+    const size_t text_b = (n + 255) & ~(size_t)255, sa_b = (N * 4 + 255) & ~(size_t)255, bwt_b = (N + 255) & ~(size_t)255;
+    const size_t o_bytes = (N + 1) * (size_t)sigma * 4;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, text_b + sa_b + bwt_b + ((o_bytes + 255) & ~(size_t)255) + 4096));
+    char *base = (char *)ctx->slab[SX_SLAB_IO].p;
+    uint8_t *d_text = (uint8_t *)base;
+    uint32_t *d_sa = (uint32_t *)(base + text_b + 256);
+    uint8_t *d_bwt = (uint8_t *)(base + text_b + 256 + sa_b);
+    uint32_t *d_c = (uint32_t *)(base + text_b + 256 + sa_b + bwt_b);
+    uint32_t *d_o = (uint32_t *)(base + text_b + 256 + sa_b + bwt_b + 1024);
+    if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
+    SX_TRY(sx_sa_build_impl(ctx, d_text, n, sigma, d_sa, d_bwt));
+    SX_TRY(sx_tables_from_bwt_impl(ctx, d_bwt, N, sigma, d_c, d_o));
+    if (want_sa) SX_TRY(stream_out(ctx, SX_SECTION_SA, d_sa, N * sizeof(uint32_t), sink, user));
+    SX_TRY(stream_out(ctx, SX_SECTION_C, d_c, (size_t)sigma * 4, sink, user));
+    SX_TRY(stream_out(ctx, SX_SECTION_O, d_o, o_bytes, sink, user));
+    return sx_sync(ctx);
+}
+
 int sx_synth_dev(sx_ctx *ctx, uint8_t *d_out, uint64_t n, uint32_t sigma, uint64_t seed)
 {
     if (!ctx || sigma < 2 || sigma > 256) return SX_E_ARG;

@@ -68,6 +68,7 @@ struct sx_ctx {
     char err[512] = {0};
     sx_slab slab[SX_NSLABS];
     uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB)
+    char *h_stage[2] = {nullptr, nullptr}; // pinned staging of the streaming downloads (allocated on first use)
     // profiling
     uint32_t chain_epoch = 0; // look-back status epoch (24 bits), see sx_device.hpp
     int64_t chain_max_override = -1; // SX_FLAG_CHAIN_MAX_ENTRIES; -1 = choose by alphabet size

@@ -187,6 +187,8 @@ void sx_ctx_destroy(sx_ctx *ctx)
         (void)hipEventDestroy(ep.b);
     }
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (char *b : ctx->h_stage)
+        if (b) (void)hipHostFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

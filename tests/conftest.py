@@ -38,10 +38,56 @@ def fasta_cases():
     z = np.load(os.path.join(ROOT, "tests", "golden", "golden_fasta.npz"))
     cases = {}
     for key in z.files:
+        if key.startswith("serial/"):
+            continue
         name, field = key.rsplit("/", 1)
         cases.setdefault(name, {})[field] = z[key]
     return {k: dict(file=v["file"].tobytes(), err=int(v["err"][0]), packed=v["packed"].tobytes(), records=int(v["records"][0]))
             for k, v in cases.items()}
+
+
+def serial_cases():
+    """name -> dict(raw, with_reverse, forward_only): the reference's write_complete_bwt_info byte streams"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_fasta.npz"))
+    cases = {}
+    for key in z.files:
+        if key.startswith("serial/"):
+            _, name, field = key.split("/")
+            cases.setdefault(name, {})[field] = z[key].tobytes()
+    return cases
+
+
+def check_serialisation(lib, cases, tmp_path):
+    """the library's build_complete_table + write_complete_bwt_info, its streaming writer, and read-back"""
+    import ctypes as C
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
+    lib.build_complete_table.restype = C.c_void_p
+    lib.write_complete_bwt_info_fname.argtypes = [C.c_char_p, C.c_void_p]
+    lib.write_complete_bwt_info_fname.restype = None
+    lib.read_complete_bwt_info_fname.argtypes = [C.c_char_p]
+    lib.read_complete_bwt_info_fname.restype = C.c_void_p
+    lib.completely_free_bwt_table.argtypes = [C.c_void_p]
+    lib.completely_free_bwt_table.restype = None
+    lib.stralg_amd_write_complete_bwt_info_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    for name, c in cases.items():
+        for rev, want in ((True, c["with_reverse"]), (False, c["forward_only"])):
+            a, b, d = (str(tmp_path / f"{name}-{int(rev)}-{k}").encode() for k in "abd")
+            t = lib.build_complete_table(c["raw"], rev)
+            lib.write_complete_bwt_info_fname(a, t)
+            lib.completely_free_bwt_table(t)
+            assert open(a, "rb").read() == want, (name, rev, "write_complete_bwt_info")
+            f = libc.fopen(b, b"wb")
+            assert lib.stralg_amd_write_complete_bwt_info_stream(f, c["raw"], rev) == 0
+            libc.fclose(f)
+            assert open(b, "rb").read() == want, (name, rev, "streaming writer")
+            t = lib.read_complete_bwt_info_fname(a)  # and back: read, write again
+            lib.write_complete_bwt_info_fname(d, t)
+            lib.completely_free_bwt_table(t)
+            assert open(d, "rb").read() == want, (name, rev, "read + write")
 
 
 @pytest.fixture(scope="session")

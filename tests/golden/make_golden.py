@@ -159,6 +159,12 @@ def main():
         # the packed image in file order (the iterator yields the records in reverse, fasta.c:131-134)
         fa[name + "/packed"] = np.frombuffer(b"".join(n + b"\0" + q + b"\0" for n, q in recs[::-1]), dtype=np.uint8)
         fa[name + "/records"] = np.array([len(recs)], dtype=np.uint32)
+    # ---- index serialisation (section 8f row 1): the reference's write_complete_bwt_info byte stream
+    for name in ("ref/mississippi", "ref/serialise", "ref/fasta0", "struct/periodic"):
+        raw = bytes(cases[name + "/raw"])
+        fa["serial/" + name.replace("/", "-") + "/raw"] = np.frombuffer(raw, dtype=np.uint8)
+        fa["serial/" + name.replace("/", "-") + "/with_reverse"] = np.frombuffer(ref.serialise(raw, True), dtype=np.uint8)
+        fa["serial/" + name.replace("/", "-") + "/forward_only"] = np.frombuffer(ref.serialise(raw, False), dtype=np.uint8)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_fasta.npz"), **fa)
     print(f"{len(fasta_inputs)} FASTA cases -> golden_fasta.npz")
 

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"typedef[^;]*;", "", text)  # function-pointer types are not symbols
     return sorted(set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text)))
 
 

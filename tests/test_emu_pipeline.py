@@ -138,6 +138,12 @@ def test_fasta_ingest_and_remap(emu_ctx, golden_fasta):
         emu_ctx.remap_dev(x, x.size, np.zeros(x.size + 1, np.uint8))
 
 
+def test_serialisation_bytes(emu_ctx, tmp_path):
+    """write_complete_bwt_info, the streaming writer and read-back against the reference's byte streams"""
+    from conftest import check_serialisation, serial_cases
+    check_serialisation(emu_ctx.lib, serial_cases(), tmp_path)
+
+
 def test_primitives(emu_ctx):
     rng = np.random.default_rng(1)
     n = 5000

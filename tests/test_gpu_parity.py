@@ -603,3 +603,37 @@ def test_fasta_large_image(gpu_ctx):
     plen, nrec = gpu_ctx.fasta_pack_dev(d_file, len(data), d_packed)
     assert nrec == 3 and plen == len(packed_want)
     assert d_packed[:plen].cpu().numpy().tobytes() == packed_want
+
+
+def test_serialisation_bytes(gpu_ctx, tmp_path):
+    """row 1 of the next scope: the reference's index file format, written from host tables and streamed from
+    the device, byte for byte (tests/golden/golden_fasta.npz serial/*, made by the reference's own writer)"""
+    from conftest import check_serialisation, serial_cases
+    check_serialisation(gpu_ctx.lib, serial_cases(), tmp_path)
+
+
+def test_streamed_index_large(gpu_ctx, tmp_path):
+    """64 Mi symbols: the streamed file (several 32 MiB chunks per section) equals the file written from host tables"""
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    lib = gpu_ctx.lib
+    lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
+    lib.build_complete_table.restype = C.c_void_p
+    lib.write_complete_bwt_info_fname.argtypes = [C.c_char_p, C.c_void_p]
+    lib.write_complete_bwt_info_fname.restype = None
+    lib.completely_free_bwt_table.argtypes = [C.c_void_p]
+    lib.completely_free_bwt_table.restype = None
+    lib.stralg_amd_write_complete_bwt_info_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    raw = np.frombuffer(b"ACGT", dtype=np.uint8)[synth(1 << 26, 5, 3) - 1].tobytes()
+    a, b = str(tmp_path / "host.bwt").encode(), str(tmp_path / "stream.bwt").encode()
+    t = lib.build_complete_table(raw, False)
+    lib.write_complete_bwt_info_fname(a, t)
+    lib.completely_free_bwt_table(t)
+    f = libc.fopen(b, b"wb")
+    assert lib.stralg_amd_write_complete_bwt_info_stream(f, raw, False) == 0
+    libc.fclose(f)
+    import filecmp
+    assert os.path.getsize(a) == 4 + (1 << 26) + 4 * ((1 << 26) + 1) + 388 + 4 * 5 + 4 * 5 * ((1 << 26) + 2) + 1
+    assert filecmp.cmp(a, b, shallow=False)
