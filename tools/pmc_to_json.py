@@ -31,7 +31,9 @@ def klass(kernel):
 
 def collect(out, sub, counter):
     agg = defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
+    # gpurun merges every call's files into the same local directory: only the latest run counts
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
