@@ -20,7 +20,6 @@
 
 namespace sx {
 
-constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void load_chunk(const uint8_t *__restrict__ T, uint64_t p0, uint32_t (&c)[17])
 {
@@ -38,6 +37,14 @@ __device__ __forceinline__ void decided_masks(const uint32_t (&c)[17], uint64_t 
 {
     dmask = 0;
     vmask = 0;
+    if (p0 + 16 <= n) { // everywhere but at the very end of the text: no position needs the 64-bit bound checks
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dmask |= (c[i] != c[i + 1] ? 1u : 0u) << i;
+            vmask |= (c[i] < c[i + 1] ? 1u : 0u) << i;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const uint64_t pos = p0 + i;
@@ -55,22 +62,28 @@ __device__ __forceinline__ void decided_masks(const uint32_t (&c)[17], uint64_t 
 }
 
 // ---- pass 1: type of each tile's first position, if the tile decides it -------
-__global__ __launch_bounds__(kBlock) void cls_first_kernel(const uint8_t *__restrict__ T, uint64_t n,
-                                                           uint8_t *__restrict__ tile_first)
+// One wave per tile, 1024 positions a step: almost every tile decides in its first few symbols, so the wave
+// stops after the first step and three quarters of the text are not read by this pass.
+__global__ __launch_bounds__(kWave) void cls_first_kernel(const uint8_t *__restrict__ T, uint64_t n,
+                                                          uint8_t *__restrict__ tile_first)
 {
-    __shared__ uint32_t best;
-    if (threadIdx.x == 0) best = kNone;
-    __syncthreads();
-    const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)threadIdx.x * kClsPerThread;
-    uint32_t c[17], dmask, vmask;
-    load_chunk(T, p0, c);
-    decided_masks(c, p0, n, dmask, vmask);
-    if (dmask) {
-        const int i = __ffs(dmask) - 1;
-        atomicMin(&best, ((threadIdx.x * kClsPerThread + (uint32_t)i) << 1) | ((vmask >> i) & 1u));
+    const int lane = lane_id();
+    for (uint32_t seg = 0; seg < (uint32_t)kClsTile / (kWave * kClsPerThread); ++seg) {
+        const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)seg * (kWave * kClsPerThread) +
+                            (uint64_t)lane * kClsPerThread;
+        uint32_t c[17], dmask, vmask;
+        load_chunk(T, p0, c);
+        decided_masks(c, p0, n, dmask, vmask);
+        const uint64_t has = __ballot(dmask != 0 ? 1 : 0);
+        if (has) { // uniform
+            const int first = __ffsll((unsigned long long)has) - 1;
+            const uint32_t mine = dmask ? (vmask >> (__ffs(dmask) - 1)) & 1u : 0u;
+            const uint32_t val = __shfl(mine, first, kWave);
+            if (lane == 0) tile_first[blockIdx.x] = (uint8_t)val;
+            return;
+        }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) tile_first[blockIdx.x] = best == kNone ? (uint8_t)2 : (uint8_t)(best & 1u);
+    if (lane == 0) tile_first[blockIdx.x] = (uint8_t)2;
 }
 
 // ---- pass 2: tiles made of one symbol whose run continues take the type of the
@@ -388,7 +401,7 @@ int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_t
     uint32_t *tile_lms = ti.tile_u32, *tile_last = ti.tile_u32 + ti.ntiles;
     SX_CHECK(hipMemsetAsync(ti.d_hist, 0, 3 * 256 * sizeof(uint32_t), ctx->stream));
     const dim3 grid(ti.ntiles), block(kBlock);
-    sx_launch(ctx, SX_KC_CLASSIFY, ti.N, cls_first_kernel, grid, block, T, n, ti.tile_first);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N / 4, cls_first_kernel, grid, dim3(kWave), T, n, ti.tile_first);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.ntiles, cls_resolve_kernel, dim3(1), block, ti.tile_first, ti.ntiles);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8, cls_types_kernel, grid, block, T, n,
               (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms, tile_last, ti.d_hist);
