@@ -121,7 +121,8 @@ __global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restric
 // (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
 __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
-    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs)
+    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
+    uint32_t ntiles)
 {
     __shared__ uint32_t wcount[kRW][256]; // per-wave digit counters, then wave bases
     __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
@@ -130,11 +131,17 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
 
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint32_t first_out = t < 256 ? offs[(uint64_t)blockIdx.x * 256 + t] : 0u; // asked for now, needed after the ranking
+    // Workgroups are dealt round robin to the 8 XCDs, each with its own L2.  Tiles that follow each other write
+    // runs that follow each other (per digit), so XCD x takes the x-th eighth of the tiles, in order: the two
+    // halves of a cache line shared by neighbouring runs then meet in one L2 instead of leaving two as partial lines.
+    const uint32_t per_xcd = (ntiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return; // uniform
+    const uint32_t first_out = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // asked for now, needed after the ranking
     for (int i = t; i < kRW * 256; i += kRT) (&wcount[0][0])[i] = 0;
     __syncthreads();
 
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kRadixTile;
+    const uint64_t tile0 = (uint64_t)tile * kRadixTile;
     const uint64_t wave0 = tile0 + (uint64_t)w * (kWave * kRadixItems);
     uint64_t key[kRadixItems];
     uint32_t lpos[kRadixItems]; // rank within (wave, digit), then slot in the tile's digit order
@@ -244,8 +251,8 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
                   digit_base);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 2048, radix_apply_kernel, dim3(nchunks), dim3(kBlock), hist, ntiles,
                   (const uint32_t *)sums, (const uint32_t *)digit_base);
-        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(ntiles), dim3(kRT),
-                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist);
+        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(((ntiles + 7) / 8) * 8), dim3(kRT),
+                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist, ntiles);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
         ++flips;
