@@ -70,7 +70,7 @@ typedef struct sx_build_stats {
     uint32_t doubling_rounds;
     uint32_t induce_rounds;  /* multisplit rounds over both passes */
     uint32_t sort_passes;    /* radix passes, all sorts */
-    uint32_t lms_path;       /* 1: prefix-key LMS sort resolved everything, 2: general path */
+    uint32_t lms_path;       /* 1: prefix-key LMS sort resolved everything, 2: general path, 3: direct sort of all suffixes */
     double ms_total;         /* wall time of the last build on the device stream */
 } sx_build_stats;
 
@@ -84,7 +84,8 @@ void sx_ctx_trim(sx_ctx *ctx);
 /* behaviour switches (testing / measurement) */
 enum {
     SX_FLAG_FORCE_GENERAL_PATH = 1, /* skip the prefix-key LMS sort: always pieces + names + prefix doubling */
-    SX_FLAG_CHAIN_MAX_ENTRIES = 2   /* induce rounds up to this many entries use the single chained launch */
+    SX_FLAG_CHAIN_MAX_ENTRIES = 2,  /* induce rounds up to this many entries use the single chained launch */
+    SX_FLAG_NO_DIRECT_SORT = 3      /* wide alphabets: never sort all suffixes by prefix directly, always LMS sort + induction */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

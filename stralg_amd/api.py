@@ -205,6 +205,10 @@ class Context:
         """SX_FLAG_CHAIN_MAX_ENTRIES: longer induce rounds take the count / offsets / scatter launches."""
         self._check(self.lib.sx_ctx_set_flag(self.h, 2, int(entries)), "sx_ctx_set_flag")
 
+    def set_no_direct_sort(self, on=True):
+        """SX_FLAG_NO_DIRECT_SORT: wide alphabets take the LMS sort + induction even where the direct sort applies."""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 3, 1 if on else 0), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

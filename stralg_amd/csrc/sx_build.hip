@@ -14,6 +14,7 @@
 #include "sx_internal.hpp"
 
 #include <chrono>
+#include <cmath>
 
 namespace sx {
 
@@ -66,6 +67,17 @@ static size_t reduce_bytes(uint64_t M, uint64_t m)
     return b;
 }
 
+// bwt[i] = text[sa[i] - 1], 0 for the suffix that starts the text (bwt.c:13-20); only the direct sort needs
+// this gather, the induction hands the BWT over with the suffix array
+__global__ __launch_bounds__(kBlock) void bwt_of_sa_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA,
+                                                           uint64_t N, uint8_t *__restrict__ bwt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t p = SA[i];
+    bwt[i] = p ? T[p - 1u] : (uint8_t)0;
+}
+
 int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa, uint8_t *d_bwt)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -95,6 +107,50 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     SX_TRY(sx_classify(ctx, T, n, an, ti));
     if (ti.maxc >= sigma) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= alphabet_size");
     ctx->stats.n_lms = ti.m;
+
+    // Wide alphabets: the induction visits the buckets one after the other, a few dependent launches per bucket
+    // (sigma = 256: 1500 rounds, most of the build), while the first few symbols already tell nearly all suffixes
+    // apart.  When the symbol statistics say that a 40-bit prefix key leaves only a few per cent of ALL suffixes
+    // tied, the suffixes are sorted directly with the machinery of the LMS sort (radix sort by prefix key, tie
+    // refinement); the result is the same suffix array.  Skewed or repetitive texts fail the tie bound inside and
+    // continue on the usual path.
+    if (n > 0 && ti.maxc >= 16 && !ctx->no_direct && !ctx->force_general) {
+        double sum_p2 = 0.0;
+        for (int c = 0; c < 256; ++c) {
+            const double p = (double)ti.h_all[c] / (double)N;
+            sum_p2 += p * p;
+        }
+        const double eff = 1.0 / sum_p2; // the alphabet size a uniform text with the same collision rate would have
+        uint32_t need = 1;
+        for (double v = eff; v < 32.0 * (double)N && need < 64; v *= eff) ++need;
+        const double bits = (double)need * log2((double)ti.maxc + 1.0);
+        if (bits <= 40.0) {
+            SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(N) + 1024));
+            sx_arena am;
+            am.base = (char *)ctx->slab[SX_SLAB_M].p;
+            am.cap = ctx->slab[SX_SLAB_M].cap;
+            const uint32_t *sorted = nullptr;
+            const void *unused = nullptr; // one-symbol windows, when the keys had room for them
+            int resolved = 0;
+            SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, &sorted, &unused, &resolved, true));
+            if (resolved) {
+                ctx->stats.lms_path = 3;
+                ctx->stats.n_samples = N;
+                SX_CHECK(hipMemcpyAsync(d_sa, sorted, N * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+                if (d_bwt && unused) // the sort carried every suffix's preceding symbol along
+                    SX_TRY(sx_bwt_from_seed_windows(ctx, (const uint32_t *)unused, N, ti.maxc, d_bwt));
+                else if (d_bwt)
+                    sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_of_sa_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock),
+                              (const uint8_t *)T, (const uint32_t *)d_sa, N, d_bwt);
+                SX_TRY(sx_sync(ctx));
+                ctx->stats.ms_total =
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return 0;
+            }
+            ctx->stats.doubling_rounds = 0;
+            ctx->stats.sort_passes = 0;
+        }
+    }
 
     const uint32_t *sorted_lms = nullptr;
     const void *seed_windows = nullptr; // windows of the sorted LMS suffixes, when the sort carried them

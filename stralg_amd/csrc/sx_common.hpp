@@ -73,6 +73,7 @@ struct sx_ctx {
     uint32_t chain_epoch = 0; // look-back status epoch (24 bits), see sx_device.hpp
     int64_t chain_max_override = -1; // SX_FLAG_CHAIN_MAX_ENTRIES; -1 = choose by alphabet size
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
+    int no_direct = 0;     // SX_FLAG_NO_DIRECT_SORT
     int prof_on = 0;
     // first launch that the runtime refused (a bad grid, ...): reported by the next sx_sync / sx_readback
     hipError_t launch_err = hipSuccess;

@@ -200,6 +200,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         ctx->force_general = value ? 1 : 0;
         return 0;
     }
+    if (flag == SX_FLAG_NO_DIRECT_SORT) {
+        ctx->no_direct = value ? 1 : 0;
+        return 0;
+    }
     if (flag == SX_FLAG_CHAIN_MAX_ENTRIES) {
         ctx->chain_max_override = value < 0 ? -1 : (int64_t)value; // negative: back to the default
         return 0;

@@ -1011,6 +1011,17 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
 }
 } // namespace
 
+// BWT from one-symbol windows of all suffixes in suffix-array order (the direct sort of wide alphabets)
+int sx_bwt_from_seed_windows(sx_ctx *ctx, const uint32_t *seedw, uint64_t N, uint32_t maxc, uint8_t *bwt_out)
+{
+    wnd_cfg cfg;
+    (void)sx_window_cfg(maxc, cfg);
+    cfg.CW = 1;
+    sx_launch(ctx, SX_KC_BWT_GATHER, N * 5, bwt_from_windows_kernel<uint32_t>, dim3(sx_div_up(N, kBlock * 16)), dim3(kBlock),
+              seedw, N, cfg, bwt_out);
+    return 0;
+}
+
 int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
               const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena)
 {

@@ -59,8 +59,9 @@ int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const 
 
 // ---- sx_lmssort.hip
 size_t sx_lms_prefix_bytes(uint64_t m);
+int sx_bwt_from_seed_windows(sx_ctx *ctx, const uint32_t *seedw, uint64_t N, uint32_t maxc, uint8_t *bwt_out);
 int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t **out,
-                          const void **seed_windows, int *resolved);
+                          const void **seed_windows, int *resolved, bool all_suffixes = false);
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);

@@ -121,6 +121,22 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
     }
 }
 
+// Keys of ALL suffixes (the direct sort of wide alphabets, see sx_sort_by_prefix): position p gets the key of
+// text[p .. p+C); the zero padding behind the sentinel reads as more sentinel digits, so suffixes that reach
+// the end of the text are ordered correctly and the key of position n is the smallest.
+__global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restrict__ T, uint64_t N, pkey_cfg kc,
+                                                          uint32_t kbits, wnd_cfg wcfg, uint64_t *__restrict__ keys,
+                                                          uint32_t *__restrict__ vals)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= N) return;
+    uint64_t key = prefix_key(T, p, kc);
+    // the symbol before the suffix rides in the unsorted key bits (a one-symbol window): after the sort it is the BWT
+    if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, (uint32_t)p, wcfg) << kbits;
+    keys[p] = key;
+    vals[p] = (uint32_t)p;
+}
+
 // Members of groups of equal keys -> (index in the sorted order, text position, group head flag), compacted in
 // order; the window of every sorted slot is lifted out of the key's payload bits on the way.  One launch: a
 // thread takes 8 consecutive keys (16-byte loads) and their two neighbours, tiles take tickets, and the number
@@ -397,11 +413,13 @@ size_t sx_lms_prefix_bytes(uint64_t m)
 // Returns 0 and *resolved = 1 with *out = device array of the m LMS suffix positions in
 // suffix order; *resolved = 0 when the caller must use the general path.
 int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t **out,
-                          const void **seed_windows, int *resolved)
+                          const void **seed_windows, int *resolved, bool all_suffixes)
 {
     *resolved = 0;
     *seed_windows = nullptr;
-    const uint64_t m = ti.m;
+    // all_suffixes: the same machinery over every position of the text instead of the LMS positions; what comes
+    // out is the suffix array itself (sx_build.hip decides when that is the cheaper way)
+    const uint64_t m = all_suffixes ? ti.N : ti.m;
     const uint32_t base = ti.maxc + 1;
     // longest prefix whose number fits 63 bits
     uint32_t Cmax = 0;
@@ -456,10 +474,19 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         if (!wide && 64 - kbits > kCntBits) wchars = (uint32_t)(64 - kbits - kCntBits) / wcfg.B;
         if (wchars > wcfg.CW) wchars = wcfg.CW;
         embed = wchars >= 4;
+        if (all_suffixes) {
+            // no induction follows a direct sort; one symbol of window is the BWT symbol of the suffix, for free
+            wchars = 64 - kbits >= (int)(kCntBits + wcfg.B) ? 1u : 0u;
+            embed = wchars == 1;
+        }
         wcfg.CW = embed ? wchars : 0;
         kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
-        sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
-                  (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va);
+        if (all_suffixes)
+            sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys_kernel, dim3(sx_div_up(m, kBlock)), block, ti.T, m, pkey_make(base, C),
+                      (uint32_t)kbits, wcfg, ka, va);
+        else
+            sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
+                      (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va);
         int in_b = 0;
         SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b));
         ks = in_b ? kb : ka;
@@ -491,6 +518,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 
     wnd_cfg full_wcfg; // refined slots get their windows straight from the text
     (void)sx_window_cfg(ti.maxc, full_wcfg);
+    if (all_suffixes) full_wcfg.CW = 1; // (the seed windows are 32-bit words: one wide symbol fits, seven do not)
     // ties are refined with the longest key that fits (Cmax symbols a round)
     uint64_t top_r = 1;
     for (uint32_t i = 0; i < Cmax; ++i) top_r *= base;

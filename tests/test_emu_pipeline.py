@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
+from stralg_amd.synth import synth
 
 
 def _sa(ctx, x, sigma):
@@ -136,6 +137,23 @@ def test_fasta_ingest_and_remap(emu_ctx, golden_fasta):
     with pytest.raises(Exception):  # more than 127 distinct symbols (remap.h:14-18)
         x = np.arange(1, 200, dtype=np.uint8)
         emu_ctx.remap_dev(x, x.size, np.zeros(x.size + 1, np.uint8))
+
+
+def test_wide_alphabets_direct_sort_and_induction(emu_ctx):
+    """alphabets of 16+ symbols: the direct prefix sort of all suffixes (lms_path 3) and, with it switched off, the
+    LMS sort + induction over many buckets; suffix array and BWT from both"""
+    for sigma, n in ((256, 30000), (21, 20000), (100, 5000), (128, 3000), (17, 5000)):
+        x = synth(n, sigma, 3)
+        x[100:112] = x[1000:1012]
+        x[5:17] = x[1000:1012]  # ties beyond the first key: refinement rounds
+        want = oracle.sa_is(x, sigma)
+        for no_direct in (False, True):
+            emu_ctx.set_no_direct_sort(no_direct)
+            sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+            emu_ctx.sa_bwt_build_dev(x, n, sigma, sa, bw)
+            assert emu_ctx.last_stats()["lms_path"] == (1 if no_direct else 3), (sigma, no_direct)
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (sigma, no_direct)
+    emu_ctx.set_no_direct_sort(False)
 
 
 def test_serialisation_bytes(emu_ctx, tmp_path):

@@ -637,3 +637,28 @@ def test_streamed_index_large(gpu_ctx, tmp_path):
     import filecmp
     assert os.path.getsize(a) == 4 + (1 << 26) + 4 * ((1 << 26) + 1) + 388 + 4 * 5 + 4 * 5 * ((1 << 26) + 2) + 1
     assert filecmp.cmp(a, b, shallow=False)
+
+
+@pytest.mark.parametrize("sigma,log2n", [(256, 24), (21, 22), (128, 20)])
+def test_wide_alphabets_direct_sort_and_induction(gpu_ctx, sigma, log2n):
+    """alphabets of 16+ symbols: the direct prefix sort of all suffixes (lms_path 3) and, with it switched off, the
+    LMS sort + induction over many buckets; suffix array and BWT from both, against the oracle"""
+    import torch
+    n = 1 << log2n
+    x = synth(n, sigma, 17)
+    x[100:112] = x[1000:1012]
+    x[5:17] = x[1000:1012]
+    want = oracle.sa_is(x, sigma)
+    want_bwt = oracle.bwt(x, want)
+    d_text = torch.from_numpy(x).cuda()
+    try:
+        for no_direct in (False, True):
+            gpu_ctx.set_no_direct_sort(no_direct)
+            sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+            bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+            gpu_ctx.sa_bwt_build_dev(d_text, n, sigma, sa, bw)
+            assert gpu_ctx.last_stats()["lms_path"] == (1 if no_direct else 3)
+            assert (sa.cpu().numpy().view(np.uint32) == want).all(), no_direct
+            assert (bw.cpu().numpy() == want_bwt).all(), no_direct
+    finally:
+        gpu_ctx.set_no_direct_sort(False)
