@@ -103,42 +103,49 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     SX_CHECK(hipMemcpyAsync(T, d_text, n, hipMemcpyDeviceToDevice, ctx->stream));
     SX_CHECK(hipMemsetAsync(T + n, 0, padded - n, ctx->stream));
 
-    sx_text_info ti;
-    SX_TRY(sx_classify(ctx, T, n, an, ti));
-    if (ti.maxc >= sigma) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= alphabet_size");
-    ctx->stats.n_lms = ti.m;
-
     // Wide alphabets: the induction visits the buckets one after the other, a few dependent launches per bucket
     // (sigma = 256: 1500 rounds, most of the build), while the first few symbols already tell nearly all suffixes
     // apart.  When the symbol statistics say that a 40-bit prefix key leaves only a few per cent of ALL suffixes
     // tied, the suffixes are sorted directly with the machinery of the LMS sort (radix sort by prefix key, tie
     // refinement); the result is the same suffix array.  Skewed or repetitive texts fail the tie bound inside and
-    // continue on the usual path.
-    if (n > 0 && ti.maxc >= 16 && !ctx->no_direct && !ctx->force_general) {
+    // continue on the usual path.  Only symbol counts are needed to decide, so this comes before the classification.
+    if (sigma > 16 && !ctx->no_direct && !ctx->force_general) {
+        sx_text_info td;
+        memset(&td, 0, sizeof td);
+        td.T = T;
+        td.n = n;
+        td.N = N;
+        sx_arena probe = an; // scratch of the probe is handed back whatever happens
+        uint32_t *d_h = probe.take<uint32_t>(256);
+        if (!d_h) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: histogram");
+        SX_TRY(sx_symbol_histogram(ctx, T, n, d_h, td.h_all));
+        td.h_all[0] += 1; // the sentinel
+        if (td.h_all[0] != 1) return sx_fail_msg(ctx, SX_E_ARG, "text contains the sentinel symbol 0");
         double sum_p2 = 0.0;
         for (int c = 0; c < 256; ++c) {
-            const double p = (double)ti.h_all[c] / (double)N;
+            if (td.h_all[c]) td.maxc = (uint32_t)c;
+            const double p = (double)td.h_all[c] / (double)N;
             sum_p2 += p * p;
         }
+        if (td.maxc >= sigma) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= alphabet_size");
         const double eff = 1.0 / sum_p2; // the alphabet size a uniform text with the same collision rate would have
         uint32_t need = 1;
         for (double v = eff; v < 32.0 * (double)N && need < 64; v *= eff) ++need;
-        const double bits = (double)need * log2((double)ti.maxc + 1.0);
-        if (bits <= 40.0) {
+        if (td.maxc >= 16 && (double)need * log2((double)td.maxc + 1.0) <= 40.0) {
             SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(N) + 1024));
             sx_arena am;
             am.base = (char *)ctx->slab[SX_SLAB_M].p;
             am.cap = ctx->slab[SX_SLAB_M].cap;
             const uint32_t *sorted = nullptr;
-            const void *unused = nullptr; // one-symbol windows, when the keys had room for them
+            const void *prev_symbols = nullptr; // one-symbol windows, when the keys had room for them
             int resolved = 0;
-            SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, &sorted, &unused, &resolved, true));
+            SX_TRY(sx_sort_lms_by_prefix(ctx, td, am, &sorted, &prev_symbols, &resolved, true));
             if (resolved) {
                 ctx->stats.lms_path = 3;
                 ctx->stats.n_samples = N;
                 SX_CHECK(hipMemcpyAsync(d_sa, sorted, N * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-                if (d_bwt && unused) // the sort carried every suffix's preceding symbol along
-                    SX_TRY(sx_bwt_from_seed_windows(ctx, (const uint32_t *)unused, N, ti.maxc, d_bwt));
+                if (d_bwt && prev_symbols) // the sort carried every suffix's preceding symbol along
+                    SX_TRY(sx_bwt_from_seed_windows(ctx, (const uint32_t *)prev_symbols, N, td.maxc, d_bwt));
                 else if (d_bwt)
                     sx_launch(ctx, SX_KC_BWT_GATHER, N * 6, bwt_of_sa_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock),
                               (const uint8_t *)T, (const uint32_t *)d_sa, N, d_bwt);
@@ -151,6 +158,11 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
             ctx->stats.sort_passes = 0;
         }
     }
+
+    sx_text_info ti;
+    SX_TRY(sx_classify(ctx, T, n, an, ti));
+    if (ti.maxc >= sigma) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= alphabet_size");
+    ctx->stats.n_lms = ti.m;
 
     const uint32_t *sorted_lms = nullptr;
     const void *seed_windows = nullptr; // windows of the sorted LMS suffixes, when the sort carried them

@@ -384,6 +384,37 @@ size_t sx_text_scratch_bytes(uint64_t n)
     return b + 4096;
 }
 
+// symbol counts alone (no types): enough to decide whether a wide-alphabet text takes the direct sort
+namespace sx {
+__global__ __launch_bounds__(kBlock) void symbol_hist_kernel(const uint8_t *__restrict__ T, uint64_t n,
+                                                             uint32_t *__restrict__ g_hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q * 16 < n; q += (uint64_t)gridDim.x * kBlock) {
+        // T is the context's padded copy: 16-byte aligned, readable past n
+        const uint4 v = *reinterpret_cast<const uint4 *>(T + q * 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (q * 16 + k < n) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&g_hist[threadIdx.x], h[threadIdx.x]);
+}
+} // namespace sx
+
+int sx_symbol_histogram(sx_ctx *ctx, const uint8_t *T, uint64_t n, uint32_t *d_scratch256, uint32_t h_out[256])
+{
+    SX_CHECK(hipMemsetAsync(d_scratch256, 0, 256 * sizeof(uint32_t), ctx->stream));
+    uint32_t grid = sx_div_up(n, kBlock * 64);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    sx_launch(ctx, SX_KC_CLASSIFY, n, symbol_hist_kernel, dim3(grid), dim3(kBlock), T, n, d_scratch256);
+    return sx_readback(ctx, d_scratch256, 256, h_out);
+}
+
 int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti)
 {
     ti.T = T;

@@ -27,6 +27,8 @@ struct sx_text_info {
 };
 
 size_t sx_text_scratch_bytes(uint64_t n);
+// symbol counts of T[0..n) (the sentinel at n is not counted); d_scratch256: 256 u32 of device scratch
+int sx_symbol_histogram(sx_ctx *ctx, const uint8_t *T, uint64_t n, uint32_t *d_scratch256, uint32_t h_out[256]);
 // carve the per-text scratch out of `arena`, run classification, read the histograms back
 int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti);
 // sample flags for piece width W (symbols between consecutive samples <= W); sets ti.M

@@ -451,8 +451,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     const dim3 block(kBlock);
 
     // offset of every classification tile in the global order of the LMS positions
-    uint32_t *tile_lms = ti.tile_u32, *tile_off = ti.tile_u32 + 4 * (size_t)ti.ntiles;
-    SX_TRY((device_scan<OpAdd>(ctx, ti.ntiles, InU32{tile_lms}, OutExclusive{tile_off}, nullptr)));
+    uint32_t *tile_lms = ti.tile_u32, *tile_off = all_suffixes ? nullptr : ti.tile_u32 + 4 * (size_t)ti.ntiles;
+    if (!all_suffixes) SX_TRY((device_scan<OpAdd>(ctx, ti.ntiles, InU32{tile_lms}, OutExclusive{tile_off}, nullptr)));
 
     const uint64_t *ks = nullptr;
     uint32_t *vs = nullptr;
