@@ -137,6 +137,75 @@ __global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restr
     vals[p] = (uint32_t)p;
 }
 
+// The same for keys of at most 12 symbols (every alphabet that qualifies for the direct sort): a thread takes 16
+// consecutive positions from three aligned 16-byte loads, so the symbols of all 16 keys are static byte picks
+// from registers, and writes its keys and positions with 16-byte stores.
+template <int G>
+__device__ __forceinline__ uint64_t key_from_words(const uint32_t (&w)[12], int first, const pkey_cfg &kc)
+{
+    uint64_t acc = 0;
+    uint32_t g = 0;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+        if ((uint32_t)s < kc.C) { // uniform
+            const int b = first + s;
+            g = __umul24(g, kc.base) + ((w[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            if ((s + 1) % G == 0) {
+                acc = acc * kc.powG + g;
+                g = 0;
+            }
+        }
+    }
+    if (kc.C % G) acc = acc * kc.powR + g; // uniform
+    return acc;
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__restrict__ T, uint64_t N, pkey_cfg kc,
+                                                            uint32_t kbits, wnd_cfg wcfg, uint64_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ vals)
+{
+    const uint64_t p0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u;
+    if (p0 >= N) return;
+    uint32_t w[12]; // text[p0 .. p0 + 48): T is the padded copy, aligned and readable past N
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(T + p0 + 16 * q);
+        w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+    }
+    uint32_t before = p0 ? (uint32_t)T[p0 - 1] : 0u; // the symbol in front of the thread's first suffix
+    uint64_t key[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        key[i] = key_from_words<G>(w, i, kc);
+        // the symbol before the suffix as a one-symbol window in the unsorted key bits (it becomes the BWT)
+        if (wcfg.CW && before) key[i] |= (uint64_t)(((before - 1u) << kCntBits) | 1u) << kbits;
+        before = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    }
+    if (p0 + 16 <= N && (((uintptr_t)keys | (uintptr_t)vals) & 15u) == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uint4 v;
+            v.x = (uint32_t)key[2 * q], v.y = (uint32_t)(key[2 * q] >> 32);
+            v.z = (uint32_t)key[2 * q + 1], v.w = (uint32_t)(key[2 * q + 1] >> 32);
+            *reinterpret_cast<uint4 *>(keys + p0 + 2 * q) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v;
+            v.x = (uint32_t)p0 + 4 * q, v.y = v.x + 1, v.z = v.x + 2, v.w = v.x + 3;
+            *reinterpret_cast<uint4 *>(vals + p0 + 4 * q) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (p0 + i < N) {
+                keys[p0 + i] = key[i];
+                vals[p0 + i] = (uint32_t)(p0 + i);
+            }
+    }
+}
+
 // Members of groups of equal keys -> (index in the sorted order, text position, group head flag), compacted in
 // order; the window of every sorted slot is lifted out of the key's payload bits on the way.  One launch: a
 // thread takes 8 consecutive keys (16-byte loads) and their two neighbours, tiles take tickets, and the number
@@ -481,7 +550,18 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         }
         wcfg.CW = embed ? wchars : 0;
         kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
-        if (all_suffixes)
+        if (all_suffixes && C <= 12) {
+            const pkey_cfg kc = pkey_make(base, C);
+            const dim3 grid16(sx_div_up(m, kBlock * 16));
+#define SX_KEYS16(G) sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys16_kernel<G>, grid16, block, ti.T, m, kc, (uint32_t)kbits, wcfg, ka, va)
+            switch (kc.G) {
+            case 10: SX_KEYS16(10); break;
+            case 6: SX_KEYS16(6); break;
+            case 4: SX_KEYS16(4); break;
+            default: SX_KEYS16(3); break;
+            }
+#undef SX_KEYS16
+        } else if (all_suffixes)
             sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys_kernel, dim3(sx_div_up(m, kBlock)), block, ti.T, m, pkey_make(base, C),
                       (uint32_t)kbits, wcfg, ka, va);
         else
