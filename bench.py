@@ -159,8 +159,10 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
         achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        size_label = f"{n >> 30} GiB" if n >= (1 << 30) and n % (1 << 30) == 0 else (f"{n >> 20} MiB" if n >= (1 << 20) else f"{n} B")
+        alpha_label = "DNA" if sigma == 5 else f"sigma={sigma}"
         out = {
-            "metric": "Msuffixes/s (SA-IS + BWT C/O tables, 1 GiB DNA)" if tables else "Msuffixes/s (SA-IS)",
+            "metric": f"Msuffixes/s ({'SA-IS + BWT C/O tables' if tables else 'SA-IS'}, {size_label} {alpha_label})",
             "value": round(value, 3),
             "unit": "Msuffixes/s",
             "n_gpus": world,
