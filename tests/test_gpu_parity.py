@@ -662,3 +662,38 @@ def test_wide_alphabets_direct_sort_and_induction(gpu_ctx, sigma, log2n):
             assert (bw.cpu().numpy() == want_bwt).all(), no_direct
     finally:
         gpu_ctx.set_no_direct_sort(False)
+
+
+def test_maximum_length(gpu_ctx):
+    """n = 2^32 - 2, the longest text the reference's uint32_t lengths allow (suffix_array_internal.c:12): every
+    32-bit index computation at its limit; checked on the device (permutation, suffixes strictly increasing)"""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230 * (1 << 30):
+        pytest.skip("needs ~230 GiB of device memory")
+    n = (1 << 32) - 2
+    text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.synth_dev(text, n, 5, 7)
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    gpu_ctx.sa_build_dev(text, n, 5, sa)
+    gpu_ctx.trim()
+    N = n + 1
+    assert int(sa[0]) & 0xFFFFFFFF == n
+    pos = sa.long() & 0xFFFFFFFF
+    del sa
+    rank = torch.full((N + 1,), -1, dtype=torch.int64, device="cuda")
+    for s0 in range(0, N, 1 << 30):  # (one scatter of 2^32 elements exceeds torch's own launch limits)
+        e0 = min(N, s0 + (1 << 30))
+        rank[pos[s0:e0]] = torch.arange(s0, e0, dtype=torch.int64, device="cuda")
+    assert bool((rank[:N] >= 0).all()), "not a permutation"
+    T = torch.zeros(N + 1, dtype=torch.uint8, device="cuda")
+    for s0 in range(0, n, 1 << 30):
+        T[s0:min(n, s0 + (1 << 30))] = text[s0:min(n, s0 + (1 << 30))]
+    del text
+    step = 1 << 28
+    for s0 in range(1, N - 1, step):
+        e0 = min(N - 1, s0 + step)
+        a, b = pos[s0:e0], pos[s0 + 1:e0 + 1]
+        ca, cb = T[a], T[b]
+        ok = (ca < cb) | ((ca == cb) & (rank[a + 1] < rank[b + 1]))
+        assert bool(ok.all()), f"suffixes out of order in slots [{s0}, {e0})"
