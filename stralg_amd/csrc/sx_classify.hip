@@ -177,21 +177,28 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     h[0][t] = 0;
     h[1][t] = 0;
     h[2][t] = 0;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kClsTile;
+    // A workgroup walks over many tiles and adds its histograms to the global ones once at the end: a global
+    // atomic per tile and symbol (262 144 tiles on 15 addresses at 1 GiB of DNA) serialises at the memory side
+    // and was most of this kernel's time.
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform
+    const uint64_t tile0 = (uint64_t)tile * kClsTile;
     const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
     uint32_t c[17], dmask, vmask;
     load_chunk(T, p0, c);
     decided_masks(c, p0, n, dmask, vmask);
-    const uint32_t tile_carry = blockIdx.x + 1 < ntiles ? tile_first[blockIdx.x + 1] : 1u;
+    const uint32_t tile_carry = tile + 1 < ntiles ? tile_first[tile + 1] : 1u;
     const bool has = dmask != 0;
     const uint32_t fv = has ? (vmask >> (__ffs(dmask) - 1)) & 1u : 0u;
     uint32_t cur = carry_from_right(has, fv, tile_carry, lds); // includes barriers (h[] is zeroed)
-    uint32_t smask = 0;
+    // every position takes the type of the nearest decided position at or above it, else the carry: the decided
+    // values spread downwards through the undecided bits in four doubling steps
+    uint32_t smask = vmask & dmask, known = dmask;
 #pragma unroll
-    for (int i = 15; i >= 0; --i) {
-        if ((dmask >> i) & 1u) cur = (vmask >> i) & 1u;
-        smask |= cur << i;
+    for (int k = 1; k < 16; k <<= 1) {
+        smask |= (smask >> k) & ~known;
+        known |= known >> k;
     }
+    if (cur) smask |= ~known & 0xFFFFu;
     last_s[t] = (smask >> 15) & 1u;
     __syncthreads();
     uint32_t prev_s;
@@ -215,6 +222,18 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     // symbol; LDS atomics from 64 lanes on four hot addresses would serialise.  Larger
     // symbols go to LDS directly (their addresses spread).
     uint64_t pk_all = 0, pk_l = 0, pk_lms = 0;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) any |= c[i];
+    if (p0 + 16 <= n && any < 8u) { // inside the text and all symbols small (DNA: always): no bound, sentinel or size checks
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint64_t one = 1ull << (8u * c[i]);
+            pk_all += one;
+            pk_l += ((smask >> i) & 1u) ? 0ull : one;
+            pk_lms += ((lmsmask >> i) & 1u) ? one : 0ull;
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if ((valid >> i) & 1u) {
@@ -252,17 +271,36 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
             }
         }
     }
-    lmsbits[(uint64_t)blockIdx.x * kBlock + t] = (uint16_t)lmsmask;
+    lmsbits[(uint64_t)tile * kBlock + t] = (uint16_t)lmsmask;
     const uint32_t cnt = (uint32_t)__popc(lmsmask);
     const uint32_t lastp1 = lmsmask ? (uint32_t)(p0 + (31 - __clz(lmsmask))) + 1u : 0u;
-    uint32_t tot_cnt, tot_last;
-    (void)block_exclusive_scan<OpAdd>(cnt, lds, tot_cnt);
-    (void)block_exclusive_scan<OpMax>(lastp1, lds, tot_last);
-    if (t == 0) {
-        tile_lms[blockIdx.x] = tot_cnt;
-        tile_last[blockIdx.x] = tot_last;
+    // tile totals: only the sums are needed, so one wave reduction each and a single barrier (which also
+    // completes h[])
+    uint32_t wsum = cnt, wmax = lastp1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        wsum += __shfl_xor(wsum, o, kWave);
+        const uint32_t other = __shfl_xor(wmax, o, kWave);
+        wmax = other > wmax ? other : wmax;
     }
-    // (the scans above end with a barrier: h[] is complete)
+    if (lane_id() == 0) {
+        lds[wave_id()] = wsum;
+        lds[kWavesPerBlock + wave_id()] = wmax;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t tot_cnt = 0, tot_last = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            tot_cnt += lds[w];
+            tot_last = lds[kWavesPerBlock + w] > tot_last ? lds[kWavesPerBlock + w] : tot_last;
+        }
+        tile_lms[tile] = tot_cnt;
+        tile_last[tile] = tot_last;
+    }
+    __syncthreads(); // lds[] and last_s[] are rewritten by the next tile
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const uint32_t v = h[k][t];
@@ -434,7 +472,7 @@ int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_t
     const dim3 grid(ti.ntiles), block(kBlock);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.N / 4, cls_first_kernel, grid, dim3(kWave), T, n, ti.tile_first);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.ntiles, cls_resolve_kernel, dim3(1), block, ti.tile_first, ti.ntiles);
-    sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8, cls_types_kernel, grid, block, T, n,
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8, cls_types_kernel, dim3(ti.ntiles < 2048 ? ti.ntiles : 2048), block, T, n,
               (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms, tile_last, ti.d_hist);
     // read the three histograms back: the host drives the bucket loop
     uint32_t h[3 * 256];
