@@ -266,9 +266,10 @@ __device__ __forceinline__ void stream_store16(uint4 *dst, uint4 v)
     __builtin_nontemporal_store(x, reinterpret_cast<sx_v4u *>(dst));
 }
 
-// ---- unaligned byte windows of the text from aligned 16-byte loads ------------------
-// (the text buffer is 256-byte aligned and padded, so the chunk after the last
-// byte wanted is always readable)
+// ---- byte windows of the text at any offset ----------------------------------------------
+// gfx950 serves global 16-byte loads at any byte address (the compiler emits global_load_dwordx4 for these
+// copies); a per-lane 16-byte load costs the address unit the same whatever its alignment, so two unaligned
+// loads replace the three aligned ones plus funnel shifts that a 32-byte window needs otherwise.
 __device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t r)
 {
     return r ? (lo >> r) | (hi << (64u - r)) : lo;
@@ -278,10 +279,25 @@ __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return (u
 // bytes [p, p+16) as two little-endian u64
 __device__ __forceinline__ void load_bytes16(const uint8_t *__restrict__ T, uint64_t p, uint64_t &o0, uint64_t &o1)
 {
-    const uint64_t base = p & ~(uint64_t)15;
-    const uint32_t s = (uint32_t)(p & 15);
-    const uint4 v0 = *reinterpret_cast<const uint4 *>(T + base);
-    const uint4 v1 = *reinterpret_cast<const uint4 *>(T + base + 16);
+    uint64_t q[2];
+    __builtin_memcpy(q, T + p, 16);
+    o0 = q[0];
+    o1 = q[1];
+}
+
+// bytes [p, p+32) as four little-endian u64
+__device__ __forceinline__ void load_bytes32(const uint8_t *__restrict__ T, uint64_t p, uint64_t (&o)[4])
+{
+    __builtin_memcpy(o, T + p, 32);
+}
+
+// The same from a 16-byte aligned image in LDS (a staged piece of the text): aligned 16-byte reads and funnel
+// shifts, LDS has no unaligned wide reads.  The image must hold 16 readable bytes past the last one wanted.
+__device__ __forceinline__ void lds_bytes16(const uint8_t *img, uint32_t p, uint64_t &o0, uint64_t &o1)
+{
+    const uint32_t base = p & ~15u, s = p & 15u;
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(img + base);
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(img + base + 16);
     const uint64_t q0 = pack64(v0.x, v0.y), q1 = pack64(v0.z, v0.w), q2 = pack64(v1.x, v1.y), q3 = pack64(v1.z, v1.w);
     const bool up = s >= 8;
     const uint64_t a = up ? q1 : q0, b = up ? q2 : q1, c = up ? q3 : q2;
@@ -289,15 +305,12 @@ __device__ __forceinline__ void load_bytes16(const uint8_t *__restrict__ T, uint
     o0 = funnel64(a, b, r);
     o1 = funnel64(b, c, r);
 }
-
-// bytes [p, p+32) as four little-endian u64
-__device__ __forceinline__ void load_bytes32(const uint8_t *__restrict__ T, uint64_t p, uint64_t (&o)[4])
+__device__ __forceinline__ void lds_bytes32(const uint8_t *img, uint32_t p, uint64_t (&o)[4])
 {
-    const uint64_t base = p & ~(uint64_t)15;
-    const uint32_t s = (uint32_t)(p & 15);
-    const uint4 v0 = *reinterpret_cast<const uint4 *>(T + base);
-    const uint4 v1 = *reinterpret_cast<const uint4 *>(T + base + 16);
-    const uint4 v2 = *reinterpret_cast<const uint4 *>(T + base + 32);
+    const uint32_t base = p & ~15u, s = p & 15u;
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(img + base);
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(img + base + 16);
+    const uint4 v2 = *reinterpret_cast<const uint4 *>(img + base + 32);
     const uint64_t q0 = pack64(v0.x, v0.y), q1 = pack64(v0.z, v0.w), q2 = pack64(v1.x, v1.y), q3 = pack64(v1.z, v1.w),
                    q4 = pack64(v2.x, v2.y), q5 = pack64(v2.z, v2.w);
     const bool up = s >= 8;

@@ -68,17 +68,21 @@ __device__ __forceinline__ uint64_t prefix_key_grouped(const uint64_t (&q)[4], c
     if (kc.C % G) acc = acc * kc.powR + g; // uniform
     return acc;
 }
+__device__ __forceinline__ uint64_t prefix_key_of(const uint64_t (&q)[4], const pkey_cfg &kc)
+{
+    switch (kc.G) { // uniform
+    case 10: return prefix_key_grouped<10>(q, kc);
+    case 6: return prefix_key_grouped<6>(q, kc);
+    case 4: return prefix_key_grouped<4>(q, kc);
+    default: return prefix_key_grouped<3>(q, kc);
+    }
+}
 __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, const pkey_cfg &kc)
 {
     if (kc.C <= 32) {
         uint64_t q[4];
         load_bytes32(T, p, q);
-        switch (kc.G) { // uniform
-        case 10: return prefix_key_grouped<10>(q, kc);
-        case 6: return prefix_key_grouped<6>(q, kc);
-        case 4: return prefix_key_grouped<4>(q, kc);
-        default: return prefix_key_grouped<3>(q, kc);
-        }
+        return prefix_key_of(q, kc);
     }
     uint64_t acc = 0;
     for (uint32_t s = 0; s < kc.C; ++s) acc = acc * kc.base + (uint64_t)T[p + s];
@@ -97,8 +101,19 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     __shared__ uint32_t spos[kClsTile / 2 + 1]; // LMS positions are at least two apart
+    // The text around the tile, staged once with coalesced loads: text[tile0 - 16 .. tile0 + 4096 + 48).  A suffix
+    // then takes its key symbols and its window from LDS; from memory every suffix cost five dependent 16-byte
+    // loads and the kernel ran at the latency of those.
+    __shared__ __attribute__((aligned(16))) uint8_t img[kClsTile + 64];
     const int t = (int)threadIdx.x;
-    const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)t * kClsPerThread;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kClsTile;
+    const uint64_t origin = tile0 - 16; // (wraps for tile 0: that chunk is zero-filled, nothing reads it)
+    for (uint32_t q = (uint32_t)t; q < (kClsTile + 64) / 16; q += kBlock) {
+        uint4 v = {0, 0, 0, 0};
+        if (tile0 + 16ull * q >= 16) v = *reinterpret_cast<const uint4 *>(T + tile0 + 16ull * q - 16);
+        *reinterpret_cast<uint4 *>(img + 16 * q) = v;
+    }
+    const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
     uint32_t mask = lmsbits[(uint64_t)blockIdx.x * kBlock + t];
     uint32_t total;
     uint32_t at = block_exclusive_scan<OpAdd>((uint32_t)__popc(mask), lds, total);
@@ -111,11 +126,18 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
     const uint32_t dst0 = tile_off[blockIdx.x];
     for (uint32_t i = (uint32_t)t; i < total; i += kBlock) {
         const uint32_t p = spos[i];
-        uint64_t key = prefix_key(T, p, kc);
+        uint64_t key;
+        if (kc.C <= 32) { // uniform
+            uint64_t q[4];
+            lds_bytes32(img, (uint32_t)((uint64_t)p - origin), q);
+            key = prefix_key_of(q, kc);
+        } else {
+            key = prefix_key(T, p, kc);
+        }
         // The key bits above kbits are not sorted on, they just ride along: put the suffix's
         // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
-        // this part of the text is in cache, instead of gathering it again after the sort.
-        if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
+        // this part of the text is at hand, instead of gathering it again after the sort.
+        if (wcfg.CW) key |= (uint64_t)wnd_fill_lds<uint32_t>(img, origin, p, wcfg) << kbits;
         keys[dst0 + i] = key;
         vals[dst0 + i] = p;
     }

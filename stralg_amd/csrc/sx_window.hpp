@@ -27,14 +27,11 @@ template <class WT> __device__ __forceinline__ WT wnd_pop(WT w, const wnd_cfg &c
     const WT cnt = w & (WT)15;
     return (((w >> kCntBits) >> c.B) << kCntBits) | (cnt - 1);
 }
-// window of position p, read from the text (p >= 1)
+// the window of a position from the (up to 15) bytes in front of it: lo = bytes 0..7, hi = bytes 8..15 of
+// text[p - cnt .. p)
 template <class WT>
-__device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p, const wnd_cfg &c)
+__device__ __forceinline__ WT wnd_from_bytes(uint64_t lo, uint64_t hi, uint32_t cnt, const wnd_cfg &c)
 {
-    const uint32_t cnt = p < c.CW ? p : c.CW;
-    // text[p-cnt .. p-1]: two aligned 16-byte loads, bytes picked with static indices
-    uint64_t lo, hi;
-    load_bytes16(T, (uint64_t)(p - cnt), lo, hi);
     WT acc = 0;
     if (cnt == c.CW) { // everywhere but at the very start of the text: the loop bound is uniform
 #pragma unroll
@@ -56,6 +53,25 @@ __device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p
     return (acc << kCntBits) | (WT)cnt;
 }
 
+// window of position p, read from the text (p >= 1)
+template <class WT>
+__device__ __forceinline__ WT wnd_fill(const uint8_t *__restrict__ T, uint32_t p, const wnd_cfg &c)
+{
+    const uint32_t cnt = p < c.CW ? p : c.CW;
+    uint64_t lo, hi;
+    load_bytes16(T, (uint64_t)(p - cnt), lo, hi);
+    return wnd_from_bytes<WT>(lo, hi, cnt, c);
+}
+
+// the same from a staged image of the text in LDS whose byte 0 is text[origin]
+template <class WT>
+__device__ __forceinline__ WT wnd_fill_lds(const uint8_t *img, uint64_t origin, uint32_t p, const wnd_cfg &c)
+{
+    const uint32_t cnt = p < c.CW ? p : c.CW;
+    uint64_t lo, hi;
+    lds_bytes16(img, (uint32_t)((uint64_t)(p - cnt) - origin), lo, hi);
+    return wnd_from_bytes<WT>(lo, hi, cnt, c);
+}
 
 } // namespace sx
 
