@@ -180,6 +180,11 @@ class Context:
                                                   _ptr(d_hist_l), _ptr(d_hist_lms)), "sx_prim_classify_dev")
 
     # ---- measurement -----------------------------------------------------------------
+    def profile_only(self, kclass_name=None):
+        """events only around launches of one kernel class (None: all classes)"""
+        k = -1 if kclass_name is None else _lib.KC_NAMES.index(kclass_name)
+        self._check(self.lib.sx_profile_only(self.h, k), "sx_profile_only")
+
     def profile_enable(self, on=True):
         self._check(self.lib.sx_profile_enable(self.h, 1 if on else 0), "sx_profile_enable")
 

@@ -75,6 +75,7 @@ struct sx_ctx {
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int no_direct = 0;     // SX_FLAG_NO_DIRECT_SORT
     int prof_on = 0;
+    int prof_only = -1; // >= 0: only launches of this kernel class are bracketed with events
     // first launch that the runtime refused (a bad grid, ...): reported by the next sx_sync / sx_readback
     hipError_t launch_err = hipSuccess;
     int launch_err_class = 0;
@@ -104,11 +105,12 @@ template <class... P, class... A>
 static inline void sx_launch(sx_ctx *ctx, int kclass, uint64_t alg_bytes, void (*kernel)(P...),
                              dim3 grid, dim3 block, A... args)
 {
-    if (ctx->prof_on) sx_prof_begin(ctx, kclass);
+    const bool timed = ctx->prof_on && (ctx->prof_only < 0 || ctx->prof_only == kclass);
+    if (timed) sx_prof_begin(ctx, kclass);
     hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess && ctx->launch_err == hipSuccess) ctx->launch_err = e, ctx->launch_err_class = kclass;
-    if (ctx->prof_on) sx_prof_end(ctx, kclass, alg_bytes);
+    if (timed) sx_prof_end(ctx, kclass, alg_bytes);
 }
 
 static inline uint32_t sx_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }

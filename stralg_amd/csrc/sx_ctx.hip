@@ -221,6 +221,13 @@ int sx_profile_enable(sx_ctx *ctx, int on)
     return 0;
 }
 
+int sx_profile_only(sx_ctx *ctx, int kclass)
+{
+    if (!ctx || kclass >= SX_KC_COUNT) return SX_E_ARG;
+    ctx->prof_only = kclass < 0 ? -1 : kclass;
+    return 0;
+}
+
 int sx_profile_reset(sx_ctx *ctx)
 {
     if (!ctx) return SX_E_ARG;

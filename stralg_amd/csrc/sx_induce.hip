@@ -991,7 +991,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         SX_TRY(sx_readback(ctx, (const uint32_t *)st.status, 2, timed_out));
         if (timed_out[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a look-back wait timed out");
     }
-    if (ctx->prof_on) {
+    if (ctx->prof_on && ctx->prof_only < 0) {
         // Algorithmic bytes of the two passes (the launches themselves were queued with bounds, not
         // sizes): the L pass scans every L-type entry and every LMS seed, the S pass every entry but
         // the sentinel's; every suffix is written once.  The counting launches read the windows, the
