@@ -461,6 +461,75 @@ __global__ __launch_bounds__(kBlock) void refine_small_groups_kernel(
     }
 }
 
+// Groups that survive two rounds of key refinement are true repeats, and the next 17 symbols rarely end them
+// (a 50 kb duplication would need 3000 rounds).  Small groups are therefore finished in one step by comparing
+// the suffixes themselves from the symbols already known equal on, 16 bytes at a time; the suffixes of a text
+// are distinct (the sentinel), so this settles every member.  Cost is the sum of the common prefixes; a
+// comparison that runs beyond kCompareCap symbols gives up and the build takes the general path.
+constexpr uint64_t kCompareCap = 1ull << 22;
+__device__ __forceinline__ bool suffix_less_from(const uint8_t *__restrict__ T, uint32_t a, uint32_t b, uint64_t off,
+                                                 uint32_t *__restrict__ hard)
+{
+    for (uint64_t l = off;; l += 16) {
+        if (l - off > kCompareCap) {
+            atomicAdd(hard, 1u);
+            return false;
+        }
+        uint64_t a0, a1, b0, b1;
+        load_bytes16(T, (uint64_t)a + l, a0, a1);
+        load_bytes16(T, (uint64_t)b + l, b0, b1);
+        if (a0 != b0 || a1 != b1) { // the first differing byte decides (little endian: lowest byte first)
+            const uint64_t x = a0 != b0 ? a0 ^ b0 : a1 ^ b1, ua = a0 != b0 ? a0 : a1, ub = a0 != b0 ? b0 : b1;
+            const int sh = (__ffsll((unsigned long long)x) - 1) & ~7;
+            return ((ua >> sh) & 0xFFull) < ((ub >> sh) & 0xFFull);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void refine_by_comparison_kernel(
+    const uint8_t *__restrict__ T, const uint32_t *__restrict__ ap, const uint32_t *__restrict__ apos,
+    const uint8_t *__restrict__ head, uint64_t A, uint64_t skip, uint32_t *__restrict__ vals_sorted,
+    uint32_t *__restrict__ ap_new, uint8_t *__restrict__ head_new, uint32_t *__restrict__ seedw, wnd_cfg wcfg,
+    uint32_t *__restrict__ counters /* [0] groups beyond kSmallGroup (left as they are), [1] comparisons given up */)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= A || !head[t]) return;
+    int size = 1;
+    while (size <= kSmallGroup && t + size < A && !head[t + size]) ++size;
+    if (size > kSmallGroup) { // ap_new / head_new already hold this group unchanged (copied before the launch)
+        atomicAdd(&counters[0], 1u);
+        return;
+    }
+    constexpr uint32_t kPad = 0xFFFFFFFFu;
+    uint32_t p[kSmallGroup];
+#pragma unroll
+    for (int i = 0; i < kSmallGroup; ++i) p[i] = i < size ? ap[t + i] : kPad;
+#define SX_CSWAP(a, b)                                                                                                 \
+    if (p[b] != kPad && (p[a] == kPad || suffix_less_from(T, p[b], p[a], skip, &counters[1]))) {                        \
+        const uint32_t tp = p[a];                                                                                      \
+        p[a] = p[b], p[b] = tp;                                                                                        \
+    }
+    SX_CSWAP(0, 1) SX_CSWAP(2, 3) SX_CSWAP(4, 5) SX_CSWAP(6, 7)
+    SX_CSWAP(0, 2) SX_CSWAP(1, 3) SX_CSWAP(4, 6) SX_CSWAP(5, 7)
+    SX_CSWAP(1, 2) SX_CSWAP(5, 6)
+    if (size > 4) {
+        SX_CSWAP(0, 4) SX_CSWAP(1, 5) SX_CSWAP(2, 6) SX_CSWAP(3, 7)
+        SX_CSWAP(2, 4) SX_CSWAP(3, 5)
+        SX_CSWAP(1, 2) SX_CSWAP(3, 4) SX_CSWAP(5, 6)
+    }
+#undef SX_CSWAP
+#pragma unroll
+    for (int i = 0; i < kSmallGroup; ++i) {
+        if (i < size) {
+            const uint32_t slot = apos[t + i];
+            vals_sorted[slot] = p[i];
+            if (seedw) seedw[slot] = p[i] ? wnd_fill<uint32_t>(T, p[i], wcfg) : 0u;
+            ap_new[t + i] = p[i];
+            head_new[t + i] = 1; // every member is told apart
+        }
+    }
+}
+
 struct InStillTied {
     const uint8_t *head;
     uint64_t A;
@@ -491,7 +560,7 @@ using namespace sx;
 size_t sx_lms_prefix_bytes(uint64_t m)
 {
     const size_t a = 256;
-    const uint64_t cap = m / 8 + 1024;
+    const uint64_t cap = m / 4 + 1024;
     size_t b = 0;
     b += 2 * (m * 8 + a);   // keys
     b += 3 * (m * 4 + a);   // values, seed windows
@@ -526,7 +595,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             ++C;
         }
     }
-    const uint32_t cap = (uint32_t)(m / 8 + 1024);
+    const uint32_t cap = (uint32_t)(m / 4 + 1024);
     uint64_t *ka = am.take<uint64_t>(m), *kb = am.take<uint64_t>(m);
     uint32_t *va = am.take<uint32_t>(m), *vb = am.take<uint32_t>(m);
     uint64_t *key_keep = am.take<uint64_t>(cap), *rk_a = am.take<uint64_t>(cap), *rk_b = am.take<uint64_t>(cap);
@@ -625,19 +694,21 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint64_t top_r = 1;
     for (uint32_t i = 0; i < Cmax; ++i) top_r *= base;
     const int kbits_r = sx_bitlen(top_r - 1) > 0 ? sx_bitlen(top_r - 1) : 1;
-    for (int round = 1; A > 0; ++round) {
-        if (round > 4) return 0; // still tied after C + 4 Cmax symbols: general path
-        ctx->stats.doubling_rounds++;
+    // keep what is still tied after a refinement step: (apos, ap_new, head_new) -> (apos, ap, head), A
+    auto keep_tied = [&]() -> int {
+        SX_TRY((device_compact(ctx, A, InStillTied{head_new, A}, OutStillTied{apos, ap_new, head_new, apos2, ap2, head2},
+                               d_scalar, SX_KC_DOUBLING, (uint64_t)A * 20)));
+        uint32_t A2 = 0;
+        SX_TRY(sx_readback(ctx, d_scalar, 1, &A2));
+        uint32_t *tp = apos; apos = apos2; apos2 = tp;
+        tp = ap; ap = ap2; ap2 = tp;
+        uint8_t *th = head; head = head2; head2 = th;
+        A = A2;
+        return 0;
+    };
+    // one refinement step by the next Cmax symbols through two radix sorts of (group, next key): any group size
+    auto refine_by_sorting = [&](uint64_t skip) -> int {
         const uint32_t gbits = (uint32_t)(sx_bitlen(A) > 0 ? sx_bitlen(A) : 1);
-        const uint64_t skip = (uint64_t)C + (uint64_t)Cmax * (round - 1);
-        // groups of up to eight members: settled by their head's thread
-        uint32_t large = 0;
-        SX_CHECK(hipMemsetAsync(d_scalar + 1, 0, sizeof(uint32_t), ctx->stream));
-        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_small_groups_kernel, dim3(sx_div_up(A, kBlock)), block, ti.T,
-                  ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip,
-                  pkey_make(base, Cmax), vs, ap_new, head_new, embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
-        SX_TRY(sx_readback(ctx, d_scalar + 1, 1, &large));
-        if (large) {
         // group ids and the next C symbols of every tied suffix
         SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head},
                                    OutActKey{ti.T, ap, ti.n, skip, pkey_make(base, Cmax), agid, key_keep, rk_a, ord_a},
@@ -654,17 +725,39 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 40, refine_write_kernel, dim3(sx_div_up(A, kBlock)), block, order,
                   (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid, (const uint64_t *)key_keep,
                   (uint64_t)A, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
+        return 0;
+    };
+    for (int round = 1; A > 0; ++round) {
+        // Few survivors are repeats proper: they get more rounds (each costs little) and, from the third round on,
+        // small groups are finished by comparing the suffixes themselves.  Many survivors after four rounds, or any
+        // after 32: repetitive text, general path.
+        const bool few = (uint64_t)A * 16 <= m;
+        if (round > (few ? 32 : 4)) return 0;
+        ctx->stats.doubling_rounds++;
+        const uint64_t skip = (uint64_t)C + (uint64_t)Cmax * (round - 1);
+        uint32_t counters[2] = {0, 0};
+        SX_CHECK(hipMemsetAsync(d_scalar + 1, 0, 2 * sizeof(uint32_t), ctx->stream));
+        if (few && round >= 3) {
+            SX_CHECK(hipMemcpyAsync(ap_new, ap, (size_t)A * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            SX_CHECK(hipMemcpyAsync(head_new, head, (size_t)A, hipMemcpyDeviceToDevice, ctx->stream));
+            sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_by_comparison_kernel, dim3(sx_div_up(A, kBlock)), block, ti.T,
+                      (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip, vs, ap_new, head_new,
+                      embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
+            SX_TRY(sx_readback(ctx, d_scalar + 1, 2, counters));
+            if (counters[1]) return 0; // a repeat beyond the comparison cap: general path
+            SX_TRY(keep_tied());
+            if (A == 0) break;
+            SX_TRY(refine_by_sorting(skip)); // what is left sits in groups of more than eight
+            SX_TRY(keep_tied());
+            continue;
         }
-        // keep what is still tied
-        SX_TRY((device_compact(ctx, A, InStillTied{head_new, A},
-                                   OutStillTied{apos, ap_new, head_new, apos2, ap2, head2}, d_scalar, SX_KC_DOUBLING,
-                                   (uint64_t)A * 20)));
-        uint32_t A2 = 0;
-        SX_TRY(sx_readback(ctx, d_scalar, 1, &A2));
-        uint32_t *tp = apos; apos = apos2; apos2 = tp;
-        tp = ap; ap = ap2; ap2 = tp;
-        uint8_t *th = head; head = head2; head2 = th;
-        A = A2;
+        // groups of up to eight members: settled by their head's thread
+        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_small_groups_kernel, dim3(sx_div_up(A, kBlock)), block, ti.T,
+                  ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip,
+                  pkey_make(base, Cmax), vs, ap_new, head_new, embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
+        SX_TRY(sx_readback(ctx, d_scalar + 1, 1, counters));
+        if (counters[0]) SX_TRY(refine_by_sorting(skip)); // larger groups exist: redo the round for everyone by sorting
+        SX_TRY(keep_tied());
     }
     *out = vs;
     *seed_windows = embed ? seedw : nullptr;

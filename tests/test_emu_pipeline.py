@@ -58,6 +58,19 @@ def test_both_lms_paths(emu_ctx):
     assert (1, True) in seen and any(p == 2 for p, _ in seen)
 
 
+def test_long_repeats_finish_by_comparison(emu_ctx):
+    """duplications far longer than the refinement keys: pairs are settled by comparing the suffixes themselves
+    (lms_path stays 1), a repeat with many copies goes through the sorting rounds"""
+    base = oracle.synth(200000, 5, 21)  # (few survivors relative to the LMS count: that is when the extra rounds apply)
+    for copies, L in ((1, 1000), (2, 500), (12, 100)):
+        x = base.copy()
+        for k in range(copies):
+            x[100000 + k * (L + 37): 100000 + k * (L + 37) + L] = x[500:500 + L]
+        assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all(), (copies, L)
+        st = emu_ctx.last_stats()
+        assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, (copies, L, st)
+
+
 def test_both_induce_round_forms(emu_ctx):
     """large rounds (count / offsets / scatter launches) and small rounds (one chained launch)"""
     rng = np.random.default_rng(12)

@@ -697,3 +697,29 @@ def test_maximum_length(gpu_ctx):
         ca, cb = T[a], T[b]
         ok = (ca < cb) | ((ca == cb) & (rank[a + 1] < rank[b + 1]))
         assert bool(ok.all()), f"suffixes out of order in slots [{s0}, {e0})"
+
+
+def test_long_repeats_finish_by_comparison(gpu_ctx):
+    """duplications far longer than the refinement keys (up to 50 000 symbols), diverged repeat families and
+    microsatellites in 4 Mi symbols of biased DNA: small groups are settled by comparing the suffixes themselves,
+    the build stays on the prefix-key path and matches the oracle"""
+    n = 1 << 22
+    rng = np.random.default_rng(5)
+    x = rng.choice(np.array([1, 2, 3, 4], dtype=np.uint8), size=n, p=[0.3, 0.2, 0.2, 0.3])
+    elem = rng.integers(1, 5, size=300, dtype=np.uint8)
+    for pos in rng.integers(0, n - 400, size=n // 3000):
+        copy = elem.copy()
+        mut = rng.random(300) < 0.08
+        copy[mut] = rng.integers(1, 5, size=int(mut.sum()), dtype=np.uint8)
+        x[pos:pos + 300] = copy
+    for L, count in ((100, 200), (1000, 30), (6000, 4), (50000, 1)):
+        for _ in range(count):
+            a, b = rng.integers(0, n - L - 1, size=2)
+            x[b:b + L] = x[a:a + L]
+    for pos in rng.integers(0, n - 400, size=n // 20000):
+        unit = rng.integers(1, 5, size=int(rng.integers(1, 5)), dtype=np.uint8)
+        L = int(rng.integers(20, 200))
+        x[pos:pos + L] = np.resize(unit, L)
+    assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all()
+    st = gpu_ctx.last_stats()
+    assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, st
