@@ -31,6 +31,10 @@ for it in range(2):
     ctx.sa_build_dev(text, n, 5, sa)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 st = ctx.last_stats()
+ctx.profile_reset(); ctx.profile_enable(True)
+ctx.sa_build_dev(text, n, 5, sa)
+torch.cuda.synchronize(); ctx.profile_enable(False)
+print({k: round(v["ms"], 2) for k, v in ctx.profile_read().items() if v["launches"]})
 print(f"genome-like 2^{log2n}: {dt*1e3:.1f} ms = {n/dt/1e6:.0f} Msuffixes/s  path={st['lms_path']} refinement rounds={st['doubling_rounds']} "
       f"key symbols={st['key_slots']} told apart by the first sort={st['n_names']}/{st['n_lms']}")
 # check on the device: permutation + neighbouring suffixes in order (rank of the next suffix decides ties of the first symbol)
