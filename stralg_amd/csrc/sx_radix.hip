@@ -58,6 +58,28 @@ __global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restr
     if (threadIdx.x < 256) hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
+// The same from the digit bytes the previous pass's scatter wrote next to its output (one byte per key, in the
+// order of that output): an eighth of the key array's traffic.
+__global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const uint8_t *__restrict__ dig, uint64_t n,
+                                                                uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)threadIdx.x * kRadixItems;
+    static_assert(kRadixItems == 16, "one 16-byte load per thread");
+    if (base + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+    } else {
+        for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[dig[i]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
 constexpr uint32_t kRadixChunk = 256; // tiles per chunk of the column sums
 constexpr int kColBatch = 16;         // independent loads in flight per thread
 
@@ -122,7 +144,8 @@ __global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restric
 __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
     uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
-    uint32_t ntiles)
+    uint32_t ntiles, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift,
+    uint32_t next_mask)
 {
     __shared__ uint32_t wcount[kRW][256]; // per-wave digit counters, then wave bases
     __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
             const uint32_t d = (uint32_t)(kk >> shift) & mask;
             dstv[k] = goff[d] + i;
             kout[dstv[k]] = kk;
+            if (dig_out) dig_out[dstv[k]] = (uint8_t)((uint32_t)(kk >> next_shift) & next_mask); // uniform test
         }
     }
     __syncthreads();
@@ -234,25 +258,33 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
     if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
     const uint32_t ntiles = sx_div_up(n, kRadixTile);
     const uint32_t nchunks = sx_div_up(ntiles, kRadixChunk);
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t)));
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t) + ((n + 255) & ~(uint64_t)255) + 256));
     uint32_t *hist = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
     uint32_t *sums = hist + (size_t)ntiles * 256, *digit_base = sums + (size_t)nchunks * 256;
+    uint8_t *dig = (uint8_t *)(digit_base + 256); // next pass's digits, written by every scatter but the last
     uint64_t *kin = ka, *kout = kb;
     uint32_t *vin = va, *vout = vb;
     int flips = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
         const uint32_t mask = (1u << bits) - 1u;
-        sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kRT),
-                  (const uint64_t *)kin, n, shift, mask, hist, ntiles);
+        const int next_shift = shift + 8;
+        const bool has_next = next_shift < end_bit;
+        const int next_bits = has_next ? (end_bit - next_shift < 8 ? end_bit - next_shift : 8) : 0;
+        if (shift == begin_bit)
+            sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kRT), (const uint64_t *)kin, n, shift,
+                      mask, hist, ntiles);
+        else
+            sx_launch(ctx, SX_KC_RADIX_HIST, n, radix_hist_digits_kernel, dim3(ntiles), dim3(kRT), (const uint8_t *)dig, n, hist);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 1024, radix_colsum_kernel, dim3(nchunks), dim3(kBlock),
                   (const uint32_t *)hist, ntiles, sums);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks * 2048, radix_bases_kernel, dim3(1), dim3(kBlock), sums, nchunks,
                   digit_base);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 2048, radix_apply_kernel, dim3(nchunks), dim3(kBlock), hist, ntiles,
                   (const uint32_t *)sums, (const uint32_t *)digit_base);
-        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * 24, radix_scatter_kernel, dim3(((ntiles + 7) / 8) * 8), dim3(kRT),
-                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist, ntiles);
+        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (has_next ? 25 : 24), radix_scatter_kernel, dim3(((ntiles + 7) / 8) * 8), dim3(kRT),
+                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist, ntiles,
+                  has_next ? dig : nullptr, next_shift & 63, has_next ? (1u << next_bits) - 1u : 0u);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
         ++flips;
