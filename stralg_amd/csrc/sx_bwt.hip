@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
                                                              const uint32_t *__restrict__ tilepre,
                                                              uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
-    constexpr uint32_t kRowWords = 64 * (kMaxSigmaO + 1); // every (RG, sigma) pair fits: 4*64*33, 2*64*65, 64*129
+    constexpr uint32_t kRowWords = 4 * 64 * 33; // the largest of 4*64*33, 2*64*65 and 64*129 words: every (RG, sigma) pair fits
     __shared__ __attribute__((aligned(16))) uint32_t rows[kRowWords];
     __shared__ uint32_t gtot[4][kMaxSigmaO]; // symbol counts of every row group
     __shared__ uint32_t pre[kMaxSigmaO];     // symbol counts before the tile

@@ -245,7 +245,8 @@ def test_fused_sa_bwt_tables(gpu_ctx):
 
 def test_wide_alphabet_tables(gpu_ctx):
     rng = np.random.default_rng(6)
-    for sigma, n in ((9, 5000), (21, 70_000), (128, 30_000)):
+    # (32, 33, 64, 65, 128: the edges of the wide kernel's tile classes, where its LDS rows are largest)
+    for sigma, n in ((9, 5000), (21, 70_000), (128, 30_000), (32, 16_382), (33, 9000), (64, 65_538), (65, 9000), (127, 9000)):
         x = rng.integers(1, sigma, size=n, dtype=np.uint8)
         sa = oracle.sa_is(x, sigma)
         c, o = gpu_ctx.bwt_tables(x, sa, sigma)

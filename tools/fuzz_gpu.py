@@ -1,0 +1,52 @@
+"""differential fuzz on the GPU: random sizes, alphabets and repeat structures against the oracle (SA, BWT, C, O)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import stralg_amd, oracle
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = stralg_amd.Context(0)
+t0 = time.time()
+paths = {}
+for k in range(cases):
+    sigma = int(rng.choice([2, 3, 5, 5, 5, 9, 17, 21, 64, 128, 256]))
+    n = int(rng.choice([1, 2, 3, 17, 255, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 65537, 100003, 300007]))
+    n = max(1, n + int(rng.integers(-3, 4)))
+    kind = int(rng.integers(0, 6))
+    if sigma == 2:
+        x = np.ones(n, dtype=np.uint8)
+    else:
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+    if kind == 1 and n > 64:      # planted repeats
+        for _ in range(int(rng.integers(1, 20))):
+            L = int(rng.integers(2, max(3, n // 4)))
+            a, b = rng.integers(0, n - L, size=2)
+            x[b:b + L] = x[a:a + L]
+    elif kind == 2 and n > 8:     # runs
+        for _ in range(int(rng.integers(1, 30))):
+            L = int(rng.integers(1, max(2, n // 8)))
+            a = int(rng.integers(0, n - L))
+            x[a:a + L] = x[a]
+    elif kind == 3:               # periodic
+        p = int(rng.integers(1, 9))
+        x = np.resize(x[:p], n)
+    elif kind == 4 and sigma > 3: # skewed
+        x = np.where(rng.random(n) < 0.9, 1, x).astype(np.uint8)
+    flag = int(rng.integers(0, 4))
+    ctx.force_general_path(flag == 1)
+    ctx.set_no_direct_sort(flag == 2)
+    # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
+    want = oracle.sa_is_strict(x, sigma) if sigma == n + 1 else oracle.sa_is(x, sigma)
+    sa = np.zeros(n + 1, np.uint32)
+    got = ctx.sa_build(x, sigma)
+    st = ctx.last_stats()
+    paths[st["lms_path"]] = paths.get(st["lms_path"], 0) + 1
+    assert (got == want).all(), ("SA", k, sigma, n, kind, flag)
+    if sigma <= 128 and n < 70000:
+        c, o = ctx.bwt_tables(x, want, sigma)
+        assert (c == oracle.c_table(x, sigma)).all(), ("C", k, sigma, n, kind)
+        assert (o.ravel() == oracle.o_table(x, want, sigma).ravel()).all(), ("O", k, sigma, n, kind)
+ctx.force_general_path(False); ctx.set_no_direct_sort(False)
+print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
