@@ -724,3 +724,14 @@ def test_long_repeats_finish_by_comparison(gpu_ctx):
     assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all()
     st = gpu_ctx.last_stats()
     assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, st
+
+
+def test_differential_fuzz():
+    """tools/fuzz_gpu.py: 250 random (size, alphabet, structure, path flag) combinations against the oracle --
+    suffix array, C and O tables from (text, sa) and from the fused build.  (This is the harness that found the
+    undersized LDS rows of the wide O-table kernel at sigma = 32 and 64.)"""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "250", "77"], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "250 cases ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

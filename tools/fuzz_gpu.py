@@ -11,8 +11,9 @@ ctx = stralg_amd.Context(0)
 t0 = time.time()
 paths = {}
 for k in range(cases):
-    sigma = int(rng.choice([2, 3, 5, 5, 5, 9, 17, 21, 64, 128, 256]))
-    n = int(rng.choice([1, 2, 3, 17, 255, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 65537, 100003, 300007]))
+    sigma = int(rng.choice([2, 3, 5, 5, 5, 8, 9, 16, 17, 21, 32, 33, 64, 65, 127, 128, 200, 256]))
+    n = int(rng.choice([1, 2, 3, 17, 255, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 65537, 100003, 300007,
+                        1048577, 2500001]))
     n = max(1, n + int(rng.integers(-3, 4)))
     kind = int(rng.integers(0, 6))
     if sigma == 2:
@@ -45,8 +46,11 @@ for k in range(cases):
     paths[st["lms_path"]] = paths.get(st["lms_path"], 0) + 1
     assert (got == want).all(), ("SA", k, sigma, n, kind, flag)
     if sigma <= 128 and n < 70000:
+        want_c, want_o = oracle.c_table(x, sigma), oracle.o_table(x, want, sigma).ravel()
         c, o = ctx.bwt_tables(x, want, sigma)
-        assert (c == oracle.c_table(x, sigma)).all(), ("C", k, sigma, n, kind)
-        assert (o.ravel() == oracle.o_table(x, want, sigma).ravel()).all(), ("O", k, sigma, n, kind)
+        assert (c == want_c).all(), ("C", k, sigma, n, kind)
+        assert (o.ravel() == want_o).all(), ("O", k, sigma, n, kind)
+        sa2, c2, o2 = ctx.build_tables(x, sigma)  # the fused build: BWT from the induction windows / the sort payload
+        assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
 ctx.force_general_path(False); ctx.set_no_direct_sort(False)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
