@@ -115,9 +115,11 @@ def emu_ctx():
     """Context on the CPU execution harness build of the kernel sources (tests/emu).
     Test infrastructure: it exercises kernel logic without a GPU and is never what
     the product loads."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "stralg_amd", "csrc"), "emu"])
+    # STRALG_EMU_ASAN=1 (set by tests/test_emu_asan.py for its child run): the AddressSanitizer build of the harness
+    asan = os.environ.get("STRALG_EMU_ASAN") == "1"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "stralg_amd", "csrc"), "emu-asan" if asan else "emu"])
     from stralg_amd.api import Context
-    ctx = Context(0, lib_path=EMU_LIB)
+    ctx = Context(0, lib_path=EMU_LIB.replace("_emu.so", "_emu_asan.so") if asan else EMU_LIB)
     yield ctx
     ctx.close()
 
