@@ -13,7 +13,7 @@ paths = {}
 for k in range(cases):
     sigma = int(rng.choice([2, 3, 5, 5, 5, 8, 9, 16, 17, 21, 32, 33, 64, 65, 127, 128, 200, 256]))
     n = int(rng.choice([1, 2, 3, 17, 255, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 65537, 100003, 300007,
-                        1048577, 2500001]))
+                        1048577, 2500001, 2500001, 9000001]))
     n = max(1, n + int(rng.integers(-3, 4)))
     kind = int(rng.integers(0, 6))
     if sigma == 2:
@@ -36,6 +36,7 @@ for k in range(cases):
     elif kind == 4 and sigma > 3: # skewed
         x = np.where(rng.random(n) < 0.9, 1, x).astype(np.uint8)
     flag = int(rng.integers(0, 4))
+    ctx.set_chain_max_entries(int(rng.choice([2048, 8192, 65536, 524288, 4194304])))  # which induce rounds are chained
     ctx.force_general_path(flag == 1)
     ctx.set_no_direct_sort(flag == 2)
     # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
@@ -52,5 +53,5 @@ for k in range(cases):
         assert (o.ravel() == want_o).all(), ("O", k, sigma, n, kind)
         sa2, c2, o2 = ctx.build_tables(x, sigma)  # the fused build: BWT from the induction windows / the sort payload
         assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
-ctx.force_general_path(False); ctx.set_no_direct_sort(False)
+ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(524288)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
