@@ -269,10 +269,11 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
         const uint64_t i = tile0 + (uint64_t)rg * kWave + lane;
         const uint32_t sym = i < N ? (uint32_t)bwt[i] : 0xFFFFu;
         if ((uint32_t)t < sigma) pre[t] = tilepre[(uint64_t)t * ntiles + tile] - tilepre[(uint64_t)t * ntiles];
-        for (uint32_t a = cp; a < sigma; a += CP) { // uniform per wave
-            const uint64_t m = __ballot(sym == a ? 1 : 0);
-            if (lane == 0) gtot[rg][a] = (uint32_t)__popcll(m);
-        }
+        // symbol counts of every row group: one LDS add per lane (a ballot per column here would double the
+        // kernel's vector work; with wide alphabets the adds spread over many words)
+        for (uint32_t k = (uint32_t)t; k < RG * kMaxSigmaO; k += kBlock) (&gtot[0][0])[k] = 0;
+        __syncthreads();
+        if (cp == 0 && sym < sigma) atomicAdd(&gtot[rg][sym], 1u); // (one wave per row group does the counting)
         __syncthreads();
         for (uint32_t a = cp; a < sigma; a += CP) {
             uint32_t base = pre[a];
