@@ -668,7 +668,11 @@ def test_wide_alphabets_direct_sort_and_induction(gpu_ctx, sigma, log2n):
 def test_maximum_length(gpu_ctx):
     """n = 2^32 - 2, the longest text the reference's uint32_t lengths allow (suffix_array_internal.c:12): every
     32-bit index computation at its limit; checked on the device (permutation, suffixes strictly increasing)"""
+    import gc
     import torch
+    gpu_ctx.trim()  # earlier tests' workspace and torch's cached blocks go back first
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 230 * (1 << 30):
         pytest.skip("needs ~230 GiB of device memory")
