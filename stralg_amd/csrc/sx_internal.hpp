@@ -4,7 +4,7 @@
 
 // ---- sx_radix.hip
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
-                  int begin_bit, int end_bit, int *result_in_b);
+                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices = false);
 
 // ---- sx_classify.hip
 constexpr int kClsPerThread = 16;                     // text positions per thread

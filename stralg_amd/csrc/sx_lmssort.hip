@@ -155,8 +155,7 @@ __global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restr
     uint64_t key = prefix_key(T, p, kc);
     // the symbol before the suffix rides in the unsorted key bits (a one-symbol window): after the sort it is the BWT
     if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, (uint32_t)p, wcfg) << kbits;
-    keys[p] = key;
-    vals[p] = (uint32_t)p;
+    keys[p] = key; // (the position is the index: the sort's first pass fills the values in)
 }
 
 // The same for keys of at most 12 symbols (every alphabet that qualifies for the direct sort): a thread takes 16
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
         if (wcfg.CW && before) key[i] |= (uint64_t)(((before - 1u) << kCntBits) | 1u) << kbits;
         before = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
     }
-    if (p0 + 16 <= N && (((uintptr_t)keys | (uintptr_t)vals) & 15u) == 0) {
+    if (p0 + 16 <= N && ((uintptr_t)keys & 15u) == 0) { // (the positions are the indices: the sort's first pass fills them in)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             uint4 v;
@@ -212,19 +211,10 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
             v.z = (uint32_t)key[2 * q + 1], v.w = (uint32_t)(key[2 * q + 1] >> 32);
             *reinterpret_cast<uint4 *>(keys + p0 + 2 * q) = v;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint4 v;
-            v.x = (uint32_t)p0 + 4 * q, v.y = v.x + 1, v.z = v.x + 2, v.w = v.x + 3;
-            *reinterpret_cast<uint4 *>(vals + p0 + 4 * q) = v;
-        }
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (p0 + i < N) {
-                keys[p0 + i] = key[i];
-                vals[p0 + i] = (uint32_t)(p0 + i);
-            }
+            if (p0 + i < N) keys[p0 + i] = key[i];
     }
 }
 
@@ -659,7 +649,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
                       (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va);
         int in_b = 0;
-        SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b));
+        SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b, all_suffixes)); // (all suffixes: value = index)
         ks = in_b ? kb : ka;
         vs = in_b ? vb : va;
         // members of groups with equal keys

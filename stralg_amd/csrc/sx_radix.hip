@@ -141,6 +141,8 @@ __global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restric
 }
 
 // (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
+// IOTA: the values of the input are its indices 0, 1, 2, ... (the first pass of a sort of all positions): not read
+template <bool IOTA>
 __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
     uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        if (i < n) sval[lpos[k]] = vin[i]; // the values are only read now: fewer live registers
+        if (i < n) sval[lpos[k]] = IOTA ? (uint32_t)i : vin[i]; // the values are only read now: fewer live registers
     }
     __syncthreads();
 #pragma unroll
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
 using namespace sx;
 
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
-                  int begin_bit, int end_bit, int *result_in_b)
+                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices)
 {
     *result_in_b = 0;
     if (n == 0 || end_bit <= begin_bit) return 0;
@@ -282,9 +284,14 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
                   digit_base);
         sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 2048, radix_apply_kernel, dim3(nchunks), dim3(kBlock), hist, ntiles,
                   (const uint32_t *)sums, (const uint32_t *)digit_base);
-        sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (has_next ? 25 : 24), radix_scatter_kernel, dim3(((ntiles + 7) / 8) * 8), dim3(kRT),
-                  (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist, ntiles,
-                  has_next ? dig : nullptr, next_shift & 63, has_next ? (1u << next_bits) - 1u : 0u);
+        if (values_are_indices && shift == begin_bit)
+            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (has_next ? 21 : 20), radix_scatter_kernel<true>, dim3(((ntiles + 7) / 8) * 8),
+                      dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist,
+                      ntiles, has_next ? dig : nullptr, next_shift & 63, has_next ? (1u << next_bits) - 1u : 0u);
+        else
+            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (has_next ? 25 : 24), radix_scatter_kernel<false>, dim3(((ntiles + 7) / 8) * 8),
+                      dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist,
+                      ntiles, has_next ? dig : nullptr, next_shift & 63, has_next ? (1u << next_bits) - 1u : 0u);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
         ++flips;
@@ -300,7 +307,7 @@ extern "C" int sx_prim_sort_pairs_dev(sx_ctx *ctx, uint64_t *d_keys_a, uint32_t 
 {
     if (!ctx || !result_in_b || begin_bit < 0 || end_bit > 64) return SX_E_ARG;
     SX_CHECK(hipSetDevice(ctx->device));
-    SX_TRY(sx_sort_pairs(ctx, d_keys_a, d_vals_a, d_keys_b, d_vals_b, n, begin_bit, end_bit, result_in_b));
+    SX_TRY(sx_sort_pairs(ctx, d_keys_a, d_vals_a, d_keys_b, d_vals_b, n, begin_bit, end_bit, result_in_b, false));
     return sx_sync(ctx);
 }
 
