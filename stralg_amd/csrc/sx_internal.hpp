@@ -4,7 +4,11 @@
 
 // ---- sx_radix.hip
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
-                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices = false);
+                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices = false,
+                  bool first_digits_ready = false);
+// where the key generator of a sort of n pairs may leave the first pass's digit of every key ((key >> begin_bit) & 255):
+// the first histogram then reads these bytes instead of the keys (first_digits_ready)
+uint8_t *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n);
 
 // ---- sx_classify.hip
 constexpr int kClsPerThread = 16;                     // text positions per thread

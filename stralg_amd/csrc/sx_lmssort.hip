@@ -97,7 +97,8 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
                                                                const uint16_t *__restrict__ lmsbits,
                                                                const uint32_t *__restrict__ tile_off, pkey_cfg kc,
                                                                uint32_t kbits, wnd_cfg wcfg,
-                                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                               uint8_t *__restrict__ dig0)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     __shared__ uint32_t spos[kClsTile / 2 + 1]; // LMS positions are at least two apart
@@ -140,6 +141,8 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
         if (wcfg.CW) key |= (uint64_t)wnd_fill_lds<uint32_t>(img, origin, p, wcfg) << kbits;
         keys[dst0 + i] = key;
         vals[dst0 + i] = p;
+        // the first radix pass's digit (its histogram reads this byte, not the key): the low 8 key bits, without payload
+        dig0[dst0 + i] = (uint8_t)(kbits >= 8 ? key : key & ((1ull << kbits) - 1ull));
     }
 }
 
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
 // the end of the text are ordered correctly and the key of position n is the smallest.
 __global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restrict__ T, uint64_t N, pkey_cfg kc,
                                                           uint32_t kbits, wnd_cfg wcfg, uint64_t *__restrict__ keys,
-                                                          uint32_t *__restrict__ vals)
+                                                          uint8_t *__restrict__ dig0)
 {
     const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= N) return;
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restr
     // the symbol before the suffix rides in the unsorted key bits (a one-symbol window): after the sort it is the BWT
     if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, (uint32_t)p, wcfg) << kbits;
     keys[p] = key; // (the position is the index: the sort's first pass fills the values in)
+    dig0[p] = (uint8_t)(kbits >= 8 ? key : key & ((1ull << kbits) - 1ull));
 }
 
 // The same for keys of at most 12 symbols (every alphabet that qualifies for the direct sort): a thread takes 16
@@ -184,7 +188,7 @@ __device__ __forceinline__ uint64_t key_from_words(const uint32_t (&w)[12], int 
 template <int G>
 __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__restrict__ T, uint64_t N, pkey_cfg kc,
                                                             uint32_t kbits, wnd_cfg wcfg, uint64_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals)
+                                                            uint8_t *__restrict__ dig0)
 {
     const uint64_t p0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u;
     if (p0 >= N) return;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
         if (wcfg.CW && before) key[i] |= (uint64_t)(((before - 1u) << kCntBits) | 1u) << kbits;
         before = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
     }
-    if (p0 + 16 <= N && ((uintptr_t)keys & 15u) == 0) { // (the positions are the indices: the sort's first pass fills them in)
+    if (p0 + 16 <= N && (((uintptr_t)keys | (uintptr_t)dig0) & 15u) == 0) { // (positions = indices: the first pass fills them in)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             uint4 v;
@@ -211,10 +215,20 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
             v.z = (uint32_t)key[2 * q + 1], v.w = (uint32_t)(key[2 * q + 1] >> 32);
             *reinterpret_cast<uint4 *>(keys + p0 + 2 * q) = v;
         }
+        uint32_t d[4] = {0, 0, 0, 0}; // the first radix pass's digits of the 16 keys
+        const uint32_t dmask = kbits >= 8 ? 0xFFu : (1u << kbits) - 1u; // (without payload bits when the key is short)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i >> 2] |= ((uint32_t)key[i] & dmask) << (8 * (i & 3));
+        uint4 v;
+        v.x = d[0], v.y = d[1], v.z = d[2], v.w = d[3];
+        *reinterpret_cast<uint4 *>(dig0 + p0) = v;
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (p0 + i < N) keys[p0 + i] = key[i];
+            if (p0 + i < N) {
+                keys[p0 + i] = key[i];
+                dig0[p0 + i] = (uint8_t)(kbits >= 8 ? key[i] : key[i] & ((1ull << kbits) - 1ull));
+            }
     }
 }
 
@@ -631,10 +645,12 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         }
         wcfg.CW = embed ? wchars : 0;
         kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+        uint8_t *dig0 = sx_sort_digit_buffer(ctx, m); // the key kernels leave the first pass's digits there
+        if (!dig0) return sx_fail_msg(ctx, SX_E_NOMEM, "sort workspace");
         if (all_suffixes && C <= 12) {
             const pkey_cfg kc = pkey_make(base, C);
             const dim3 grid16(sx_div_up(m, kBlock * 16));
-#define SX_KEYS16(G) sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys16_kernel<G>, grid16, block, ti.T, m, kc, (uint32_t)kbits, wcfg, ka, va)
+#define SX_KEYS16(G) sx_launch(ctx, SX_KC_KEYS, m * 10, all_keys16_kernel<G>, grid16, block, ti.T, m, kc, (uint32_t)kbits, wcfg, ka, dig0)
             switch (kc.G) {
             case 10: SX_KEYS16(10); break;
             case 6: SX_KEYS16(6); break;
@@ -644,12 +660,12 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 #undef SX_KEYS16
         } else if (all_suffixes)
             sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys_kernel, dim3(sx_div_up(m, kBlock)), block, ti.T, m, pkey_make(base, C),
-                      (uint32_t)kbits, wcfg, ka, va);
+                      (uint32_t)kbits, wcfg, ka, dig0);
         else
             sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
-                      (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va);
+                      (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va, dig0);
         int in_b = 0;
-        SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b, all_suffixes)); // (all suffixes: value = index)
+        SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b, all_suffixes, true)); // (all suffixes: value = index)
         ks = in_b ? kb : ka;
         vs = in_b ? vb : va;
         // members of groups with equal keys

@@ -252,15 +252,30 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
 
 using namespace sx;
 
+// workspace of a sort of n pairs: tile table, chunk sums, digit bases, then one digit byte per pair
+static size_t sort_workspace(uint64_t n, uint32_t &ntiles, uint32_t &nchunks)
+{
+    ntiles = sx_div_up(n, kRadixTile);
+    nchunks = sx_div_up(ntiles, kRadixChunk);
+    return ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t) + ((n + 255) & ~(uint64_t)255) + 256;
+}
+
+uint8_t *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n)
+{
+    uint32_t ntiles, nchunks;
+    const size_t bytes = sort_workspace(n, ntiles, nchunks);
+    if (sx_slab_ensure(ctx, SX_SLAB_SORT, bytes) != 0) return nullptr;
+    return (uint8_t *)ctx->slab[SX_SLAB_SORT].p + ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t);
+}
+
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
-                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices)
+                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready)
 {
     *result_in_b = 0;
     if (n == 0 || end_bit <= begin_bit) return 0;
     if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
-    const uint32_t ntiles = sx_div_up(n, kRadixTile);
-    const uint32_t nchunks = sx_div_up(ntiles, kRadixChunk);
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t) + ((n + 255) & ~(uint64_t)255) + 256));
+    uint32_t ntiles, nchunks;
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, sort_workspace(n, ntiles, nchunks)));
     uint32_t *hist = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
     uint32_t *sums = hist + (size_t)ntiles * 256, *digit_base = sums + (size_t)nchunks * 256;
     uint8_t *dig = (uint8_t *)(digit_base + 256); // next pass's digits, written by every scatter but the last
@@ -273,7 +288,7 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
         const int next_shift = shift + 8;
         const bool has_next = next_shift < end_bit;
         const int next_bits = has_next ? (end_bit - next_shift < 8 ? end_bit - next_shift : 8) : 0;
-        if (shift == begin_bit)
+        if (shift == begin_bit && !first_digits_ready)
             sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kRT), (const uint64_t *)kin, n, shift,
                       mask, hist, ntiles);
         else
@@ -307,7 +322,7 @@ extern "C" int sx_prim_sort_pairs_dev(sx_ctx *ctx, uint64_t *d_keys_a, uint32_t 
 {
     if (!ctx || !result_in_b || begin_bit < 0 || end_bit > 64) return SX_E_ARG;
     SX_CHECK(hipSetDevice(ctx->device));
-    SX_TRY(sx_sort_pairs(ctx, d_keys_a, d_vals_a, d_keys_b, d_vals_b, n, begin_bit, end_bit, result_in_b, false));
+    SX_TRY(sx_sort_pairs(ctx, d_keys_a, d_vals_a, d_keys_b, d_vals_b, n, begin_bit, end_bit, result_in_b, false, false));
     return sx_sync(ctx);
 }
 
