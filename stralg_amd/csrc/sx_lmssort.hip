@@ -233,32 +233,24 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
 }
 
 // Members of groups of equal keys -> (index in the sorted order, text position, group head flag), compacted in
-// order; the window of every sorted slot is lifted out of the key's payload bits on the way.  One launch: a
-// thread takes 8 consecutive keys (16-byte loads) and their two neighbours, tiles take tickets, and the number
-// of tied members in earlier tiles comes from the chained look-back of sx_device.hpp (one status word per tile,
-// a whole wave looking back 64 tiles a step), so the sorted keys are read once.
-// A tile is kTiedSub sub-tiles of 2048 keys taken one after the other: with thousands of tiles in flight a
-// look-back walks over most of them (a hop to another XCD's status word costs microseconds), so a tile has to
-// carry enough traffic (8192 keys: 147 KB) to hide a walk of tens of microseconds.
+// order; the window of every sorted slot is lifted out of the key's payload bits on the way.  Two launches and a
+// small scan, no dependence between tiles: `tied_mark` reads the sorted keys once (a thread takes 8 consecutive
+// keys, 16-byte loads, and their two neighbours), writes the windows, the tile's count and the tile's members,
+// compacted inside the tile, to a staging area (the sort's spare ping-pong buffers, free by now); `tied_gather`
+// moves every tile's few members to their place in the global list.  (A single chained launch with decoupled
+// look-back read no more bytes but took 1.8 ms against 1.2: with thousands of tiles in flight a look-back walks
+// over most of them, and a hop to another XCD's status word costs microseconds.)
 constexpr int kTiedItems = 8, kTiedSub = 4;
 constexpr int kTiedSubTile = kBlock * kTiedItems, kTiedTile = kTiedSubTile * kTiedSub;
-__global__ __launch_bounds__(kBlock) void tied_compact_kernel(const uint64_t *__restrict__ ks,
-                                                              const uint32_t *__restrict__ vs, uint64_t m, uint64_t kmask,
-                                                              uint32_t kbits, uint32_t *__restrict__ apos,
-                                                              uint32_t *__restrict__ ap, uint8_t *__restrict__ ahead,
-                                                              uint32_t cap, uint32_t *__restrict__ seedw,
-                                                              uint64_t *__restrict__ status, uint32_t epoch)
+__global__ __launch_bounds__(kBlock) void tied_mark_kernel(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ vs,
+                                                           uint64_t m, uint64_t kmask, uint32_t kbits,
+                                                           uint32_t *__restrict__ seedw, uint32_t *__restrict__ tile_count,
+                                                           uint2 *__restrict__ stage /* (sorted index, position) */,
+                                                           uint8_t *__restrict__ stage_head)
 {
     __shared__ uint64_t lds[kWavesPerBlock];
-    __shared__ uint32_t s_tile, s_prefix;
     const int t = (int)threadIdx.x;
-    // header words of the status buffer: [0] time-out flag, [1] ticket counter, [2] total (written by the last tile)
-    const uint32_t ntiles = (uint32_t)((m + kTiedTile - 1) / kTiedTile);
-    for (;;) { // workgroups keep taking tiles: the grid bounds how many tiles, hence look-back hops, are in flight
-    if (t == 0) s_tile = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(status + 1), 1ull);
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= ntiles) break; // uniform
+    const uint32_t tile = blockIdx.x;
     uint32_t fmask = 0, hmask = 0; // tied / group head, bit 8 s + i = key i of this thread in sub-tile s
     uint64_t counts = 0;           // tied keys of this thread per sub-tile, 16-bit fields
 #pragma unroll
@@ -312,16 +304,14 @@ __global__ __launch_bounds__(kBlock) void tied_compact_kernel(const uint64_t *__
     // tied keys before this thread inside each sub-tile (one packed scan), and per sub-tile in all
     uint64_t tot;
     const uint64_t ex = block_exclusive_sum64(counts, lds, tot);
-    uint32_t tile_total = 0;
+    if (t == 0) {
+        uint32_t tile_total = 0;
 #pragma unroll
-    for (int sub = 0; sub < kTiedSub; ++sub) tile_total += (uint32_t)(tot >> (16 * sub)) & 0xFFFFu;
-    if (wave_id() == 0) { // tied members in earlier tiles
-        const uint32_t before = chain_exclusive_prefix_wave(status, 1u, tile, 0u, tile_total, epoch);
-        if (t == 0) s_prefix = before;
+        for (int sub = 0; sub < kTiedSub; ++sub) tile_total += (uint32_t)(tot >> (16 * sub)) & 0xFFFFu;
+        tile_count[tile] = tile_total;
     }
-    __syncthreads();
     if (fmask) {
-        uint32_t sub_base = s_prefix;
+        uint32_t sub_base = 0;
 #pragma unroll
         for (int sub = 0; sub < kTiedSub; ++sub) {
             const uint64_t j0 = (uint64_t)tile * kTiedTile + (uint64_t)sub * kTiedSubTile + (uint64_t)t * kTiedItems;
@@ -329,19 +319,34 @@ __global__ __launch_bounds__(kBlock) void tied_compact_kernel(const uint64_t *__
 #pragma unroll
             for (int i = 0; i < kTiedItems; ++i) {
                 if ((fmask >> (8 * sub + i)) & 1u) {
-                    if (slot < cap) {
-                        apos[slot] = (uint32_t)(j0 + i);
-                        ap[slot] = vs[j0 + i];
-                        ahead[slot] = (uint8_t)((hmask >> (8 * sub + i)) & 1u);
-                    }
+                    const uint64_t at = (uint64_t)tile * kTiedTile + slot;
+                    uint2 e;
+                    e.x = (uint32_t)(j0 + i), e.y = vs[j0 + i];
+                    stage[at] = e;
+                    stage_head[at] = (uint8_t)((hmask >> (8 * sub + i)) & 1u);
                     ++slot;
                 }
             }
             sub_base += (uint32_t)(tot >> (16 * sub)) & 0xFFFFu;
         }
     }
-    if (t == 0 && tile + 1 == ntiles) status[2] = (uint64_t)(s_prefix + tile_total); // the last tile
-    __syncthreads(); // s_tile and s_prefix are rewritten by the next round
+}
+
+__global__ __launch_bounds__(kBlock) void tied_gather_kernel(const uint32_t *__restrict__ tile_count,
+                                                             const uint32_t *__restrict__ tile_off,
+                                                             const uint2 *__restrict__ stage,
+                                                             const uint8_t *__restrict__ stage_head,
+                                                             uint32_t *__restrict__ apos, uint32_t *__restrict__ ap,
+                                                             uint8_t *__restrict__ ahead, uint32_t cap)
+{
+    const uint32_t tile = blockIdx.x, cnt = tile_count[tile], off = tile_off[tile];
+    for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
+        const uint32_t slot = off + i;
+        if (slot >= cap) break;
+        const uint2 e = stage[(uint64_t)tile * kTiedTile + i];
+        apos[slot] = e.x;
+        ap[slot] = e.y;
+        ahead[slot] = stage_head[(uint64_t)tile * kTiedTile + i];
     }
 }
 
@@ -571,6 +576,7 @@ size_t sx_lms_prefix_bytes(uint64_t m)
     b += 3 * (cap * 8 + a); // refinement keys: kept copy + sort ping-pong
     b += 8 * (cap * 4 + a); // apos x2, ap x2, ap_new, agid, order x2
     b += 3 * (cap + a);     // heads
+    b += 2 * ((m / 8192 + 2) * 4 + a); // tie counts and offsets per tile of the sorted keys
     return b + 4096;
 }
 
@@ -609,7 +615,9 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint8_t *head = am.take<uint8_t>(cap), *head2 = am.take<uint8_t>(cap), *head_new = am.take<uint8_t>(cap);
     uint32_t *seedw = am.take<uint32_t>(m);
     uint32_t *d_scalar = am.take<uint32_t>(16);
-    if (!seedw || !ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
+    const uint32_t tied_tiles = sx_div_up(m, kTiedTile);
+    uint32_t *tile_cnt = am.take<uint32_t>(tied_tiles), *tile_pos = am.take<uint32_t>(tied_tiles);
+    if (!tile_cnt || !tile_pos || !seedw || !ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
         !agid || !ord_a || !ord_b || !head || !head2 || !head_new || !d_scalar)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
     const dim3 block(kBlock);
@@ -671,16 +679,15 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         // members of groups with equal keys
         {
             const uint32_t tiles = sx_div_up(m, kTiedTile);
-            const uint32_t tied_grid = 2048; // measured at m = 3.1e8: 256 workgroups 3.4 ms, 512 2.2, 1024-2048 1.8, one per tile 2.2
-            SX_TRY(sx_chain_slab(ctx, SX_SLAB_CHAIN, ((size_t)tiles + kChainHeader) * sizeof(uint64_t)));
-            uint64_t *status = (uint64_t *)ctx->slab[SX_SLAB_CHAIN].p;
-            SX_CHECK(hipMemsetAsync(status, 0, kChainHeader * sizeof(uint64_t), ctx->stream));
-            sx_launch(ctx, SX_KC_NAMES, m * 16, tied_compact_kernel, dim3(tiles < tied_grid ? tiles : tied_grid), block, ks, (const uint32_t *)vs, m, kmask,
-                      (uint32_t)kbits, apos, ap, head, cap, embed ? seedw : nullptr, status, sx_chain_next_epoch(ctx));
-            uint32_t hdr[6];
-            SX_TRY(sx_readback(ctx, (const uint32_t *)status, 6, hdr));
-            if (hdr[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "tie detection: a look-back wait timed out");
-            A = hdr[4];
+            // staging in the sort's spare buffers: 8 bytes per slot in the other key array, heads in the other value array
+            uint2 *stage = (uint2 *)(in_b ? ka : kb);
+            uint8_t *stage_head = (uint8_t *)(in_b ? va : vb);
+            sx_launch(ctx, SX_KC_NAMES, m * 13, tied_mark_kernel, dim3(tiles), block, ks, (const uint32_t *)vs, m, kmask,
+                      (uint32_t)kbits, embed ? seedw : nullptr, tile_cnt, stage, stage_head);
+            SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_cnt}, OutExclusive{tile_pos}, d_scalar, SX_KC_NAMES, 0)));
+            sx_launch(ctx, SX_KC_NAMES, 0, tied_gather_kernel, dim3(tiles), block, (const uint32_t *)tile_cnt,
+                      (const uint32_t *)tile_pos, (const uint2 *)stage, (const uint8_t *)stage_head, apos, ap, head, cap);
+            SX_TRY(sx_readback(ctx, d_scalar, 1, &A));
         }
         ctx->stats.n_names = m - A; // suffixes told apart by the first sort
         ctx->stats.key_slots = C;
