@@ -542,14 +542,19 @@ struct fasta_records *load_fasta_records(const char *fname, enum error_codes *er
     fseek(f, 0, SEEK_SET);
     uint8_t *image = malloc((size_t)fsize + 1);
     uint8_t *packed = malloc((size_t)fsize + 2);
-    uint32_t *term = malloc(((size_t)fsize + 2) * sizeof *term);
-    if (!image || !packed || !term) die("load_fasta_records: out of memory", -2, NULL);
+    if (!image || !packed) die("load_fasta_records: out of memory", -2, NULL);
     if (fsize && fread(image, (size_t)fsize, 1, f) != 1) die("load_fasta_records: read failed", -1, NULL);
     fclose(f);
+    /* every record but the first starts at a '>', and every record has two terminators: a bound for the table */
+    size_t starts = 1;
+    for (const uint8_t *p = image, *end = image + fsize; (p = memchr(p, '>', (size_t)(end - p))) != NULL; ++p) ++starts;
+    const uint64_t term_cap = 2 * (uint64_t)starts + 2;
+    uint32_t *term = malloc(term_cap * sizeof *term);
+    if (!term) die("load_fasta_records: out of memory", -2, NULL);
     sx_ctx *ctx = thread_ctx();
     uint64_t packed_len = 0;
     uint32_t n = 0;
-    const int rc = sx_fasta_pack(ctx, image, (uint64_t)fsize, packed, &packed_len, term, (uint64_t)fsize + 2, &n);
+    const int rc = sx_fasta_pack(ctx, image, (uint64_t)fsize, packed, &packed_len, term, term_cap, &n);
     free(image);
     if (rc == SX_E_MALFORMED) {
         free(packed);
