@@ -598,7 +598,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     // shortest prefix that tells ~97 % of m suffixes of a uniformly random text apart
     uint32_t C = 1;
     {
-        const double eff = ti.maxc > 2 ? (double)ti.maxc : 2.0, target = 32.0 * (double)m;
+        // (the direct sort of all suffixes accepts twice the ties to stay within 40 key bits at 32, 128, ... symbols)
+        const double eff = ti.maxc > 2 ? (double)ti.maxc : 2.0, target = (all_suffixes ? 16.0 : 32.0) * (double)m;
         double v = eff;
         while (v < target && C < Cmax) {
             v *= eff;
