@@ -5,12 +5,15 @@
 // its newline (fasta.c:26-48); a sequence loses all white space and ends at the next '>',
 // wherever it stands, or at the end of the file (fasta.c:50-70).  Whether a byte belongs to a
 // header or to a sequence depends only on the last '\n' or '>' before it ('\n' -> sequence,
-// '>' -> header, none -> header), so the sequential packing loop becomes
-//   1. a max-scan carrying (position, kind) of the last such byte -> a code per byte
-//      (drop / keep / header terminator / sequence terminator),
-//   2. a stream compaction of the kept bytes and terminators -> the packed image,
-//   3. a compaction of the terminator positions -> the record table (terminators alternate
-//      header, sequence, header, ...).
+// '>' -> header, none -> header), so the sequential packing loop becomes three passes over
+// 4096-byte tiles with 16 bytes per thread in registers:
+//   1. (position, kind) of the last such byte of every tile; a max-scan over the tiles gives each
+//      tile its entry state,
+//   2. every thread walks its 16 bytes in the right state and counts what it emits (kept bytes,
+//      terminators); sum-scans over the tiles give each tile its place in the packed image and in
+//      the terminator table,
+//   3. the same walk again, writing the packed image and the terminator positions (terminators
+//      alternate header, sequence, header, ...: the record table).
 // stralg/remap.c:8-31,102-114 (build table from the symbols present, relabel) is a presence
 // histogram, a 256-entry table built on the host, and a streaming lookup.
 #include "sx_common.hpp"
@@ -30,70 +33,143 @@ __global__ __launch_bounds__(kBlock) void fasta_first_nul_kernel(const uint8_t *
         if (file[i] == 0) atomicMin(first, (uint32_t)i);
 }
 
-// byte i of the image, with the terminating NUL the reference's buffer holds at `end`
-struct FastaIn {
-    const uint8_t *file;
-    uint64_t end;
-    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
-    {
-        const uint32_t b = i < end ? file[i] : 0u;
-        if (b == '\n') return ((uint32_t)(i + 1) << 1) | 1u;
-        if (b == '>') return (uint32_t)(i + 1) << 1;
-        return 0u;
+// ---- packing: three passes over tiles of 4096 bytes, 16 bytes per thread in registers ------------------------
+constexpr int kFaPer = 16, kFaTile = kBlock * kFaPer;
+
+// the thread's 16 bytes (zero beyond `end`: position `end` itself is the terminating NUL of the reference's buffer)
+__device__ __forceinline__ void fasta_load16(const uint8_t *__restrict__ file, uint64_t i0, uint64_t end, uint32_t (&b)[kFaPer])
+{
+    if (i0 + kFaPer <= end && ((uintptr_t)(file + i0) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(file + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < kFaPer; ++k) b[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kFaPer; ++k) b[k] = i0 + k < end ? (uint32_t)file[i0 + k] : 0u;
     }
-};
-enum { FA_DROP = 0, FA_KEEP = 1, FA_NAME_END = 2, FA_SEQ_END = 3 };
-struct FastaCode {
-    const uint8_t *file;
-    uint64_t end;
-    uint8_t *code;
-    uint32_t *flags; // [0] set: the image ends inside a header line; [1] position of the first header terminator
-    __device__ __forceinline__ void operator()(uint64_t i, uint32_t last, uint32_t) const
-    {
-        const uint32_t b = i < end ? file[i] : 0u;
-        const bool in_seq = last != 0 && (last & 1u);
-        uint32_t c;
-        if (in_seq) {
-            c = (b == '>' || i >= end) ? FA_SEQ_END : (fasta_space(b) ? FA_DROP : FA_KEEP);
-        } else if (i >= end) {
-            c = FA_DROP;
-            atomicOr(&flags[0], 1u);
-        } else if (b == '\n') {
-            c = FA_NAME_END;
-            atomicMin(&flags[1], (uint32_t)i);
-        } else {
-            c = (b == '>' || b == ' ' || b == '\t') ? FA_DROP : FA_KEEP;
+}
+
+// (position + 1, kind) of the last '\n' (kind 1: a sequence follows) or '>' (kind 0: a header follows) among the bytes
+__device__ __forceinline__ uint32_t fasta_last_special(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end)
+{
+    uint32_t last = 0;
+#pragma unroll
+    for (int k = 0; k < kFaPer; ++k) {
+        if (i0 + k < end) {
+            if (b[k] == '\n') last = ((uint32_t)(i0 + k + 1) << 1) | 1u;
+            else if (b[k] == '>') last = (uint32_t)(i0 + k + 1) << 1;
         }
-        code[i] = (uint8_t)c;
     }
+    return last;
+}
+
+// What the packing loop of fasta.c:26-70 does with these bytes, entered in header or sequence state:
+// emit: bytes that reach the packed image (kept characters and terminators), term: the terminators among them,
+// name_end: header terminators; eof_in_name: the image ends inside a header line (MALFORMED_FILE).
+struct fa_chunk {
+    uint32_t emit, term, name_end;
+    bool eof_in_name;
 };
-struct FastaEmit {
-    const uint8_t *code;
-    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return code[i] != FA_DROP ? 1u : 0u; }
-};
-struct FastaWrite {
-    const uint8_t *file, *code;
-    uint8_t *packed;
-    uint32_t *scal; // [2] position of the first header terminator in the file -> [0] its position in the packed image
-    __device__ __forceinline__ void operator()(uint64_t i, uint32_t dst, uint32_t f) const
-    {
-        if (!f) return;
-        packed[dst] = code[i] == FA_KEEP ? file[i] : (uint8_t)0;
-        if (code[i] == FA_NAME_END && (uint32_t)i == scal[2]) scal[0] = dst;
+__device__ __forceinline__ fa_chunk fasta_walk(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end, bool in_seq)
+{
+    fa_chunk r{0, 0, 0, false};
+#pragma unroll
+    for (int k = 0; k < kFaPer; ++k) {
+        const uint64_t i = i0 + k;
+        if (i > end) continue;
+        const uint32_t c = b[k], bit = 1u << k;
+        if (in_seq) {
+            if (c == '>' || i == end) {
+                r.emit |= bit, r.term |= bit; // the sequence's terminator
+                in_seq = false;
+            } else if (!fasta_space(c)) {
+                r.emit |= bit;
+            }
+        } else if (i == end) {
+            r.eof_in_name = true;
+        } else if (c == '\n') {
+            r.emit |= bit, r.term |= bit, r.name_end |= bit; // the header's terminator
+            in_seq = true;
+        } else if (!(c == '>' || c == ' ' || c == '\t')) {
+            r.emit |= bit;
+        }
     }
-};
-struct FastaIsTerm {
-    const uint8_t *packed;
-    __device__ __forceinline__ uint32_t operator()(uint64_t j) const { return packed[j] == 0 ? 1u : 0u; }
-};
-struct FastaTermOut {
-    uint32_t *term;
-    uint64_t cap;
-    __device__ __forceinline__ void operator()(uint64_t j, uint32_t dst, uint32_t f) const
-    {
-        if (f && dst < cap) term[dst] = (uint32_t)j;
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void fasta_tile_last_kernel(const uint8_t *__restrict__ file, uint64_t end,
+                                                                 uint32_t *__restrict__ tile_last)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
+    uint32_t b[kFaPer];
+    fasta_load16(file, i0, end, b);
+    const uint32_t tot = block_reduce<OpMax>(fasta_last_special(b, i0, end), lds);
+    if (threadIdx.x == 0) tile_last[blockIdx.x] = tot;
+}
+
+// state of every thread's first byte = kind of the last special byte before it (none: header)
+__device__ __forceinline__ bool fasta_enter_state(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end, uint32_t tile_carry,
+                                                  uint32_t *lds)
+{
+    uint32_t tot;
+    const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(b, i0, end), lds, tot);
+    const uint32_t last = before > tile_carry ? before : tile_carry;
+    return last != 0 && (last & 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void fasta_count_kernel(const uint8_t *__restrict__ file, uint64_t end,
+                                                             const uint32_t *__restrict__ tile_carry,
+                                                             uint32_t *__restrict__ tile_emit, uint32_t *__restrict__ tile_term,
+                                                             uint32_t *__restrict__ scal /* [1] malformed, [2] first header end */)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
+    uint32_t b[kFaPer];
+    fasta_load16(file, i0, end, b);
+    const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[blockIdx.x], lds);
+    const fa_chunk c = fasta_walk(b, i0, end, in_seq);
+    if (c.eof_in_name) atomicOr(&scal[1], 1u);
+    if (c.name_end) atomicMin(&scal[2], (uint32_t)(i0 + (uint32_t)(__ffs(c.name_end) - 1)));
+    const uint32_t tot = block_reduce<OpAdd>((uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16), lds);
+    if (threadIdx.x == 0) {
+        tile_emit[blockIdx.x] = tot & 0xFFFFu;
+        tile_term[blockIdx.x] = tot >> 16;
     }
-};
+}
+
+__global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__restrict__ file, uint64_t end,
+                                                             const uint32_t *__restrict__ tile_carry,
+                                                             const uint32_t *__restrict__ tile_eoff,
+                                                             const uint32_t *__restrict__ tile_toff, uint8_t *__restrict__ packed,
+                                                             uint32_t *__restrict__ term_out, uint64_t term_cap,
+                                                             uint32_t *__restrict__ scal /* [2] first header end -> [0] its packed position */)
+{
+    __shared__ uint32_t lds[kWavesPerBlock];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
+    uint32_t b[kFaPer];
+    fasta_load16(file, i0, end, b);
+    const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[blockIdx.x], lds);
+    const fa_chunk c = fasta_walk(b, i0, end, in_seq);
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<OpAdd>((uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16), lds, tot);
+    uint32_t out = tile_eoff[blockIdx.x] + (ex & 0xFFFFu), tq = tile_toff[blockIdx.x] + (ex >> 16);
+    const uint32_t first_end = scal[2];
+#pragma unroll
+    for (int k = 0; k < kFaPer; ++k) {
+        if ((c.emit >> k) & 1u) {
+            const bool is_term = (c.term >> k) & 1u;
+            packed[out] = is_term ? (uint8_t)0 : (uint8_t)b[k];
+            if (is_term) {
+                if (term_out && tq < term_cap) term_out[tq] = out;
+                ++tq;
+                if (((c.name_end >> k) & 1u) && (uint32_t)(i0 + k) == first_end) scal[0] = out;
+            }
+            ++out;
+        }
+    }
+}
 
 // which byte values occur: 256 flags as 8 words
 __global__ __launch_bounds__(kBlock) void remap_present_kernel(const uint8_t *__restrict__ in, uint64_t n,
@@ -172,10 +248,13 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
     SX_CHECK(hipSetDevice(ctx->device));
     *packed_len_out = 0;
     *n_records_out = 0;
-    // scratch: one code per byte (+ the virtual terminator) and four scalars
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, file_len + 1 + 256 + 64));
-    uint32_t *scal = (uint32_t *)ctx->slab[SX_SLAB_N].p; // [0] first NUL, [1] malformed, [2] first header end, [3] totals
-    uint8_t *code = (uint8_t *)ctx->slab[SX_SLAB_N].p + 256;
+    // scratch: four scalars and five u32 per 4096-byte tile
+    const uint64_t span_max = file_len + 1;
+    const uint32_t tiles_max = sx_div_up(span_max, kFaTile);
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, 256 + (size_t)5 * tiles_max * sizeof(uint32_t) + 1024));
+    uint32_t *scal = (uint32_t *)ctx->slab[SX_SLAB_N].p; // [0] first NUL / packed position, [1] malformed, [2] first header end
+    uint32_t *tile_last = scal + 64, *tile_carry = tile_last + tiles_max, *tile_emit = tile_carry + tiles_max,
+             *tile_term = tile_emit + tiles_max, *tile_eoff = tile_term + tiles_max;
     const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
     SX_CHECK(hipMemcpyAsync(scal, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     uint32_t first_nul = 0xFFFFFFFFu;
@@ -187,19 +266,22 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
     }
     const uint64_t end = first_nul < file_len ? first_nul : file_len;
     const uint64_t span = end + 1; // with the terminating NUL of the reference's buffer
-    SX_TRY((device_scan<OpMax>(ctx, span, FastaIn{d_file, end}, FastaCode{d_file, end, code, scal + 1}, nullptr, SX_KC_MISC,
-                               span * 3)));
-    SX_TRY((device_compact(ctx, span, FastaEmit{code}, FastaWrite{d_file, code, d_packed_out, scal}, scal + 3, SX_KC_MISC, span * 3)));
-    uint32_t h[4];
-    SX_TRY(sx_readback(ctx, scal, 4, h));
-    const uint64_t packed_len = h[3];
-    *packed_len_out = packed_len;
-    uint32_t n_term = 0;
-    if (packed_len) {
-        SX_TRY((device_compact(ctx, packed_len, FastaIsTerm{d_packed_out}, FastaTermOut{d_term_out, d_term_out ? term_cap : 0},
-                               scal + 3, SX_KC_MISC, packed_len * 2)));
-        SX_TRY(sx_readback(ctx, scal + 3, 1, &n_term));
-    }
+    const uint32_t tiles = sx_div_up(span, kFaTile);
+    const dim3 grid(tiles), block(kBlock);
+    sx_launch(ctx, SX_KC_MISC, span, fasta_tile_last_kernel, grid, block, d_file, end, tile_last);
+    SX_TRY((device_scan<OpMax>(ctx, tiles, InU32{tile_last}, OutExclusive{tile_carry}, nullptr, SX_KC_MISC, 0)));
+    sx_launch(ctx, SX_KC_MISC, span, fasta_count_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry, tile_emit,
+              tile_term, scal);
+    // (tile_last is free again: the terminator offsets go there)
+    uint32_t *tile_toff = tile_last;
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_emit}, OutExclusive{tile_eoff}, scal + 3, SX_KC_MISC, 0)));
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_term}, OutExclusive{tile_toff}, scal + 4, SX_KC_MISC, 0)));
+    sx_launch(ctx, SX_KC_MISC, span * 2, fasta_write_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry,
+              (const uint32_t *)tile_eoff, (const uint32_t *)tile_toff, d_packed_out, d_term_out, d_term_out ? term_cap : 0, scal);
+    uint32_t h[5];
+    SX_TRY(sx_readback(ctx, scal, 5, h));
+    *packed_len_out = h[3];
+    const uint32_t n_term = h[4];
     *n_records_out = n_term / 2;
     // MALFORMED_FILE (fasta.c:121-124): the image ends inside a header line -- or, because the reference packs in
     // place, the first header line had nothing to drop, so that its terminator overwrote the newline being examined
