@@ -93,33 +93,42 @@ template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v,
     return total;
 }
 
-// Lanes of the wave holding the same BITS-bit digit (and valid) as this lane.
-template <int BITS> __device__ __forceinline__ uint64_t match_any(uint32_t digit, bool valid)
-{
-    uint64_t peers = __ballot(valid ? 1 : 0);
-#pragma unroll
-    for (int b = 0; b < BITS; ++b) {
-        const bool bit = (digit >> b) & 1u;
-        const uint64_t m = __ballot(bit ? 1 : 0);
-        peers &= bit ? m : ~m;
-    }
-    return valid ? peers : 0ull;
-}
-
 // Stable ranking step shared by the radix scatter and the induce scatter:
 // items are presented wave by wave in (item k, lane) order; `counter` is this
 // wave's LDS counter row (one u32 per digit).  Returns the rank of the item
 // among the wave's items with the same digit seen so far.
-template <int BITS>
-__device__ __forceinline__ uint32_t wave_rank_step(uint32_t digit, bool valid, uint32_t *counter)
+// The lanes holding the same digit are found bit by bit (a ballot per bit).  The ranking of a radix pass is
+// bound by vector instructions, not by memory, so each step is kept to four: bit b of the digit is spread over
+// a register (x), compared (the ballot m), and each half of the peer mask keeps the lanes whose bit equals this
+// lane's with one three-input bit operation, p & ~(m ^ x); the rank comes from mbcnt.  Every lane reads the
+// digit's counter before the group's first lane adds the group's size: the LDS executes a wave's operations in
+// order, so no value has to come back from the atomic and be passed around.  ALL: every lane is valid.
+template <int BITS, bool ALL>
+__device__ __forceinline__ uint32_t wave_rank_inorder(uint32_t digit, bool valid, uint32_t *counter)
 {
-    const uint64_t peers = match_any<BITS>(digit, valid);
-    const uint32_t r = (uint32_t)__popcll(peers & lanemask_lt());
-    uint32_t old = 0;
-    if (valid && r == 0) old = atomicAdd(&counter[digit], (uint32_t)__popcll(peers));
-    const int leader = peers ? (__ffsll((unsigned long long)peers) - 1) : lane_id();
-    old = __shfl(old, leader, kWave);
+    uint32_t lo = ~0u, hi = ~0u;
+    if (!ALL) {
+        const uint64_t v = __ballot(valid ? 1 : 0);
+        lo = (uint32_t)v;
+        hi = (uint32_t)(v >> 32);
+    }
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const uint32_t x = (uint32_t)((int32_t)(digit << (31 - b)) >> 31);
+        const uint64_t m = __ballot(x != 0u ? 1 : 0);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m, x, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m >> 32), x, 0x90);
+    }
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    const uint32_t old = counter[(ALL || valid) ? digit : 0u];
+    __builtin_amdgcn_wave_barrier();
+    if ((ALL || valid) && r == 0) atomicAdd(&counter[digit], (uint32_t)(__popc(lo) + __popc(hi)));
+    __builtin_amdgcn_wave_barrier();
     return old + r;
+}
+template <int BITS> __device__ __forceinline__ uint32_t wave_rank_step(uint32_t digit, bool valid, uint32_t *counter)
+{
+    return wave_rank_inorder<BITS, false>(digit, valid, counter);
 }
 
 // ---- chained scan across workgroups (decoupled look-back) ------------------------------

@@ -140,46 +140,32 @@ __global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restric
     }
 }
 
-// (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
-// IOTA: the values of the input are its indices 0, 1, 2, ... (the first pass of a sort of all positions): not read
-template <bool IOTA>
-__global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
-    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
-    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
-    uint32_t ntiles, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift,
-    uint32_t next_mask)
+// One tile of the scatter.  FULL: the tile lies inside the input (all but the last one): no bound checks.
+// IOTA: the values of the input are its indices 0, 1, 2, ... (the first pass of a sort of all positions): not read.
+template <bool IOTA, bool FULL>
+__device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                   uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint64_t n,
+                                                   int shift, uint32_t mask, uint32_t tile, uint32_t first_out,
+                                                   uint8_t *__restrict__ dig_out, int next_shift, uint32_t next_mask,
+                                                   uint32_t (*wcount)[256], uint32_t *goff, uint32_t *scan_lds,
+                                                   uint64_t *skey)
 {
-    __shared__ uint32_t wcount[kRW][256]; // per-wave digit counters, then wave bases
-    __shared__ uint32_t dbase[256];                  // first slot of each digit inside the tile
-    __shared__ uint32_t goff[256];                   // global offset of the digit minus dbase
-    __shared__ uint32_t scan_lds[kRW];
-    __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
-
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    // Workgroups are dealt round robin to the 8 XCDs, each with its own L2.  Tiles that follow each other write
-    // runs that follow each other (per digit), so XCD x takes the x-th eighth of the tiles, in order: the two
-    // halves of a cache line shared by neighbouring runs then meet in one L2 instead of leaving two as partial lines.
-    const uint32_t per_xcd = (ntiles + 7u) / 8u;
-    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles) return; // uniform
-    const uint32_t first_out = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // asked for now, needed after the ranking
-    for (int i = t; i < kRW * 256; i += kRT) (&wcount[0][0])[i] = 0;
-    __syncthreads();
-
     const uint64_t tile0 = (uint64_t)tile * kRadixTile;
     const uint64_t wave0 = tile0 + (uint64_t)w * (kWave * kRadixItems);
     uint64_t key[kRadixItems];
-    uint32_t lpos[kRadixItems]; // rank within (wave, digit), then slot in the tile's digit order
+    uint32_t lpos[kRadixItems]; // [12:0] rank within (wave, digit), then slot in the tile's digit order; [31:16] digit
+    static_assert(kRadixTile <= 65536, "slot and digit share a register");
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        key[k] = i < n ? kin[i] : ~0ull;
+        key[k] = (FULL || i < n) ? kin[i] : ~0ull;
     }
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
         const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-        lpos[k] = wave_rank_step<8>(d, i < n, wcount[w]);
+        lpos[k] = wave_rank_inorder<8, FULL>(d, FULL || i < n, wcount[w]) | (d << 16);
     }
     __syncthreads();
     {
@@ -198,26 +184,23 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
         __syncthreads();
         uint32_t base = 0;
         for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
-        const uint32_t ex = base + inc - s;
+        const uint32_t ex = base + inc - s; // first slot of the digit inside the tile
         if (t < 256) {
-            dbase[d] = ex;
+#pragma unroll
+            for (int ww = 0; ww < kRW; ++ww) wcount[ww][d] += ex; // first slot of (wave, digit)
             goff[d] = first_out - ex;
         }
     }
     __syncthreads();
     // A large tile keeps the runs per digit long, so the LDS image is used twice, for the keys
     // and then for the values, instead of holding both.
-#pragma unroll
-    for (int k = 0; k < kRadixItems; ++k) {
-        const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-        lpos[k] += dbase[d] + wcount[w][d];
-    }
     const uint64_t left = n - tile0;
-    const uint32_t cnt = left < (uint64_t)kRadixTile ? (uint32_t)left : (uint32_t)kRadixTile;
+    const uint32_t cnt = FULL || left >= (uint64_t)kRadixTile ? (uint32_t)kRadixTile : (uint32_t)left;
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        if (i < n) skey[lpos[k]] = key[k];
+        lpos[k] = (lpos[k] & 0xFFFFu) + wcount[w][lpos[k] >> 16];
+        if (FULL || i < n) skey[lpos[k]] = key[k];
     }
     __syncthreads();
     uint32_t dstv[kRadixItems]; // destinations of the slots this thread copies out
@@ -225,7 +208,7 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     for (int k = 0; k < kRadixItems; ++k) {
         const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
         dstv[k] = 0;
-        if (i < cnt) {
+        if (FULL || i < cnt) {
             const uint64_t kk = skey[i];
             const uint32_t d = (uint32_t)(kk >> shift) & mask;
             dstv[k] = goff[d] + i;
@@ -238,14 +221,45 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        if (i < n) sval[lpos[k]] = IOTA ? (uint32_t)i : vin[i]; // the values are only read now: fewer live registers
+        if (FULL || i < n) sval[lpos[k]] = IOTA ? (uint32_t)i : vin[i]; // the values are only read now: fewer live registers
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
-        if (i < cnt) vout[dstv[k]] = sval[i];
+        if (FULL || i < cnt) vout[dstv[k]] = sval[i];
     }
+}
+
+// (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
+template <bool IOTA>
+__global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
+    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
+    uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
+    uint32_t ntiles, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift,
+    uint32_t next_mask)
+{
+    __shared__ uint32_t wcount[kRW][256]; // per-wave digit counters, then the first slot of each (wave, digit)
+    __shared__ uint32_t goff[256];        // global offset of the digit minus its first slot inside the tile
+    __shared__ uint32_t scan_lds[kRW];
+    __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
+
+    const int t = (int)threadIdx.x;
+    // Workgroups are dealt round robin to the 8 XCDs, each with its own L2.  Tiles that follow each other write
+    // runs that follow each other (per digit), so XCD x takes the x-th eighth of the tiles, in order: the two
+    // halves of a cache line shared by neighbouring runs then meet in one L2 instead of leaving two as partial lines.
+    const uint32_t per_xcd = (ntiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return; // uniform
+    const uint32_t first_out = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // asked for now, needed after the ranking
+    for (int i = t; i < kRW * 256; i += kRT) (&wcount[0][0])[i] = 0;
+    __syncthreads();
+    if ((uint64_t)(tile + 1) * kRadixTile <= n) // uniform
+        radix_scatter_tile<IOTA, true>(kin, vin, kout, vout, n, shift, mask, tile, first_out, dig_out, next_shift, next_mask,
+                                       wcount, goff, scan_lds, skey);
+    else
+        radix_scatter_tile<IOTA, false>(kin, vin, kout, vout, n, shift, mask, tile, first_out, dig_out, next_shift, next_mask,
+                                        wcount, goff, scan_lds, skey);
 }
 
 } // namespace sx

@@ -151,6 +151,29 @@ static inline int __builtin_amdgcn_readfirstlane(int x)
     return (int)(unsigned)v[__builtin_ctzll(live)];
 }
 
+// wave-level helpers of the ranking code: a scheduling barrier is a rendezvous of the wave's fibers here
+static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(0); }
+static inline unsigned emu_bitop3(unsigned a, unsigned b, unsigned c, unsigned tt)
+{
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) {
+        const unsigned idx = (((a >> i) & 1u) << 2) | (((b >> i) & 1u) << 1) | ((c >> i) & 1u);
+        r |= ((tt >> idx) & 1u) << i;
+    }
+    return r;
+}
+#define __builtin_amdgcn_bitop3_b32(a, b, c, tt) emu_bitop3((a), (b), (c), (tt))
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned add)
+{
+    const int l = emu_lane();
+    return add + (unsigned)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned add)
+{
+    const int l = emu_lane();
+    return add + (l > 32 ? (unsigned)__builtin_popcount(m & ((1u << (l - 32)) - 1u)) : 0u);
+}
+
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
