@@ -85,7 +85,8 @@ void sx_ctx_trim(sx_ctx *ctx);
 enum {
     SX_FLAG_FORCE_GENERAL_PATH = 1, /* skip the prefix-key LMS sort: always pieces + names + prefix doubling */
     SX_FLAG_CHAIN_MAX_ENTRIES = 2,  /* induce rounds up to this many entries use the single chained launch */
-    SX_FLAG_NO_DIRECT_SORT = 3      /* wide alphabets: never sort all suffixes by prefix directly, always LMS sort + induction */
+    SX_FLAG_NO_DIRECT_SORT = 3,     /* wide alphabets: never sort all suffixes by prefix directly, always LMS sort + induction */
+    SX_FLAG_PREFIX_SYMBOLS = 4      /* first attempt of the prefix-key sort takes this many symbols (0: by the text's size) */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

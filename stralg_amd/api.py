@@ -214,6 +214,10 @@ class Context:
         """SX_FLAG_NO_DIRECT_SORT: wide alphabets take the LMS sort + induction even where the direct sort applies."""
         self._check(self.lib.sx_ctx_set_flag(self.h, 3, 1 if on else 0), "sx_ctx_set_flag")
 
+    def set_prefix_symbols(self, symbols):
+        """SX_FLAG_PREFIX_SYMBOLS: the prefix-key sort's first attempt takes this many symbols (0: by the size)."""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 4, int(symbols)), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

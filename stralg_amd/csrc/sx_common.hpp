@@ -72,6 +72,7 @@ struct sx_ctx {
     // profiling
     uint32_t chain_epoch = 0; // look-back status epoch (24 bits), see sx_device.hpp
     int64_t chain_max_override = -1; // SX_FLAG_CHAIN_MAX_ENTRIES; -1 = choose by alphabet size
+    int prefix_symbols = 0;          // SX_FLAG_PREFIX_SYMBOLS; 0 = choose by the number of suffixes
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int no_direct = 0;     // SX_FLAG_NO_DIRECT_SORT
     int prof_on = 0;

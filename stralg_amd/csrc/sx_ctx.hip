@@ -204,6 +204,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         ctx->no_direct = value ? 1 : 0;
         return 0;
     }
+    if (flag == SX_FLAG_PREFIX_SYMBOLS) {
+        ctx->prefix_symbols = value > 0 ? value : 0;
+        return 0;
+    }
     if (flag == SX_FLAG_CHAIN_MAX_ENTRIES) {
         ctx->chain_max_override = value < 0 ? -1 : (int64_t)value; // negative: back to the default
         return 0;

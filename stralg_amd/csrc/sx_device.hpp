@@ -103,6 +103,9 @@ template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v,
 // lane's with one three-input bit operation, p & ~(m ^ x); the rank comes from mbcnt.  Every lane reads the
 // digit's counter before the group's first lane adds the group's size: the LDS executes a wave's operations in
 // order, so no value has to come back from the atomic and be passed around.  ALL: every lane is valid.
+#ifndef SX_OPAQUE_VGPR // the CPU test harness defines it away
+#define SX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 template <int BITS, bool ALL>
 __device__ __forceinline__ uint32_t wave_rank_inorder(uint32_t digit, bool valid, uint32_t *counter)
 {
@@ -114,7 +117,8 @@ __device__ __forceinline__ uint32_t wave_rank_inorder(uint32_t digit, bool valid
     }
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
-        const uint32_t x = (uint32_t)((int32_t)(digit << (31 - b)) >> 31);
+        uint32_t x = (uint32_t)((int32_t)(digit << (31 - b)) >> 31);
+        SX_OPAQUE_VGPR(x); // compare x itself: the compiler would rather shift the digit once more for the test
         const uint64_t m = __ballot(x != 0u ? 1 : 0);
         lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m, x, 0x90);
         hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m >> 32), x, 0x90);

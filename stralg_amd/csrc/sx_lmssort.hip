@@ -37,18 +37,56 @@ namespace sx {
 // 24-bit multiply-adds, and the 64-bit accumulator is touched once per group (DNA: G = 10,
 // two groups for 17 symbols).  G is one of four compile-time sizes so that the group ends
 // are static; the last group is the short one.
+// Bases up to 6 (DNA + sentinel = 5) go four symbols at a time: the weights base^3, base^2, base, 1 of a
+// word's symbols fit a byte each, so one v_dot4_u32_u8 is the Horner step of a whole word; three words
+// (base^12 < 2^32) are joined with 24-bit multiply-adds before the 64-bit accumulator is touched.  17
+// symbols: 5 dot products, 3 short multiply-adds and one long one instead of 17 extract-multiply-add steps
+// (the key kernel is bound by vector instructions, not by memory).
 struct pkey_cfg {
     uint32_t base, C;
     uint32_t G;    // 10, 6, 4 or 3: the largest of these with base^G <= 2^24
     uint32_t powG; // base^G
     uint32_t powR; // base^(C mod G)
+    uint32_t dot;   // base <= 6: the dot-product form below
+    uint32_t coef4; // base^3 | base^2 << 8 | base << 16 | 1 << 24
+    uint32_t B4, B12, Br; // base^4, base^12, base^(C mod 4)
+    uint32_t powT;  // weight of the last, short group: base^(4 * ((C / 4) mod 3) + C mod 4)
 };
 static inline pkey_cfg pkey_make(uint32_t base, uint32_t C)
 {
-    pkey_cfg k{base, C, base <= 5 ? 10u : (base <= 16 ? 6u : (base <= 64 ? 4u : 3u)), 1, 1};
+    pkey_cfg k{base, C, base <= 5 ? 10u : (base <= 16 ? 6u : (base <= 64 ? 4u : 3u)), 1, 1, 0, 0, 1, 1, 1, 1};
     for (uint32_t i = 0; i < k.G; ++i) k.powG *= base;
     for (uint32_t i = 0; i < C % k.G; ++i) k.powR *= base;
+    if (base >= 2 && base <= 6 && C <= 32) {
+        k.dot = 1;
+        k.coef4 = (base * base * base) | (base * base) << 8 | base << 16 | 1u << 24;
+        for (uint32_t i = 0; i < 4; ++i) k.B4 *= base;
+        for (uint32_t i = 0; i < 12; ++i) k.B12 *= base;
+        for (uint32_t i = 0; i < C % 4; ++i) k.Br *= base;
+        for (uint32_t i = 0; i < 4 * ((C / 4) % 3) + C % 4; ++i) k.powT *= base;
+    }
     return k;
+}
+// kw[k] holds symbols 4k .. 4k+3 of the prefix, the first one in the low byte
+template <int NW> __device__ __forceinline__ uint64_t prefix_key_dot(const uint32_t (&kw)[NW], const pkey_cfg &kc)
+{
+    const uint32_t nw = kc.C >> 2, r = kc.C & 3u;
+    uint64_t acc = 0;
+    uint32_t g = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        if ((uint32_t)k < nw) { // uniform
+            g = __builtin_amdgcn_udot4(kw[k], kc.coef4, __umul24(g, kc.B4), false);
+            if (k % 3 == 2) { // static
+                acc = acc * kc.B12 + g;
+                g = 0;
+            }
+        } else if ((uint32_t)k == nw && r) { // uniform
+            g = __builtin_amdgcn_udot4(kw[k], kc.coef4 >> (8u * (4u - r)), __umul24(g, kc.Br), false);
+        }
+    }
+    if (kc.powT > 1) acc = acc * kc.powT + g; // uniform
+    return acc;
 }
 template <int G>
 __device__ __forceinline__ uint64_t prefix_key_grouped(const uint64_t (&q)[4], const pkey_cfg &kc)
@@ -70,6 +108,11 @@ __device__ __forceinline__ uint64_t prefix_key_grouped(const uint64_t (&q)[4], c
 }
 __device__ __forceinline__ uint64_t prefix_key_of(const uint64_t (&q)[4], const pkey_cfg &kc)
 {
+    if (kc.dot) { // uniform
+        const uint32_t kw[8] = {(uint32_t)q[0], (uint32_t)(q[0] >> 32), (uint32_t)q[1], (uint32_t)(q[1] >> 32),
+                                (uint32_t)q[2], (uint32_t)(q[2] >> 32), (uint32_t)q[3], (uint32_t)(q[3] >> 32)};
+        return prefix_key_dot<8>(kw, kc);
+    }
     switch (kc.G) { // uniform
     case 10: return prefix_key_grouped<10>(q, kc);
     case 6: return prefix_key_grouped<6>(q, kc);
@@ -89,10 +132,63 @@ __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, ui
     return acc;
 }
 
+// Key and window of a suffix for DNA-like texts with everything static: C key symbols of a base <= 6, a window
+// of CW two-bit codes.  The bytes text[p - CW .. p + C) come from the staged tile as nine aligned words and
+// one byte-align step each; window and key are dot products (sx_window.hpp, prefix_key_dot).  The key kernel
+// is bound by instruction issue (260 instructions per suffix with run-time C, base and window shape: 2.0 ms
+// at 1 GiB); this form needs about 90.
+template <int C, int CW>
+__device__ __forceinline__ uint64_t key_and_window_dna(const uint8_t *img, uint32_t off, const pkey_cfg &kc,
+                                                       uint32_t kbits)
+{
+    constexpr int B = 2;
+    static_assert(C >= 1 && CW >= 1 && CW <= 14 && C + CW <= 32, "window and key inside one 32-byte span");
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(img + (off & ~3u));
+    const uint32_t sh = off & 3u;
+    uint32_t raw[9], W[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) raw[k] = w32[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh); // bytes 4k .. 4k+3 of the span
+    W[8] = 0;
+    // window: span bytes 0 .. CW-1, the farthest symbol first (wnd_from_bytes with B = 2)
+    constexpr uint32_t wcoef = (1u << 24) | (1u << (16 + B)) | (1u << (8 + 2 * B)) | (1u << (3 * B));
+    uint32_t a = 0;
+#pragma unroll
+    for (int k = 0; k < (CW + 3) / 4; ++k) {
+        if (k < CW / 4) a = __builtin_amdgcn_udot4(W[k], wcoef, a << (4 * B), false);
+        else a = __builtin_amdgcn_udot4(W[k], wcoef >> ((8 * (4 - CW % 4)) & 31), a << ((CW % 4) * B), false);
+    }
+    constexpr uint32_t bias = ((1u << (B * CW)) - 1u) / 3u; // a one in each code field
+    const uint32_t wnd = ((a - bias) << kCntBits) | (uint32_t)CW;
+    // key: span bytes CW .. CW + C
+    constexpr int NW = (C + 3) / 4, R = C % 4, d0 = CW / 4, sb = 8 * (CW % 4);
+    static_assert(d0 + NW <= 8, "the key's words end inside the span");
+    uint64_t acc = 0;
+    uint32_t g = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const uint32_t kw = sb ? (W[d0 + k] >> sb) | (W[d0 + k + 1] << ((32 - sb) & 31)) : W[d0 + k];
+        if (k < C / 4) {
+            g = __builtin_amdgcn_udot4(kw, kc.coef4, k % 3 ? __umul24(g, kc.B4) : 0u, false);
+            if (k % 3 == 2) {
+                acc = k == 2 ? (uint64_t)g : acc * kc.B12 + g;
+                g = 0;
+            }
+        } else {
+            g = __builtin_amdgcn_udot4(kw, kc.coef4 >> ((8 * (4 - R)) & 31), __umul24(g, kc.Br), false);
+        }
+    }
+    if ((C / 4) % 3 || R) acc = acc * kc.powT + g;
+    return acc | (uint64_t)wnd << kbits;
+}
+
 // One workgroup per classification tile (4096 text positions): the tile's LMS positions are
 // listed in LDS from the LMS bit array, then every thread turns listed positions into
 // (key, position) pairs at the tile's offset in the global LMS order.  This is the compaction of
 // the LMS positions (role of sa_is.c:203-218 place_LMS's scan) and the key generation in one pass.
+// CS > 0: kc.C == CS, kc.dot, and the windows are WS two-bit codes (the host checks).
+template <int CS, int WS>
 __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__restrict__ T,
                                                                const uint16_t *__restrict__ lmsbits,
                                                                const uint32_t *__restrict__ tile_off, pkey_cfg kc,
@@ -128,21 +224,26 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
     for (uint32_t i = (uint32_t)t; i < total; i += kBlock) {
         const uint32_t p = spos[i];
         uint64_t key;
-        if (kc.C <= 32) { // uniform
-            uint64_t q[4];
-            lds_bytes32(img, (uint32_t)((uint64_t)p - origin), q);
-            key = prefix_key_of(q, kc);
+        if (CS > 0 && p >= (uint32_t)WS) { // (everywhere but at the very start of the text)
+            key = key_and_window_dna<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1)>(img, (uint32_t)((uint64_t)(p - (uint32_t)WS) - origin), kc, kbits);
         } else {
-            key = prefix_key(T, p, kc);
+            if (kc.C <= 32) { // uniform
+                uint64_t q[4];
+                lds_bytes32(img, (uint32_t)((uint64_t)p - origin), q);
+                key = prefix_key_of(q, kc);
+            } else {
+                key = prefix_key(T, p, kc);
+            }
+            // The key bits above kbits are not sorted on, they just ride along: put the suffix's
+            // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
+            // this part of the text is at hand, instead of gathering it again after the sort.
+            if (wcfg.CW) key |= (uint64_t)wnd_fill_lds<uint32_t>(img, origin, p, wcfg) << kbits;
         }
-        // The key bits above kbits are not sorted on, they just ride along: put the suffix's
-        // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
-        // this part of the text is at hand, instead of gathering it again after the sort.
-        if (wcfg.CW) key |= (uint64_t)wnd_fill_lds<uint32_t>(img, origin, p, wcfg) << kbits;
-        keys[dst0 + i] = key;
-        vals[dst0 + i] = p;
+        // written once, next read by another kernel: streaming stores (the sort's first pass gained 4 %)
+        __builtin_nontemporal_store(key, keys + dst0 + i);
+        __builtin_nontemporal_store(p, vals + dst0 + i);
         // the first radix pass's digit (its histogram reads this byte, not the key): the low 8 key bits, without payload
-        dig0[dst0 + i] = (uint8_t)(kbits >= 8 ? key : key & ((1ull << kbits) - 1ull));
+        __builtin_nontemporal_store((uint8_t)(kbits >= 8 ? key : key & ((1ull << kbits) - 1ull)), dig0 + dst0 + i);
     }
 }
 
@@ -606,6 +707,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             ++C;
         }
     }
+    if (ctx->prefix_symbols > 0) C = (uint32_t)ctx->prefix_symbols < Cmax ? (uint32_t)ctx->prefix_symbols : Cmax; // (tests)
     const uint32_t cap = (uint32_t)(m / 4 + 1024);
     uint64_t *ka = am.take<uint64_t>(m), *kb = am.take<uint64_t>(m);
     uint32_t *va = am.take<uint32_t>(m), *vb = am.take<uint32_t>(m);
@@ -671,8 +773,25 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys_kernel, dim3(sx_div_up(m, kBlock)), block, ti.T, m, pkey_make(base, C),
                       (uint32_t)kbits, wcfg, ka, dig0);
         else
-            sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel, dim3(ti.ntiles), block, ti.T,
-                      (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, pkey_make(base, C), (uint32_t)kbits, wcfg, ka, va, dig0);
+        {
+            const pkey_cfg kc = pkey_make(base, C);
+            // DNA-like texts: everything static for the usual prefix lengths (base 5: the window takes what
+            // 64 - kbits - 4 bits hold)
+            const bool dna = kc.dot && wcfg.B == 2 && kbits >= 8;
+#define SX_TILE_KEYS(CS, WS)                                                                                           \
+    sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel<CS, WS>, dim3(ti.ntiles), block, ti.T,   \
+              (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0)
+            const uint32_t shape = dna ? C * 16 + wcfg.CW : 0u;
+            switch (shape) {
+            case 14 * 16 + 13: SX_TILE_KEYS(14, 13); break;
+            case 15 * 16 + 12: SX_TILE_KEYS(15, 12); break;
+            case 16 * 16 + 11: SX_TILE_KEYS(16, 11); break;
+            case 17 * 16 + 10: SX_TILE_KEYS(17, 10); break;
+            case 18 * 16 + 9: SX_TILE_KEYS(18, 9); break;
+            default: SX_TILE_KEYS(0, 0); break;
+            }
+#undef SX_TILE_KEYS
+        }
         int in_b = 0;
         SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b, all_suffixes, true)); // (all suffixes: value = index)
         ks = in_b ? kb : ka;

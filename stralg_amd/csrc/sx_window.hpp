@@ -33,6 +33,23 @@ template <class WT>
 __device__ __forceinline__ WT wnd_from_bytes(uint64_t lo, uint64_t hi, uint32_t cnt, const wnd_cfg &c)
 {
     WT acc = 0;
+    if (cnt == c.CW && c.B <= 2) { // (uniform second test) four symbols per dot-product instruction
+        // code fields of B <= 2 bits: the weights 2^(3B), 2^(2B), 2^B, 1 of a word's four symbols fit a byte each,
+        // so a word of text is turned into 4 B window bits by one v_dot4_u32_u8; the -1 of every code is taken
+        // off at the end as one constant.  (DNA: 14 symbols = 4 dot products instead of 14 extract-shift-or steps;
+        // the key kernel of the LMS sort is bound by vector instructions.)
+        const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        const uint32_t nw = c.CW >> 2, r = c.CW & 3u;
+        const uint32_t coef4 = (1u << 24) | (1u << (16 + c.B)) | (1u << (8 + 2 * c.B)) | (1u << (3 * c.B));
+        uint32_t a = 0, bias = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (j < nw) a = __builtin_amdgcn_udot4(w[j], coef4, a << (4 * c.B), false);
+            else if (j == nw && r) a = __builtin_amdgcn_udot4(w[j], coef4 >> (8 * (4 - r)), a << (r * c.B), false);
+        }
+        for (uint32_t i = 0; i < c.CW; ++i) bias |= 1u << (c.B * i); // uniform
+        return (WT)(((a - bias) << kCntBits) | cnt);
+    }
     if (cnt == c.CW) { // everywhere but at the very start of the text: the loop bound is uniform
 #pragma unroll
         for (uint32_t i = 0; i < 15; ++i) {

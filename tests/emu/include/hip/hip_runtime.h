@@ -163,6 +163,16 @@ static inline unsigned emu_bitop3(unsigned a, unsigned b, unsigned c, unsigned t
     return r;
 }
 #define __builtin_amdgcn_bitop3_b32(a, b, c, tt) emu_bitop3((a), (b), (c), (tt))
+static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool)
+{
+    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return c;
+}
+static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh)
+{
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3u)));
+}
+#define SX_OPAQUE_VGPR(x) ((void)0) /* a register-allocation hint on the GPU */
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned add)
 {
     const int l = emu_lane();

@@ -58,6 +58,24 @@ def test_both_lms_paths(emu_ctx):
     assert (1, True) in seen and any(p == 2 for p, _ in seen)
 
 
+def test_static_key_shapes(emu_ctx):
+    """the key kernel's static forms for DNA-like texts (prefix lengths of 64 Mi ... 4 Gi symbol inputs), forced
+    on small texts: keys and embedded windows by dot products"""
+    rng = np.random.default_rng(17)
+    x = rng.integers(1, 5, size=9000, dtype=np.uint8)
+    x[5000:5040] = x[200:240]  # some ties for the refinement rounds as well
+    y = np.concatenate([x[:40], x[:40], x[3:2000]])  # LMS positions inside the first symbols of the text
+    try:
+        for text in (x, y):
+            want = oracle.sa_is(text, 5)
+            for C in (13, 14, 15, 16, 17, 18, 19):
+                emu_ctx.set_prefix_symbols(C)
+                assert (_sa(emu_ctx, text, 5) == want).all(), C
+                assert emu_ctx.last_stats()["key_slots"] == C
+    finally:
+        emu_ctx.set_prefix_symbols(0)
+
+
 def test_long_repeats_finish_by_comparison(emu_ctx):
     """duplications far longer than the refinement keys: pairs are settled by comparing the suffixes themselves
     (lms_path stays 1), a repeat with many copies goes through the sorting rounds"""
