@@ -165,6 +165,23 @@ __device__ __forceinline__ uint32_t carry_from_right(bool has, uint32_t first_va
 }
 
 // ---- pass 3: types, LMS bits, histograms ------------------------------------------
+// The kernel is bound by instruction issue, not by memory (500 instructions per thread and tile when every byte
+// is extracted and compared on its own: 1.5 ms at 1 GiB), so the 16 bytes of a thread stay in their four words:
+//  * "smaller than / different from the right neighbour" per byte without carries between bytes (the high bit of
+//    each byte is handled apart), one three-input bit operation each, and the four flag bits of a word are
+//    gathered by a dot product with the weights 1, 2, 4, 8 (16 ... 128 for the next word);
+//  * histograms of symbols below 8 (all of DNA): the three bit planes of the symbols are gathered the same way,
+//    the 16-bit "is symbol a" masks are one bit operation each, and the counts are popcounts of those masks
+//    (and of their intersections with the type masks) that accumulate in registers over all the tiles a
+//    workgroup walks; they are reduced over the wave once, at the end.
+__device__ __forceinline__ uint32_t gather16(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3, int bit)
+{
+    // bit `bit` of every byte of the four words -> 16 bits, byte 0 of m0 first
+    const uint32_t lo = __builtin_amdgcn_udot4(m1, 0x80402010u, __builtin_amdgcn_udot4(m0, 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(m3, 0x80402010u, __builtin_amdgcn_udot4(m2, 0x08040201u, 0u, false), false);
+    return ((lo >> bit) | (hi << (8 - bit))) & 0xFFFFu; // (a byte holds 0 or 1 << bit: the sums are the masks << bit)
+}
+
 __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     const uint8_t *__restrict__ T, uint64_t n, const uint8_t *__restrict__ tile_first, uint32_t ntiles,
     uint16_t *__restrict__ lmsbits, uint32_t *__restrict__ tile_lms, uint32_t *__restrict__ tile_last,
@@ -177,128 +194,140 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     h[0][t] = 0;
     h[1][t] = 0;
     h[2][t] = 0;
+    __syncthreads();
+    uint32_t cnt_all[8], cnt_s[8], cnt_lms[8]; // symbols below 8: all / S-type / LMS positions of this thread so far
+#pragma unroll
+    for (int a = 0; a < 8; ++a) cnt_all[a] = cnt_s[a] = cnt_lms[a] = 0;
     // A workgroup walks over many tiles and adds its histograms to the global ones once at the end: a global
     // atomic per tile and symbol (262 144 tiles on 15 addresses at 1 GiB of DNA) serialises at the memory side
     // and was most of this kernel's time.
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform
-    const uint64_t tile0 = (uint64_t)tile * kClsTile;
-    const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
-    uint32_t c[17], dmask, vmask;
-    load_chunk(T, p0, c);
-    decided_masks(c, p0, n, dmask, vmask);
-    const uint32_t tile_carry = tile + 1 < ntiles ? tile_first[tile + 1] : 1u;
-    const bool has = dmask != 0;
-    const uint32_t fv = has ? (vmask >> (__ffs(dmask) - 1)) & 1u : 0u;
-    uint32_t cur = carry_from_right(has, fv, tile_carry, lds); // includes barriers (h[] is zeroed)
-    // every position takes the type of the nearest decided position at or above it, else the carry: the decided
-    // values spread downwards through the undecided bits in four doubling steps
-    uint32_t smask = vmask & dmask, known = dmask;
+        const uint64_t tile0 = (uint64_t)tile * kClsTile;
+        const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
+        const uint4 v = *reinterpret_cast<const uint4 *>(T + p0);
+        const uint32_t w[5] = {v.x, v.y, v.z, v.w, (uint32_t)T[p0 + 16]};
+        const bool inside = p0 + 16 <= n; // everywhere but at the very end of the text
+        uint32_t dmask, vmask;
+        if (inside) {
+            uint32_t ne[4], lt[4];
+            const uint32_t H = 0x80808080u, L = 0x7F7F7F7Fu;
 #pragma unroll
-    for (int k = 1; k < 16; k <<= 1) {
-        smask |= (smask >> k) & ~known;
-        known |= known >> k;
-    }
-    if (cur) smask |= ~known & 0xFFFFu;
-    last_s[t] = (smask >> 15) & 1u;
-    __syncthreads();
-    uint32_t prev_s;
-    if (t > 0) {
-        prev_s = last_s[t - 1];
-    } else if (tile0 == 0) {
-        prev_s = 1; // position 0 is never LMS
-    } else {
-        const uint32_t a = T[tile0 - 1], b = c[0];
-        prev_s = a < b ? 1u : (a > b ? 0u : (smask & 1u));
-    }
-    // LMS: S-type whose left neighbour is L-type (sa_is.c:155-162)
-    uint32_t lmsmask = smask & ~((smask << 1) | prev_s);
-    uint32_t valid = 0xFFFFu;
-    if (p0 > n) valid = 0;
-    else if (n - p0 < 15) valid = (2u << (uint32_t)(n - p0)) - 1u; // positions p0 .. n
-    lmsmask &= valid;
-    // Histograms.  Symbols below 8 (all of DNA) are counted in registers, eight 8-bit
-    // counters per u64 (a thread holds 16 positions, so a counter cannot overflow), reduced
-    // over the wave in two halves of 16-bit lanes, and reach LDS as one add per wave and
-    // symbol; LDS atomics from 64 lanes on four hot addresses would serialise.  Larger
-    // symbols go to LDS directly (their addresses spread).
-    uint64_t pk_all = 0, pk_l = 0, pk_lms = 0;
-    uint32_t any = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) any |= c[i];
-    if (p0 + 16 <= n && any < 8u) { // inside the text and all symbols small (DNA: always): no bound, sentinel or size checks
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint64_t one = 1ull << (8u * c[i]);
-            pk_all += one;
-            pk_l += ((smask >> i) & 1u) ? 0ull : one;
-            pk_lms += ((lmsmask >> i) & 1u) ? one : 0ull;
-        }
-    } else
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if ((valid >> i) & 1u) {
-            const uint32_t ch = (p0 + i == n) ? 0u : c[i];
-            const bool is_l = !((smask >> i) & 1u), is_lms = (lmsmask >> i) & 1u;
-            if (ch < 8u) {
-                const uint64_t one = 1ull << (8u * ch);
-                pk_all += one;
-                if (is_l) pk_l += one;
-                if (is_lms) pk_lms += one;
-            } else {
-                atomicAdd(&h[0][ch], 1u);
-                if (is_l) atomicAdd(&h[1][ch], 1u);
-                if (is_lms) atomicAdd(&h[2][ch], 1u);
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t x = w[j], y = __builtin_amdgcn_alignbyte(w[j + 1], w[j], 1u); // y: the right neighbours
+                const uint32_t d = (x | H) - (y & L); // per byte, no borrow: bit 7 = "low 7 bits of x >= those of y"
+                // x < y: the high bits say so, or they agree and the low bits do
+                lt[j] = __builtin_amdgcn_bitop3_b32(x, y, d, 0x4D) & H; // (~x & y) | (~(x ^ y) & ~d)
+                const uint32_t e = x ^ y;
+                ne[j] = (((e & L) + L) | e) & H;
             }
+            dmask = gather16(ne[0], ne[1], ne[2], ne[3], 7);
+            vmask = gather16(lt[0], lt[1], lt[2], lt[3], 7);
+        } else {
+            uint32_t c[17];
+#pragma unroll
+            for (int i = 0; i < 17; ++i) c[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            decided_masks(c, p0, n, dmask, vmask);
         }
+        const uint32_t tile_carry = tile + 1 < ntiles ? tile_first[tile + 1] : 1u;
+        const bool has = dmask != 0;
+        const uint32_t fv = has ? (vmask >> (__ffs(dmask) - 1)) & 1u : 0u;
+        uint32_t cur = carry_from_right(has, fv, tile_carry, lds); // includes barriers
+        // every position takes the type of the nearest decided position at or above it, else the carry: the decided
+        // values spread downwards through the undecided bits in four doubling steps
+        uint32_t smask = vmask & dmask, known = dmask;
+#pragma unroll
+        for (int k = 1; k < 16; k <<= 1) {
+            smask |= (smask >> k) & ~known;
+            known |= known >> k;
+        }
+        if (cur) smask |= ~known & 0xFFFFu;
+        last_s[t] = (smask >> 15) & 1u;
+        __syncthreads();
+        uint32_t prev_s;
+        if (t > 0) {
+            prev_s = last_s[t - 1];
+        } else if (tile0 == 0) {
+            prev_s = 1; // position 0 is never LMS
+        } else {
+            const uint32_t a = T[tile0 - 1], b = w[0] & 0xFFu;
+            prev_s = a < b ? 1u : (a > b ? 0u : (smask & 1u));
+        }
+        // LMS: S-type whose left neighbour is L-type (sa_is.c:155-162)
+        uint32_t lmsmask = smask & ~((smask << 1) | prev_s);
+        uint32_t valid = 0xFFFFu;
+        if (p0 > n) valid = 0;
+        else if (n - p0 < 15) valid = (2u << (uint32_t)(n - p0)) - 1u; // positions p0 .. n
+        lmsmask &= valid;
+        if (inside && ((w[0] | w[1] | w[2] | w[3]) & 0xF8F8F8F8u) == 0) { // all symbols below 8 (DNA: always)
+            const uint32_t one = 0x01010101u;
+            const uint32_t b0 = gather16(w[0] & one, w[1] & one, w[2] & one, w[3] & one, 0);
+            const uint32_t b1 = gather16(w[0] & (one << 1), w[1] & (one << 1), w[2] & (one << 1), w[3] & (one << 1), 1);
+            const uint32_t b2 = gather16(w[0] & (one << 2), w[1] & (one << 2), w[2] & (one << 2), w[3] & (one << 2), 2);
+            // positions holding symbol A: every plane agrees with A's bit (a truth table with a single one)
+#define SX_CLS_COUNT(A)                                                                                                \
+    {                                                                                                                  \
+        const uint32_t eq = __builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & 0xFFFFu; \
+        cnt_all[A] += (uint32_t)__popc(eq);                                                                            \
+        cnt_s[A] += (uint32_t)__popc(eq & smask);                                                                      \
+        cnt_lms[A] += (uint32_t)__popc(eq & lmsmask);                                                                  \
     }
-    {
-        const uint64_t m16 = 0x00FF00FF00FF00FFull;
-        uint64_t part[6] = {pk_all & m16, (pk_all >> 8) & m16, pk_l & m16, (pk_l >> 8) & m16,
-                            pk_lms & m16, (pk_lms >> 8) & m16};
+            SX_CLS_COUNT(0) SX_CLS_COUNT(1) SX_CLS_COUNT(2) SX_CLS_COUNT(3)
+            SX_CLS_COUNT(4) SX_CLS_COUNT(5) SX_CLS_COUNT(6) SX_CLS_COUNT(7)
+#undef SX_CLS_COUNT
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part[k] += __shfl_xor(part[k], o, kWave);
-        }
-        if (lane_id() == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const uint32_t v = (uint32_t)((part[k] >> (16 * f)) & 0xFFFFull);
-                    if (v) atomicAdd(&h[k >> 1][2 * f + (k & 1)], v); // even fields: symbols 0,2,4,6; odd: 1,3,5,7
+            for (int i = 0; i < 16; ++i) {
+                if ((valid >> i) & 1u) {
+                    const uint32_t ch = (p0 + i == n) ? 0u : (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    atomicAdd(&h[0][ch], 1u);
+                    if (!((smask >> i) & 1u)) atomicAdd(&h[1][ch], 1u);
+                    if ((lmsmask >> i) & 1u) atomicAdd(&h[2][ch], 1u);
                 }
             }
         }
-    }
-    lmsbits[(uint64_t)tile * kBlock + t] = (uint16_t)lmsmask;
-    const uint32_t cnt = (uint32_t)__popc(lmsmask);
-    const uint32_t lastp1 = lmsmask ? (uint32_t)(p0 + (31 - __clz(lmsmask))) + 1u : 0u;
-    // tile totals: only the sums are needed, so one wave reduction each and a single barrier (which also
-    // completes h[])
-    uint32_t wsum = cnt, wmax = lastp1;
+        lmsbits[(uint64_t)tile * kBlock + t] = (uint16_t)lmsmask;
+        const uint32_t cnt = (uint32_t)__popc(lmsmask);
+        const uint32_t lastp1 = lmsmask ? (uint32_t)(p0 + (31 - __clz(lmsmask))) + 1u : 0u;
+        // tile totals: only the sums are needed, so one wave reduction each and a single barrier
+        uint32_t wsum = cnt, wmax = lastp1;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        wsum += __shfl_xor(wsum, o, kWave);
-        const uint32_t other = __shfl_xor(wmax, o, kWave);
-        wmax = other > wmax ? other : wmax;
-    }
-    if (lane_id() == 0) {
-        lds[wave_id()] = wsum;
-        lds[kWavesPerBlock + wave_id()] = wmax;
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t tot_cnt = 0, tot_last = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) {
-            tot_cnt += lds[w];
-            tot_last = lds[kWavesPerBlock + w] > tot_last ? lds[kWavesPerBlock + w] : tot_last;
+        for (int o = 32; o > 0; o >>= 1) {
+            wsum += __shfl_xor(wsum, o, kWave);
+            const uint32_t other = __shfl_xor(wmax, o, kWave);
+            wmax = other > wmax ? other : wmax;
         }
-        tile_lms[tile] = tot_cnt;
-        tile_last[tile] = tot_last;
+        if (lane_id() == 0) {
+            lds[wave_id()] = wsum;
+            lds[kWavesPerBlock + wave_id()] = wmax;
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t tot_cnt = 0, tot_last = 0;
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+                tot_cnt += lds[ww];
+                tot_last = lds[kWavesPerBlock + ww] > tot_last ? lds[kWavesPerBlock + ww] : tot_last;
+            }
+            tile_lms[tile] = tot_cnt;
+            tile_last[tile] = tot_last;
+        }
+        __syncthreads(); // lds[] and last_s[] are rewritten by the next tile
     }
-    __syncthreads(); // lds[] and last_s[] are rewritten by the next tile
+    // the register counts: over the wave, then one LDS add per wave and symbol (L-type = all - S-type)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        uint32_t x = cnt_all[a], y = cnt_s[a], z = cnt_lms[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x += __shfl_xor(x, o, kWave);
+            y += __shfl_xor(y, o, kWave);
+            z += __shfl_xor(z, o, kWave);
+        }
+        if (lane_id() == 0) {
+            if (x) atomicAdd(&h[0][a], x);
+            if (x - y) atomicAdd(&h[1][a], x - y);
+            if (z) atomicAdd(&h[2][a], z);
+        }
     }
     __syncthreads();
 #pragma unroll
