@@ -335,28 +335,56 @@ __device__ __forceinline__ void lds_bytes32(const uint8_t *img, uint32_t p, uint
     o[3] = funnel64(d, e, r);
 }
 
-// In-place exclusive prefix sum of row[0..count) by one workgroup; returns the total.
+// In-place exclusive prefix sum of row[0..count) by one workgroup; returns the total.  8192 entries a step: loaded
+// and stored with the lanes on consecutive entries, turned through LDS (`stage`, kScanRowStage words; a word of
+// padding per 32 keeps both views free of bank conflicts) so that a thread scans 32 consecutive ones.  (With each
+// thread loading its own 32 entries a load instruction touched 64 cache lines: 100 us for the 131 072 tile counts
+// of a large induce round, most of the time between that round's counting and scattering launches.)
+constexpr int kScanRowPer = 32;
+constexpr int kScanRowStage = kBlock * kScanRowPer + kBlock;
 __device__ __forceinline__ uint32_t block_scan_row_inplace(uint32_t *__restrict__ row, uint64_t count,
-                                                           uint32_t *lds)
+                                                           uint32_t *lds, uint32_t *stage)
 {
-    constexpr int kPer = 32; // every thread's loads of one step are in flight together
+    constexpr int kPer = kScanRowPer;
+    const uint32_t t = threadIdx.x;
     uint32_t carry = 0;
     for (uint64_t start = 0; start < count; start += (uint64_t)kBlock * kPer) { // uniform trip count
-        const uint64_t i0 = start + (uint64_t)threadIdx.x * kPer;
-        uint32_t v[kPer], acc = 0;
+        uint32_t v[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            v[k] = i0 + k < count ? row[i0 + k] : 0u;
+            const uint64_t i = start + (uint64_t)k * kBlock + t;
+            v[k] = i < count ? row[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t e = (uint32_t)k * kBlock + t;
+            stage[e + (e >> 5)] = v[k];
+        }
+        __syncthreads();
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t e = t * kPer + (uint32_t)k;
+            v[k] = stage[e + (e >> 5)];
             acc += v[k];
         }
         uint32_t tot;
         uint32_t run = carry + block_exclusive_scan<OpAdd>(acc, lds, tot);
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            if (i0 + k < count) row[i0 + k] = run;
+            const uint32_t e = t * kPer + (uint32_t)k;
+            stage[e + (e >> 5)] = run;
             run += v[k];
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint64_t i = start + (uint64_t)k * kBlock + t;
+            const uint32_t e = (uint32_t)k * kBlock + t;
+            if (i < count) row[i] = stage[e + (e >> 5)];
+        }
         carry += tot;
+        __syncthreads(); // `stage` is refilled by the next step
     }
     return carry;
 }

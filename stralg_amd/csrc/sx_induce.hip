@@ -177,11 +177,12 @@ __global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__rest
                                                                 uint32_t chain_max)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
+    __shared__ uint32_t stage[kScanRowStage];
     const uint32_t len = range_in[1] - range_in[0];
     if (len <= chain_max) return;
     const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
     const uint32_t key = blockIdx.x;
-    const uint32_t total = block_scan_row_inplace(hist + (uint64_t)key * stride, ntiles, lds);
+    const uint32_t total = block_scan_row_inplace(hist + (uint64_t)key * stride, ntiles, lds, stage);
     if (threadIdx.x == 0) {
         const uint32_t cur = cursor_cur[key];
         cursor_nxt[key] = dir > 0 ? cur + total : cur - total;
