@@ -848,7 +848,7 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
 // host look per batch
 template <class WT>
 int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_entries, int rev, int mode, uint32_t c,
-                    int dir, int which, uint32_t *total_in_region)
+                    int dir, int which, uint32_t *total_in_region, double share /* of symbol c in the text */)
 {
     sx_ctx *ctx = st.ctx;
     bool first = true;
@@ -869,9 +869,12 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             uint32_t tb = bound_tiles >> k;
             const uint32_t floor_tiles = bound_tiles < 256 ? bound_tiles : 256;
             if (tb < floor_tiles) tb = floor_tiles;
-            // a run of c's continues with probability ~1/#symbols: expect the rounds to shrink fast
-            const int sh = st.small_alphabet ? k : 3 * k;
-            const uint32_t likely = sh < 32 ? (bound_tiles >> sh) : 0u;
+            // a run of c's continues with the probability of c: expect round k to hold share^k of the region
+            // (twice that, to be on the safe side, decides whether the three-launch form is queued as well: a launch
+            // that finds nothing to do still costs 5 us, and there were 20 of them per bucket)
+            double expect = 2.0 * (double)bound_tiles;
+            for (int i = 0; i < k; ++i) expect *= share;
+            const uint32_t likely = expect < (double)bound_tiles ? (uint32_t)expect : bound_tiles;
             launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir);
         }
         launch_tail<WT>(st, spec, spec + 1, rev, mode, c, dir);
@@ -952,7 +955,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (ti.h_all[c] == 0) continue;
         if (ti.h_l[c]) {
             uint32_t head_end = 0;
-            SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end));
+            SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end, (double)ti.h_all[c] / (double)N));
             if (head_end - begin[c] != ti.h_l[c])
                 return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
         }
@@ -974,7 +977,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         const uint32_t n_s = ti.h_all[c] - ti.h_l[c];
         if (c > 0 && n_s) {
             uint32_t tail_end = 0;
-            SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end));
+            SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end, (double)ti.h_all[c] / (double)N));
             if (begin[c + 1] - tail_end != n_s)
                 return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
         }
