@@ -174,14 +174,6 @@ __device__ __forceinline__ uint32_t carry_from_right(bool has, uint32_t first_va
 //    the 16-bit "is symbol a" masks are one bit operation each, and the counts are popcounts of those masks
 //    (and of their intersections with the type masks) that accumulate in registers over all the tiles a
 //    workgroup walks; they are reduced over the wave once, at the end.
-__device__ __forceinline__ uint32_t gather16(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3, int bit)
-{
-    // bit `bit` of every byte of the four words -> 16 bits, byte 0 of m0 first
-    const uint32_t lo = __builtin_amdgcn_udot4(m1, 0x80402010u, __builtin_amdgcn_udot4(m0, 0x08040201u, 0u, false), false);
-    const uint32_t hi = __builtin_amdgcn_udot4(m3, 0x80402010u, __builtin_amdgcn_udot4(m2, 0x08040201u, 0u, false), false);
-    return ((lo >> bit) | (hi << (8 - bit))) & 0xFFFFu; // (a byte holds 0 or 1 << bit: the sums are the masks << bit)
-}
-
 __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     const uint8_t *__restrict__ T, uint64_t n, const uint8_t *__restrict__ tile_first, uint32_t ntiles,
     uint16_t *__restrict__ lmsbits, uint32_t *__restrict__ tile_lms, uint32_t *__restrict__ tile_last,

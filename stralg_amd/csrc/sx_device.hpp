@@ -335,6 +335,17 @@ __device__ __forceinline__ void lds_bytes32(const uint8_t *img, uint32_t p, uint
     o[3] = funnel64(d, e, r);
 }
 
+// Bit `bit` of each of the 16 bytes of four words as a 16-bit mask, byte 0 of m0 first; every byte of m0..m3 must
+// hold 0 or 1 << bit.  Four dot products with the weights 1, 2, 4, 8 / 16, 32, 64, 128.
+__device__ __forceinline__ uint32_t gather16(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3, int bit)
+{
+    // bit `bit` of every byte of the four words -> 16 bits, byte 0 of m0 first
+    const uint32_t lo = __builtin_amdgcn_udot4(m1, 0x80402010u, __builtin_amdgcn_udot4(m0, 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(m3, 0x80402010u, __builtin_amdgcn_udot4(m2, 0x08040201u, 0u, false), false);
+    return ((lo >> bit) | (hi << (8 - bit))) & 0xFFFFu; // (a byte holds 0 or 1 << bit: the sums are the masks << bit)
+}
+
+
 // In-place exclusive prefix sum of row[0..count) by one workgroup; returns the total.  8192 entries a step: loaded
 // and stored with the lanes on consecutive entries, turned through LDS (`stage`, kScanRowStage words; a word of
 // padding per 32 keeps both views free of bank conflicts) so that a thread scans 32 consecutive ones.  (With each

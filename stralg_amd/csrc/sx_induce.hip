@@ -77,15 +77,17 @@ __device__ __forceinline__ void load_quad(const uint64_t *__restrict__ p, uint64
     o[0] = pack64(v0.x, v0.y), o[1] = pack64(v0.z, v0.w), o[2] = pack64(v1.x, v1.y), o[3] = pack64(v1.z, v1.w);
 }
 
-// Only the windows are read: a stored window is empty exactly when its entry is position 0
-// (which induces nothing); every other window is refilled from the text the moment it runs
-// dry.  The counts of a tile do not depend on the order of its entries, so the tile's index
-// range is read as aligned quads (16 bytes per lane per load); the one or two quads that straddle
-// the range ends are read entry by entry.  BITS = 3 (at most 8 buckets): per-thread packed
-// counters reduced over the wave, instead of 64 lanes queueing on a handful of LDS words.
+// Counting reads one byte per entry, not the entry: every writer of (SA, WN) leaves the entry's symbol
+// text[SA[i] - 1] in a byte array next to them (0 for the entry of position 0, which induces nothing) --
+// the array that is the BWT in the end.  The LMS seeds have no such bytes (srcB == NULL); there the windows are
+// read: a stored window is empty exactly when its entry is position 0, every other window is refilled from the
+// text the moment it runs dry.  The counts of a tile do not depend on the order of its entries, so the tile's
+// index range is read as aligned 16-byte pieces; the one or two pieces that straddle the range ends are read
+// entry by entry.  BITS = 3 (at most 8 buckets): a wave per tile, symbol masks and popcounts per lane
+// (sx_device.hpp: gather16) reduced over the wave, instead of 64 lanes queueing on a handful of LDS words.
 template <class WT, int BITS>
-__global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__restrict__ srcP,
-                                                              const WT *__restrict__ srcW,
+__global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restrict__ srcW,
+                                                              const uint8_t *__restrict__ srcB,
                                                               const uint32_t *__restrict__ range_in, int rev,
                                                               int mode, uint32_t c, wnd_cfg cfg,
                                                               uint32_t *__restrict__ hist, uint32_t stride,
@@ -95,7 +97,53 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__
     const uint32_t lo = range_in[0], len = range_in[1] - lo;
     if (len <= chain_max) return;
     const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
-    const bool aligned = ((uintptr_t)srcW & 15u) == 0;
+    const bool aligned = srcB ? ((uintptr_t)srcB & 15u) == 0 : ((uintptr_t)srcW & 15u) == 0;
+    if (BITS == 3 && srcB) {
+        // a wave per tile, all of the tile's pieces in flight at once, no LDS and no barrier
+        constexpr int kPieces = kIndTile / 16 / kWave + 1; // the tile's range may start inside a piece
+        const int lane = lane_id();
+        for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave_id(); tile < ntiles; tile += gridDim.x * kWavesPerBlock) {
+            const uint32_t tile0 = tile * (uint32_t)kIndTile;
+            const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
+            const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
+            uint32_t S[kPieces][4];
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                const uint64_t e0 = ((uint64_t)(a >> 4) + (uint64_t)lane + (uint64_t)k * kWave) * 16u;
+                S[k][0] = S[k][1] = S[k][2] = S[k][3] = 0; // (symbol 0 counts nowhere)
+                if (aligned && e0 >= a && e0 + 16u <= b) {
+                    load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S[k]);
+                } else if (e0 < b && e0 + 16u > a) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (e0 + e >= a && e0 + e < b) S[k][e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
+                }
+            }
+            uint32_t n_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // this lane's entries per symbol (at most 16 * kPieces)
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                const uint32_t one = 0x01010101u;
+                const uint32_t b0 = gather16(S[k][0] & one, S[k][1] & one, S[k][2] & one, S[k][3] & one, 0);
+                const uint32_t b1 = gather16(S[k][0] & (one << 1), S[k][1] & (one << 1), S[k][2] & (one << 1), S[k][3] & (one << 1), 1);
+                const uint32_t b2 = gather16(S[k][0] & (one << 2), S[k][1] & (one << 2), S[k][2] & (one << 2), S[k][3] & (one << 2), 2);
+#define SX_IND_COUNT(A) n_of[A] += (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & 0xFFFFu);
+                SX_IND_COUNT(1) SX_IND_COUNT(2) SX_IND_COUNT(3) SX_IND_COUNT(4) SX_IND_COUNT(5) SX_IND_COUNT(6) SX_IND_COUNT(7)
+#undef SX_IND_COUNT
+            }
+            uint64_t even = (uint64_t)n_of[2] << 16 | (uint64_t)n_of[4] << 32 | (uint64_t)n_of[6] << 48; // 16-bit fields
+            uint64_t odd = (uint64_t)n_of[1] | (uint64_t)n_of[3] << 16 | (uint64_t)n_of[5] << 32 | (uint64_t)n_of[7] << 48;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                even += __shfl_xor(even, o, kWave);
+                odd += __shfl_xor(odd, o, kWave);
+            }
+            if ((uint32_t)lane < nkeys && lane < 8) {
+                const uint32_t v = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
+                hist[(uint64_t)lane * stride + tile] = lane != 0 && induce_accept((uint32_t)lane, c, mode) ? v : 0u;
+            }
+        }
+        return;
+    }
     if (BITS == 3) {
         // a wave per tile, all of the tile's quads in flight at once, no LDS and no barrier
         constexpr int kQuads = kIndTile / 4 / kWave + 1; // the tile's range may start inside a quad
@@ -144,21 +192,40 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const uint32_t *__
         const uint32_t tile0 = tile * (uint32_t)kIndTile;
         const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
         const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
-        for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kBlock) {
-            const uint64_t e0 = q * 4u;
-            WT W[4] = {0, 0, 0, 0};
-            if (aligned && e0 >= a && e0 + 4u <= b) {
-                load_quad(srcW + e0, W);
-            } else {
+        if (srcB) {
+            for (uint64_t q = (uint64_t)(a >> 4) + threadIdx.x; q * 16u < b; q += kBlock) {
+                const uint64_t e0 = q * 16u;
+                uint32_t S[4] = {0, 0, 0, 0};
+                if (aligned && e0 >= a && e0 + 16u <= b) {
+                    load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
+                    for (int e = 0; e < 16; ++e)
+                        if (e0 + e >= a && e0 + e < b) S[e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t ch = (S[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                    if (ch != 0 && induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                }
             }
+        } else {
+            for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kBlock) {
+                const uint64_t e0 = q * 4u;
+                WT W[4] = {0, 0, 0, 0};
+                if (aligned && e0 >= a && e0 + 4u <= b) {
+                    load_quad(srcW + e0, W);
+                } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
-                    const uint32_t ch = wnd_first<WT>(W[e], cfg);
-                    if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                    for (int e = 0; e < 4; ++e)
+                        if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
+                        const uint32_t ch = wnd_first<WT>(W[e], cfg);
+                        if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                    }
                 }
             }
         }
@@ -198,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev,
     int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs,
     uint32_t stride, const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA,
-    WT *__restrict__ WN, uint32_t nkeys, uint32_t chain_max)
+    WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t nkeys, uint32_t chain_max)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gpos[256]; // destination index of the tile's first entry, per bucket
@@ -262,6 +329,7 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
                 if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
                 SA[dst] = j;
                 WN[dst] = nw;
+                BW[dst] = wnd_symbol<WT>(nw, cfg);
             }
         }
         __syncthreads(); // LDS is reused by the next tile
@@ -280,8 +348,8 @@ template <class WT, int MODE>
 __global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, uint32_t c,
     wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs, uint32_t stride,
-    const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ SA, WT *__restrict__ WN, uint32_t nkeys,
-    uint32_t chain_max)
+    const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW,
+    uint32_t nkeys, uint32_t chain_max)
 {
     constexpr bool kRev = MODE == MODE_S_FROM_S || MODE == MODE_S_FROM_L; // the S pass scans right to left
     constexpr uint64_t kField16 = 0x00FF00FF00FF00FFull;
@@ -405,8 +473,10 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
             if (i < produced) {
                 const uint32_t g = gadj[sD[i]];
                 const uint32_t dst = kRev ? g - i : g + i;
+                const WT nw = sW[i];
                 SA[dst] = sP[i];
-                WN[dst] = sW[i];
+                WN[dst] = nw;
+                BW[dst] = wnd_symbol<WT>(nw, cfg);
             }
         }
         __syncthreads(); // LDS is reused by the next tile
@@ -426,7 +496,8 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in,
     uint32_t *__restrict__ range_out, int rev, int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
     const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt, int dir, uint32_t *__restrict__ SA,
-    WT *__restrict__ WN, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch, uint32_t *__restrict__ ticket,
+    WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch,
+    uint32_t *__restrict__ ticket,
     uint32_t chain_max /* rounds longer than this are left to the three-launch form; ~0u: take any round */)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
@@ -530,6 +601,7 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
                 if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
                 SA[dst] = j;
                 WN[dst] = nw;
+                BW[dst] = wnd_symbol<WT>(nw, cfg);
             }
         }
         __syncthreads(); // LDS is reused by the next tile
@@ -545,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
 // Entries written in one iteration are read in the next by other waves of the same
 // workgroup: the barrier's workgroup-scope fence orders them (the waves share the CU's L1).
 template <class WT, int BITS>
-__global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *WN, const uint32_t *__restrict__ range_in,
+__global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *WN, uint8_t *BW, const uint32_t *__restrict__ range_in,
                                                              uint32_t *__restrict__ range_out, int rev, int mode,
                                                              uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
                                                              const uint32_t *__restrict__ cursor_cur,
@@ -598,8 +670,10 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
                     const uint32_t j = o / len + 1u, i = o % len;
                     const uint32_t v = SA[lo + (rev ? len - 1u - i : i)] - j;
                     const uint32_t dst = dir > 0 ? cur + o : cur - 1u - o;
+                    const WT nw = v ? wnd_fill<WT>(T, v, cfg) : (WT)0;
                     SA[dst] = v;
-                    WN[dst] = v ? wnd_fill<WT>(T, v, cfg) : (WT)0;
+                    WN[dst] = nw;
+                    BW[dst] = wnd_symbol<WT>(nw, cfg);
                 }
                 __syncthreads();
                 if ((uint32_t)t == c) {
@@ -661,6 +735,7 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
                 if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg);
                 SA[dst] = j;
                 WN[dst] = nw;
+                BW[dst] = wnd_symbol<WT>(nw, cfg);
             }
         }
         __syncthreads();
@@ -724,10 +799,13 @@ __global__ __launch_bounds__(kBlock) void bwt_from_windows_kernel(const WT *__re
     }
 }
 
-template <class WT> __global__ void set_entry_kernel(uint32_t *SA, WT *WN, uint32_t p, const uint8_t *T, wnd_cfg cfg)
+template <class WT>
+__global__ void set_entry_kernel(uint32_t *SA, WT *WN, uint8_t *BW, uint32_t p, const uint8_t *T, wnd_cfg cfg)
 {
+    const WT w = p ? wnd_fill<WT>(T, p, cfg) : (WT)0;
     SA[0] = p;
-    WN[0] = p ? wnd_fill<WT>(T, p, cfg) : (WT)0;
+    WN[0] = w;
+    BW[0] = wnd_symbol<WT>(w, cfg);
 }
 
 } // namespace sx
@@ -736,9 +814,9 @@ using namespace sx;
 
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 {
-    // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + control block
+    // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + symbol bytes + control block
     const uint64_t ntiles = (N + kIndTile - 1) / kIndTile + 1;
-    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)sigma * ntiles * 4 + 256 + 16384;
+    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 16384;
 }
 
 namespace {
@@ -749,6 +827,7 @@ template <class WT> struct induce_state {
     const uint8_t *T;
     uint32_t *SA;
     WT *WN;
+    uint8_t *BW; // text[SA[i] - 1] of every written slot (0 for position 0): what the counting launches read; the BWT in the end
     uint32_t *cursor[2]; // ping-pong: a round reads one, its last tile writes the other
     uint32_t *ranges;    // (kMaxSpec + 2) x {lo, hi}
     uint32_t *tickets;   // kMaxSpec + 2
@@ -780,18 +859,20 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     const uint32_t chain_max = both ? st.chain_max : ~0u;
     if (both) {
         // the round may be a large one: queue the three-launch form as well
+        // (entries of the suffix array have their symbol bytes next to them; the LMS seeds only their windows)
+        const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
         if (st.small_alphabet)
-            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcP, srcW,
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
         else
-            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcW, srcB,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
         if (st.small_alphabet) {
 #define SX_SCATTER_SMALL(M)                                                                                            \
     sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_small_kernel<WT, M>, dim3(grid), dim3(kBlock), srcP, srcW, \
-              (const uint32_t *)rin, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, st.SA, st.WN, st.nk,   \
+              (const uint32_t *)rin, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, st.SA, st.WN, st.BW, st.nk, \
               chain_max)
             switch (mode) { // mode fixes the scan direction (rev) and the side the buckets grow to (dir)
             case MODE_L_FROM_L: SX_SCATTER_SMALL(MODE_L_FROM_L); break;
@@ -803,24 +884,24 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         } else if (st.nk <= 32) // five ballots per match instead of eight
             sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 5>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
-                      st.SA, st.WN, st.nk, chain_max);
+                      st.SA, st.WN, st.BW, st.nk, chain_max);
         else
             sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
                       (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
-                      st.SA, st.WN, st.nk, chain_max);
+                      st.SA, st.WN, st.BW, st.nk, chain_max);
     }
     uint32_t cgrid = grid > 1024 ? 1024 : grid;
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
-                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
                   epoch, st.tickets + range_slot, chain_max);
     else if (st.nk <= 32)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 5>, dim3(cgrid), dim3(kBlock), srcP, srcW,
-                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
                   epoch, st.tickets + range_slot, chain_max);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 8>, dim3(cgrid), dim3(kBlock), srcP, srcW,
-                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.nk, st.status,
+                  (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
                   epoch, st.tickets + range_slot, chain_max);
     st.par ^= 1;
     ctx->stats.induce_rounds++;
@@ -833,11 +914,11 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
     const uint32_t *cur = st.cursor[st.par];
     uint32_t *nxt = st.cursor[st.par ^ 1];
     if (st.small_alphabet)
-        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kBlock), st.SA, st.WN,
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, 4096u);
     else
-        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kBlock), st.SA, st.WN,
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, 4096u);
     st.par ^= 1;
@@ -907,12 +988,13 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.cfg = cfg;
     st.par = 0;
     st.WN = arena.take<WT>(N);
+    st.BW = bwt_out ? bwt_out : arena.take<uint8_t>(N);
     WT *seedW = seed_windows ? (WT *)seed_windows : arena.take<WT>(ti.m ? ti.m : 1);
     st.cursor[0] = arena.take<uint32_t>(256);
     st.cursor[1] = arena.take<uint32_t>(256);
     st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 3));
     st.tickets = arena.take<uint32_t>(kMaxSpec + 3);
-    if (!st.WN || !seedW || !st.cursor[0] || !st.cursor[1] || !st.ranges || !st.tickets)
+    if (!st.WN || !st.BW || !seedW || !st.cursor[0] || !st.cursor[1] || !st.ranges || !st.tickets)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
 
     // bucket boundaries on the host (sa_is.c:176-201)
@@ -947,7 +1029,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.m * (4 + sizeof(WT) + 16), fill_windows_kernel<WT>,
                   dim3(sx_div_up(ti.m, kBlock)), dim3(kBlock), ti.T, sorted_lms, ti.m, cfg, seedW);
     // the sentinel suffix (sa_is.c:463: SA[0] = n)
-    sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, (uint32_t)ti.n, ti.T, cfg);
+    sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, st.BW, (uint32_t)ti.n, ti.T, cfg);
 
     // ---- L pass: buckets ascending, cursors at the bucket heads ------------------------
     SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -998,19 +1080,16 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     if (ctx->prof_on && ctx->prof_only < 0) {
         // Algorithmic bytes of the two passes (the launches themselves were queued with bounds, not
         // sizes): the L pass scans every L-type entry and every LMS seed, the S pass every entry but
-        // the sentinel's; every suffix is written once.  The counting launches read the windows, the
-        // scatter launches the (position, window) pairs; the few entries that went through the chained
+        // the sentinel's; every suffix is written once.  The counting launches read the symbol bytes (windows for the seeds), the
+        // scatter launches the (position, window) pairs and write a symbol byte along; the few entries that went through the chained
         // rounds are booked here too.
         uint64_t n_l = 0;
         for (uint32_t c = 0; c < nk; ++c) n_l += ti.h_l[c];
         const uint64_t scanned = n_l + ti.m + (N - 1);
-        ctx->kstat[SX_KC_INDUCE_GATHER].alg_bytes += scanned * sizeof(WT);
-        ctx->kstat[SX_KC_INDUCE_SCATTER].alg_bytes += (scanned + N) * (4 + sizeof(WT));
+        ctx->kstat[SX_KC_INDUCE_GATHER].alg_bytes += (scanned - ti.m) + ti.m * sizeof(WT); // symbol bytes; seeds: windows
+        ctx->kstat[SX_KC_INDUCE_SCATTER].alg_bytes += (scanned + N) * (4 + sizeof(WT)) + N;
     }
-    // the windows now hold text[SA[i]-1] for every slot: the BWT for free (bwt.c:13-20)
-    if (bwt_out)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N * (sizeof(WT) + 1), bwt_from_windows_kernel<WT>, dim3(sx_div_up(N, kBlock * 16)),
-                  dim3(kBlock), (const WT *)st.WN, N, cfg, bwt_out);
+    // st.BW now holds text[SA[i]-1] for every slot: the BWT (bwt.c:13-20), written along with the entries
     return 0;
 }
 } // namespace

@@ -22,6 +22,11 @@ template <class WT> __device__ __forceinline__ uint32_t wnd_first(WT w, const wn
 {
     return (uint32_t)((w >> kCntBits) & (WT)c.mask) + 1u;
 }
+// the symbol in front of the entry, 0 for the one entry with nothing in front of it (position 0): its BWT symbol
+template <class WT> __device__ __forceinline__ uint8_t wnd_symbol(WT w, const wnd_cfg &c)
+{
+    return (uint8_t)(wnd_count<WT>(w) ? wnd_first<WT>(w, c) : 0u);
+}
 template <class WT> __device__ __forceinline__ WT wnd_pop(WT w, const wnd_cfg &c)
 {
     const WT cnt = w & (WT)15;
