@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
                                                               const uint32_t *__restrict__ range_in, int rev,
                                                               int mode, uint32_t c, wnd_cfg cfg,
                                                               uint32_t *__restrict__ hist, uint32_t stride,
-                                                              uint32_t nkeys, uint32_t chain_max)
+                                                              uint32_t nkeys, uint32_t chain_max,
+                                                              uint64_t src_len /* entries of the source arrays */)
 {
     __shared__ uint32_t h[256];
     const uint32_t lo = range_in[0], len = range_in[1] - lo;
@@ -106,17 +107,23 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
             const uint32_t tile0 = tile * (uint32_t)kIndTile;
             const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
             const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
-            uint32_t S[kPieces][4];
+            // Every lane loads whole aligned pieces, also the one or two that straddle the ends of [a, b) (they lie
+            // inside the array): the bytes outside the range are masked after the bit planes are gathered.  (Reading
+            // those pieces byte by byte under a branch made every wave wait for a chain of dependent loads: the launch
+            // ran at 1 TB/s of its 1 byte per entry.)
+            uint32_t S[kPieces][4], inside[kPieces];
 #pragma unroll
             for (int k = 0; k < kPieces; ++k) {
                 const uint64_t e0 = ((uint64_t)(a >> 4) + (uint64_t)lane + (uint64_t)k * kWave) * 16u;
                 S[k][0] = S[k][1] = S[k][2] = S[k][3] = 0; // (symbol 0 counts nowhere)
-                if (aligned && e0 >= a && e0 + 16u <= b) {
-                    load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S[k]);
-                } else if (e0 < b && e0 + 16u > a) {
+                const uint32_t from = e0 < a ? (uint32_t)(a - e0) : 0u, to = e0 >= b ? 0u : (b - e0 < 16u ? (uint32_t)(b - e0) : 16u);
+                inside[k] = from < to ? ((1u << to) - 1u) & ~((1u << from) - 1u) : 0u; // the piece's entries in [a, b)
+                if (aligned && e0 + 16u <= src_len) {
+                    if (inside[k]) load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S[k]);
+                } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        if (e0 + e >= a && e0 + e < b) S[k][e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
+                        if ((inside[k] >> e) & 1u) S[k][e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
                 }
             }
             uint32_t n_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // this lane's entries per symbol (at most 16 * kPieces)
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
                 const uint32_t b0 = gather16(S[k][0] & one, S[k][1] & one, S[k][2] & one, S[k][3] & one, 0);
                 const uint32_t b1 = gather16(S[k][0] & (one << 1), S[k][1] & (one << 1), S[k][2] & (one << 1), S[k][3] & (one << 1), 1);
                 const uint32_t b2 = gather16(S[k][0] & (one << 2), S[k][1] & (one << 2), S[k][2] & (one << 2), S[k][3] & (one << 2), 2);
-#define SX_IND_COUNT(A) n_of[A] += (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & 0xFFFFu);
+#define SX_IND_COUNT(A) n_of[A] += (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & inside[k]);
                 SX_IND_COUNT(1) SX_IND_COUNT(2) SX_IND_COUNT(3) SX_IND_COUNT(4) SX_IND_COUNT(5) SX_IND_COUNT(6) SX_IND_COUNT(7)
 #undef SX_IND_COUNT
             }
@@ -153,16 +160,19 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
             const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
             const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
             WT W[kQuads][4];
+            uint32_t inside[kQuads]; // (whole aligned quads are loaded, the entries outside [a, b) masked: see above)
 #pragma unroll
             for (int k = 0; k < kQuads; ++k) {
                 const uint64_t e0 = ((uint64_t)(a >> 2) + (uint64_t)lane + (uint64_t)k * kWave) * 4u;
                 W[k][0] = W[k][1] = W[k][2] = W[k][3] = 0;
-                if (aligned && e0 >= a && e0 + 4u <= b) {
-                    load_quad(srcW + e0, W[k]);
+                const uint32_t from = e0 < a ? (uint32_t)(a - e0) : 0u, to = e0 >= b ? 0u : (b - e0 < 4u ? (uint32_t)(b - e0) : 4u);
+                inside[k] = from < to ? ((1u << to) - 1u) & ~((1u << from) - 1u) : 0u;
+                if (aligned && e0 + 4u <= src_len) {
+                    if (inside[k]) load_quad(srcW + e0, W[k]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (e0 + e >= a && e0 + e < b) W[k][e] = srcW[e0 + e];
+                        if ((inside[k] >> e) & 1u) W[k][e] = srcW[e0 + e];
                 }
             }
             uint64_t packed = 0; // one 8-bit counter per bucket (a lane sees at most 4 * kQuads entries)
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t ch = wnd_first<WT>(W[k][e], cfg) & 7u;
-                    const bool ok = wnd_count<WT>(W[k][e]) != 0 && induce_accept(ch, c, mode);
+                    const bool ok = ((inside[k] >> e) & 1u) && wnd_count<WT>(W[k][e]) != 0 && induce_accept(ch, c, mode);
                     packed += (uint64_t)(ok ? 1u : 0u) << (8u * ch);
                 }
             }
@@ -827,6 +837,7 @@ template <class WT> struct induce_state {
     const uint8_t *T;
     uint32_t *SA;
     WT *WN;
+    uint64_t N, m; // entries of (SA, WN, BW) and of the seed arrays
     uint8_t *BW; // text[SA[i] - 1] of every written slot (0 for position 0): what the counting launches read; the BWT in the end
     uint32_t *cursor[2]; // ping-pong: a round reads one, its last tile writes the other
     uint32_t *ranges;    // (kMaxSpec + 2) x {lo, hi}
@@ -861,12 +872,13 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         // the round may be a large one: queue the three-launch form as well
         // (entries of the suffix array have their symbol bytes next to them; the LMS seeds only their windows)
         const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
+        const uint64_t src_len = srcP == st.SA ? st.N : st.m;
         if (st.small_alphabet)
             sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
         else
             sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcW, srcB,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max);
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
         if (st.small_alphabet) {
@@ -989,6 +1001,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.par = 0;
     st.WN = arena.take<WT>(N);
     st.BW = bwt_out ? bwt_out : arena.take<uint8_t>(N);
+    st.N = N;
+    st.m = ti.m;
     WT *seedW = seed_windows ? (WT *)seed_windows : arena.take<WT>(ti.m ? ti.m : 1);
     st.cursor[0] = arena.take<uint32_t>(256);
     st.cursor[1] = arena.take<uint32_t>(256);

@@ -8,7 +8,7 @@ rows.sort()
 # last step: find the last set_entry_kernel
 idx = [i for i, r in enumerate(rows) if "set_entry" in r[2]]
 i0 = idx[-1]
-end = next(i for i in range(i0, len(rows)) if "bwt_from_windows" in rows[i][2])
+end = next((i for i in range(i0, len(rows)) if "bwt_count" in rows[i][2] or "otable" in rows[i][2]), len(rows) - 1)
 prev = rows[i0][0]
 tot_gap = 0
 for s, e, nme, g in rows[i0:end + 1]:
