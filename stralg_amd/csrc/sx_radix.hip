@@ -159,7 +159,8 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        key[k] = (FULL || i < n) ? kin[i] : ~0ull;
+        // read once, never again: streaming loads leave L2 to the runs being written (10.1 -> 9.95 ms per sort)
+        key[k] = (FULL || i < n) ? __builtin_nontemporal_load(kin + i) : ~0ull;
     }
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
@@ -212,7 +213,7 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
             const uint64_t kk = skey[i];
             const uint32_t d = (uint32_t)(kk >> shift) & mask;
             dstv[k] = goff[d] + i;
-            kout[dstv[k]] = kk;
+            kout[dstv[k]] = kk; // (streaming stores here cost 20 %: the runs of neighbouring tiles meet in L2)
             if (dig_out) dig_out[dstv[k]] = (uint8_t)((uint32_t)(kk >> next_shift) & next_mask); // uniform test
         }
     }
@@ -221,7 +222,8 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        if (FULL || i < n) sval[lpos[k]] = IOTA ? (uint32_t)i : vin[i]; // the values are only read now: fewer live registers
+        // the values are only read now: fewer live registers
+        if (FULL || i < n) sval[lpos[k]] = IOTA ? (uint32_t)i : __builtin_nontemporal_load(vin + i);
     }
     __syncthreads();
 #pragma unroll
