@@ -260,6 +260,31 @@ def test_fused_sa_bwt_tables(gpu_ctx):
             assert (sa2 == want).all() and (o2 == oracle.o_table(x, want, sigma)).all(), (sigma, n)
 
 
+def test_unaligned_bwt_buffer(gpu_ctx):
+    """the caller's BWT buffer is the induction's symbol-byte array: the counting launches read it in aligned
+    16-byte pieces, or byte by byte when the caller's pointer is not 16-byte aligned; both round forms"""
+    import torch
+    rng = np.random.default_rng(26)
+    try:
+        for sigma, n in ((5, 300_007), (3, 70_001), (21, 200_003)):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            x[1000:3000] = x[5000]  # a run: many rounds of one bucket
+            want = oracle.sa_is(x, sigma)
+            d = torch.from_numpy(x).cuda()
+            for chain_max in (2048, 524288):
+                gpu_ctx.set_chain_max_entries(chain_max)
+                for off in (0, 1, 7):
+                    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+                    buf = torch.zeros(n + 1 + 16, dtype=torch.uint8, device="cuda")
+                    bw = buf[off: off + n + 1]
+                    gpu_ctx.sa_bwt_build_dev(d, n, sigma, sa, bw)
+                    assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, chain_max, off)
+                    assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), (sigma, chain_max, off)
+                    assert int(buf[off + n + 1:].sum()) == 0 and int(buf[:off].sum()) == 0  # nothing outside
+    finally:
+        gpu_ctx.set_chain_max_entries(-1)
+
+
 def test_wide_alphabet_tables(gpu_ctx):
     rng = np.random.default_rng(6)
     # (32, 33, 64, 65, 128: the edges of the wide kernel's tile classes, where its LDS rows are largest)

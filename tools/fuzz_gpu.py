@@ -39,6 +39,7 @@ for k in range(cases):
     ctx.set_chain_max_entries(int(rng.choice([2048, 8192, 65536, 524288, 4194304])))  # which induce rounds are chained
     ctx.force_general_path(flag == 1)
     ctx.set_no_direct_sort(flag == 2)
+    ctx.set_prefix_symbols(int(rng.choice([0, 0, 0, 12, 14, 15, 16, 17, 18, 19, 23])))  # the key kernel's static forms too
     # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
     want = oracle.sa_is_strict(x, sigma) if sigma == n + 1 else oracle.sa_is(x, sigma)
     sa = np.zeros(n + 1, np.uint32)
@@ -53,5 +54,5 @@ for k in range(cases):
         assert (o.ravel() == want_o).all(), ("O", k, sigma, n, kind)
         sa2, c2, o2 = ctx.build_tables(x, sigma)  # the fused build: BWT from the induction windows / the sort payload
         assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
-ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(524288)
+ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(524288); ctx.set_prefix_symbols(0)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
