@@ -124,7 +124,8 @@ __device__ __forceinline__ uint32_t wave_rank_inorder(uint32_t digit, bool valid
         hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m >> 32), x, 0x90);
     }
     const uint32_t r = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-    const uint32_t old = counter[(ALL || valid) ? digit : 0u];
+    // (a relaxed atomic load: the compiler must keep it ordered with the adds to the same, run-time, address)
+    const uint32_t old = __hip_atomic_load(&counter[(ALL || valid) ? digit : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_wave_barrier();
     if ((ALL || valid) && r == 0) atomicAdd(&counter[digit], (uint32_t)(__popc(lo) + __popc(hi)));
     __builtin_amdgcn_wave_barrier();

@@ -195,6 +195,9 @@ static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) 
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#endif
 template <class T> static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <class T, class V> static inline void __hip_atomic_store(T *p, V v, int, int) { *p = (T)v; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
