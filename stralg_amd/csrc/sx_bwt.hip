@@ -118,6 +118,58 @@ __global__ __launch_bounds__(kBlock) void bwt_count_small_kernel(const uint8_t *
     if (which < (uint32_t)SPLIT && a < sigma && tile < ntiles) tilehist[(uint64_t)a * ntiles + tile] = h[which][a];
 }
 
+// The same for tiles of 1024 rows (sigma <= 8): a wave per tile, 16 symbols per lane in one load, counts as popcounts
+// of symbol masks gathered by dot products (sx_device.hpp: gather16), one reduction over the wave.  (The kernel
+// above reads 8 symbols per thread and ran at 1.8 TB/s of its one byte per row.)
+__global__ __launch_bounds__(kBlock) void bwt_count_wave_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
+                                                                uint32_t sigma, uint32_t *__restrict__ tilehist,
+                                                                uint32_t ntiles)
+{
+    const int lane = lane_id();
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave_id();
+    if (tile >= ntiles) return; // whole waves
+    const uint64_t r0 = (uint64_t)tile * 1024u + (uint64_t)lane * 16u;
+    uint32_t S[4] = {0, 0, 0, 0};
+    uint32_t inside = 0xFFFFu; // rows below N
+    if (r0 + 16u <= N && ((uintptr_t)bwt & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bwt + r0);
+        S[0] = v.x, S[1] = v.y, S[2] = v.z, S[3] = v.w;
+    } else {
+        inside = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (r0 + e < N) {
+                S[e >> 2] |= (uint32_t)bwt[r0 + e] << (8 * (e & 3));
+                inside |= 1u << e;
+            }
+    }
+    // (a symbol >= 8 would be taken for its low three bits here; the totals check of the caller does not see that,
+    // so such bytes are counted as nothing: the sum then falls short of N and the caller reports the bad symbol)
+    const uint32_t high = (S[0] | S[1] | S[2] | S[3]) & 0xF8F8F8F8u;
+    if (high) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if ((S[e >> 2] >> (8 * (e & 3))) & 0xF8u) inside &= ~(1u << e);
+    }
+    const uint32_t one = 0x01010101u;
+    const uint32_t b0 = gather16(S[0] & one, S[1] & one, S[2] & one, S[3] & one, 0);
+    const uint32_t b1 = gather16(S[0] & (one << 1), S[1] & (one << 1), S[2] & (one << 1), S[3] & (one << 1), 1);
+    const uint32_t b2 = gather16(S[0] & (one << 2), S[1] & (one << 2), S[2] & (one << 2), S[3] & (one << 2), 2);
+    uint32_t n_of[8];
+#define SX_BWT_COUNT(A) n_of[A] = (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & inside);
+    SX_BWT_COUNT(0) SX_BWT_COUNT(1) SX_BWT_COUNT(2) SX_BWT_COUNT(3) SX_BWT_COUNT(4) SX_BWT_COUNT(5) SX_BWT_COUNT(6) SX_BWT_COUNT(7)
+#undef SX_BWT_COUNT
+    uint64_t even = (uint64_t)n_of[0] | (uint64_t)n_of[2] << 16 | (uint64_t)n_of[4] << 32 | (uint64_t)n_of[6] << 48; // 16-bit fields
+    uint64_t odd = (uint64_t)n_of[1] | (uint64_t)n_of[3] << 16 | (uint64_t)n_of[5] << 32 | (uint64_t)n_of[7] << 48;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        even += __shfl_xor(even, o, kWave);
+        odd += __shfl_xor(odd, o, kWave);
+    }
+    if ((uint32_t)lane < sigma && lane < 8)
+        tilehist[(uint64_t)lane * ntiles + tile] = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
+}
+
 // The tile counts [sigma][ntiles] are scanned as one flat array (device_scan); the prefix of
 // (symbol a, tile t) inside its row is flat[a*ntiles + t] - flat[a*ntiles], and the symbol
 // totals -- hence the C table (bwt.c:35-45) -- are differences of the row starts.
@@ -332,6 +384,9 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     if (d_bwt_in && small && tile_rows == 8 * kBlock)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<1>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
                   tilehist, ntiles);
+    else if (d_bwt_in && small && tile_rows == 1024)
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_wave_kernel, dim3(sx_div_up(ntiles, kWavesPerBlock)), dim3(kBlock), d_bwt_in,
+                  N, sigma, tilehist, ntiles);
     else if (d_bwt_in && small && tile_rows == 4 * kBlock)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<2>, dim3(sx_div_up(ntiles, 2)), dim3(kBlock), d_bwt_in, N,
                   sigma, tilehist, ntiles);
