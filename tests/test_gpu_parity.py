@@ -67,6 +67,13 @@ def test_classify_against_model(gpu_ctx):
     inputs = [rng.integers(1, 5, size=100_000, dtype=np.uint8), rng.integers(1, 256, size=70_000, dtype=np.uint8),
               np.concatenate([np.full(9000, 2, np.uint8), [1], np.full(5000, 3, np.uint8), [4]]).astype(np.uint8),
               np.full(20_000, 7, np.uint8)]
+    # runs that span thousands of tiles and the 4096-tile chunks of the resolve pass (types carried across chunks)
+    big = rng.integers(1, 5, size=50_000_000, dtype=np.uint8)
+    big[5_000_000:25_000_000] = 2
+    big[25_000_000] = 1            # the run ends on a smaller symbol: L-type all along
+    big[30_000_000:47_000_000] = 3
+    big[47_000_000] = 4            # ... on a larger one: S-type
+    inputs += [big, np.full(40_000_000, 3, np.uint8)]
     for x in inputs:
         n = x.size
         T = np.concatenate((x, np.zeros(1, np.uint8)))
