@@ -73,54 +73,9 @@ __global__ __launch_bounds__(kBlock) void bwt_count_kernel(const uint8_t *__rest
     }
 }
 
-// The same for sigma <= 8: a workgroup covers kBlock * 8 rows = SPLIT tiles (whole waves per tile); a thread
-// takes its 8 symbols in one load and counts them in 8-bit fields of one register pair; 64 lanes adding to
-// five hot LDS words would queue.
-template <int SPLIT>
-__global__ __launch_bounds__(kBlock) void bwt_count_small_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
-                                                                 uint32_t sigma, uint32_t *__restrict__ tilehist,
-                                                                 uint32_t ntiles)
-{
-    constexpr int PER = 8;
-    static_assert(kWavesPerBlock % SPLIT == 0, "whole waves per tile");
-    __shared__ uint32_t h[SPLIT][8];
-    if (threadIdx.x < SPLIT * 8) (&h[0][0])[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t r0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * PER;
-    const int part = (int)threadIdx.x / (kBlock / SPLIT); // which of the workgroup's tiles
-    uint32_t sym[PER];
-    if (r0 + PER <= N && ((uintptr_t)bwt & 7u) == 0) {
-        const uint64_t word = *reinterpret_cast<const uint64_t *>(bwt + r0);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) sym[k] = (uint32_t)(word >> (8 * k)) & 0xFFu;
-    } else {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) sym[k] = r0 + k < N ? (uint32_t)bwt[r0 + k] : 0xFFu;
-    }
-    uint64_t packed = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k)
-        if (sym[k] < 8u) packed += 1ull << (8u * sym[k]); // a symbol >= sigma is caught by the totals check
-    uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        even += __shfl_xor(even, o, kWave);
-        odd += __shfl_xor(odd, o, kWave);
-    }
-    const int lane = lane_id();
-    if (lane < 8) {
-        const uint32_t v = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
-        if (v) atomicAdd(&h[part][lane], v);
-    }
-    __syncthreads();
-    const uint32_t a = threadIdx.x & 7u, which = threadIdx.x >> 3;
-    const uint64_t tile = (uint64_t)blockIdx.x * SPLIT + which;
-    if (which < (uint32_t)SPLIT && a < sigma && tile < ntiles) tilehist[(uint64_t)a * ntiles + tile] = h[which][a];
-}
-
 // The same for tiles of 1024 rows (sigma <= 8): a wave per tile, 16 symbols per lane in one load, counts as popcounts
-// of symbol masks gathered by dot products (sx_device.hpp: gather16), one reduction over the wave.  (The kernel
-// above reads 8 symbols per thread and ran at 1.8 TB/s of its one byte per row.)
+// of symbol masks gathered by dot products (sx_device.hpp: gather16), one reduction over the wave.  (With 8 symbols
+// per thread in packed byte counters the launch ran at 1.8 TB/s of its one byte per row.)
 __global__ __launch_bounds__(kBlock) void bwt_count_wave_kernel(const uint8_t *__restrict__ bwt, uint64_t N,
                                                                 uint32_t sigma, uint32_t *__restrict__ tilehist,
                                                                 uint32_t ntiles)
@@ -381,15 +336,10 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
     uint32_t *totals = ar.take<uint32_t>(256 + 16); // per-symbol totals, then the grand total
     if (!bwt || !tilehist || !totals) return sx_fail_msg(ctx, SX_E_INTERNAL, "bwt: arena too small");
 
-    if (d_bwt_in && small && tile_rows == 8 * kBlock)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<1>, dim3(ntiles), dim3(kBlock), d_bwt_in, N, sigma,
-                  tilehist, ntiles);
-    else if (d_bwt_in && small && tile_rows == 1024)
+    static_assert(small_cfg<5>::tile == 1024 && small_cfg<8>::tile == 1024, "bwt_count_wave: a wave per 1024-row tile");
+    if (d_bwt_in && small)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_wave_kernel, dim3(sx_div_up(ntiles, kWavesPerBlock)), dim3(kBlock), d_bwt_in,
                   N, sigma, tilehist, ntiles);
-    else if (d_bwt_in && small && tile_rows == 4 * kBlock)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_small_kernel<2>, dim3(sx_div_up(ntiles, 2)), dim3(kBlock), d_bwt_in, N,
-                  sigma, tilehist, ntiles);
     else if (d_bwt_in)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(loop_grid), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
                   tilehist, ntiles);
