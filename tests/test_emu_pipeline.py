@@ -109,7 +109,8 @@ def test_bwt_tables(emu_ctx, golden):
         assert (ct == c["c"]).all() and (ot == c["o"]).all(), name
     # wide-alphabet O kernel (8 < sigma <= 128) and the last row across a tile edge
     rng = np.random.default_rng(9)
-    for sigma, n in ((21, 700), (128, 300), (32, 1100), (33, 600), (64, 900), (65, 300), (5, 1023), (5, 1024), (5, 2049)):
+    for sigma, n in ((21, 700), (128, 300), (32, 1100), (33, 600), (64, 900), (65, 300), (5, 1023), (5, 1024), (5, 2049), (3, 1500),
+                     (4, 1025), (6, 2100), (7, 1030), (8, 1500), (2, 700)):
         x = rng.integers(1, sigma, size=n, dtype=np.uint8)
         sa = oracle.sa_is(x, sigma)
         ct, ot = emu_ctx.bwt_tables(x, sa, sigma)

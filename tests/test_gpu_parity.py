@@ -248,7 +248,8 @@ def test_fused_sa_bwt_tables(gpu_ctx):
     """sx_sa_bwt_build_dev + sx_bwt_tables_from_bwt_dev (what bench.py times) and sx_build_tables"""
     import torch
     rng = np.random.default_rng(16)
-    for sigma, n in ((5, 1 << 20), (5, 1023), (4, 77), (17, 50_000), (128, 20_000), (200, 30_000)):
+    for sigma, n in ((5, 1 << 20), (5, 1023), (4, 77), (3, 9000), (6, 300_001), (7, 5000), (8, 70_000), (17, 50_000), (128, 20_000),
+                     (200, 30_000)):
         x = rng.integers(1, sigma, size=n, dtype=np.uint8)
         want = oracle.sa_is(x, sigma)
         d = torch.from_numpy(x).cuda()

@@ -11,7 +11,7 @@ ctx = stralg_amd.Context(0)
 t0 = time.time()
 paths = {}
 for k in range(cases):
-    sigma = int(rng.choice([2, 3, 5, 5, 5, 8, 9, 16, 17, 21, 32, 33, 64, 65, 127, 128, 200, 256]))
+    sigma = int(rng.choice([2, 3, 4, 5, 5, 5, 6, 7, 8, 9, 16, 17, 21, 32, 33, 64, 65, 127, 128, 200, 256]))
     n = int(rng.choice([1, 2, 3, 17, 255, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 65537, 100003, 300007,
                         1048577, 2500001, 2500001, 9000001]))
     n = max(1, n + int(rng.integers(-3, 4)))
