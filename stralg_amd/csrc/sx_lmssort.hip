@@ -137,12 +137,12 @@ __device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, ui
 // one byte-align step each; window and key are dot products (sx_window.hpp, prefix_key_dot).  The key kernel
 // is bound by instruction issue (260 instructions per suffix with run-time C, base and window shape: 2.0 ms
 // at 1 GiB); this form needs about 90.
-template <int C, int CW>
+template <int C, int CW, int B>
 __device__ __forceinline__ uint64_t key_and_window_dna(const uint8_t *img, uint32_t off, const pkey_cfg &kc,
                                                        uint32_t kbits)
 {
-    constexpr int B = 2;
-    static_assert(C >= 1 && CW >= 1 && CW <= 14 && C + CW <= 32, "window and key inside one 32-byte span");
+    static_assert(B == 2 || B == 3, "two-bit codes (up to 4 symbols) or three-bit codes (5 ... 8 symbols)");
+    static_assert(C >= 1 && CW >= 1 && CW * B <= 28 && C + CW <= 32, "window and key inside one 32-byte span");
     const uint32_t *w32 = reinterpret_cast<const uint32_t *>(img + (off & ~3u));
     const uint32_t sh = off & 3u;
     uint32_t raw[9], W[9];
@@ -151,15 +151,23 @@ __device__ __forceinline__ uint64_t key_and_window_dna(const uint8_t *img, uint3
 #pragma unroll
     for (int k = 0; k < 8; ++k) W[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh); // bytes 4k .. 4k+3 of the span
     W[8] = 0;
-    // window: span bytes 0 .. CW-1, the farthest symbol first (wnd_from_bytes with B = 2)
-    constexpr uint32_t wcoef = (1u << 24) | (1u << (16 + B)) | (1u << (8 + 2 * B)) | (1u << (3 * B));
+    // window: span bytes 0 .. CW-1, the farthest symbol first (wnd_from_bytes).  Two-bit codes: the weights 64, 16, 4,
+    // 1 of a word's symbols fit a byte each, one dot product per word; three-bit codes: 512 does not, two symbols
+    // (weights 8, 1) per dot product.
     uint32_t a = 0;
 #pragma unroll
     for (int k = 0; k < (CW + 3) / 4; ++k) {
-        if (k < CW / 4) a = __builtin_amdgcn_udot4(W[k], wcoef, a << (4 * B), false);
-        else a = __builtin_amdgcn_udot4(W[k], wcoef >> ((8 * (4 - CW % 4)) & 31), a << ((CW % 4) * B), false);
+        constexpr uint32_t wcoef = (1u << 24) | (1u << (16 + 2)) | (1u << (8 + 4)) | (1u << 6);
+        const int nsym = CW - 4 * k < 4 ? CW - 4 * k : 4; // (static: the loop is unrolled)
+        if (B == 2) {
+            a = __builtin_amdgcn_udot4(W[k], wcoef >> ((8 * (4 - nsym)) & 31), a << (nsym * 2), false);
+        } else {
+            const int nh = nsym < 2 ? nsym : 2, nl = nsym - nh;
+            a = __builtin_amdgcn_udot4(W[k], nh == 2 ? 0x00000108u : 0x00000001u, a << (3 * nh), false);
+            if (nl) a = __builtin_amdgcn_udot4(W[k], nl == 2 ? 0x01080000u : 0x00010000u, a << (3 * nl), false);
+        }
     }
-    constexpr uint32_t bias = ((1u << (B * CW)) - 1u) / 3u; // a one in each code field
+    constexpr uint32_t bias = ((1u << (B * CW)) - 1u) / ((1u << B) - 1u); // a one in each code field
     const uint32_t wnd = ((a - bias) << kCntBits) | (uint32_t)CW;
     // key: span bytes CW .. CW + C
     constexpr int NW = (C + 3) / 4, R = C % 4, d0 = CW / 4, sb = 8 * (CW % 4);
@@ -187,8 +195,8 @@ __device__ __forceinline__ uint64_t key_and_window_dna(const uint8_t *img, uint3
 // listed in LDS from the LMS bit array, then every thread turns listed positions into
 // (key, position) pairs at the tile's offset in the global LMS order.  This is the compaction of
 // the LMS positions (role of sa_is.c:203-218 place_LMS's scan) and the key generation in one pass.
-// CS > 0: kc.C == CS, kc.dot, and the windows are WS two-bit codes (the host checks).
-template <int CS, int WS>
+// CS > 0: kc.C == CS, kc.dot, and the windows are WS codes of BS bits (the host checks).
+template <int CS, int WS, int BS>
 __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__restrict__ T,
                                                                const uint16_t *__restrict__ lmsbits,
                                                                const uint32_t *__restrict__ tile_off, pkey_cfg kc,
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
         const uint32_t p = spos[i];
         uint64_t key;
         if (CS > 0 && p >= (uint32_t)WS) { // (everywhere but at the very start of the text)
-            key = key_and_window_dna<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1)>(img, (uint32_t)((uint64_t)(p - (uint32_t)WS) - origin), kc, kbits);
+            key = key_and_window_dna<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1), (CS > 0 ? BS : 2)>(img, (uint32_t)((uint64_t)(p - (uint32_t)WS) - origin), kc, kbits);
         } else {
             if (kc.C <= 32) { // uniform
                 uint64_t q[4];
@@ -777,18 +785,24 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             const pkey_cfg kc = pkey_make(base, C);
             // DNA-like texts: everything static for the usual prefix lengths (base 5: the window takes what
             // 64 - kbits - 4 bits hold)
-            const bool dna = kc.dot && wcfg.B == 2 && kbits >= 8;
-#define SX_TILE_KEYS(CS, WS)                                                                                           \
-    sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel<CS, WS>, dim3(ti.ntiles), block, ti.T,   \
-              (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0)
-            const uint32_t shape = dna ? C * 16 + wcfg.CW : 0u;
+            const bool dna = kc.dot && (wcfg.B == 2 || wcfg.B == 3) && kbits >= 8;
+#define SX_TILE_KEYS(CS, WS, BS)                                                                                       \
+    sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel<CS, WS, BS>, dim3(ti.ntiles), block,     \
+              ti.T, (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0)
+            const uint32_t shape = dna ? (C * 16 + wcfg.CW) * 4 + wcfg.B : 0u;
             switch (shape) {
-            case 14 * 16 + 13: SX_TILE_KEYS(14, 13); break;
-            case 15 * 16 + 12: SX_TILE_KEYS(15, 12); break;
-            case 16 * 16 + 11: SX_TILE_KEYS(16, 11); break;
-            case 17 * 16 + 10: SX_TILE_KEYS(17, 10); break;
-            case 18 * 16 + 9: SX_TILE_KEYS(18, 9); break;
-            default: SX_TILE_KEYS(0, 0); break;
+            // base 5 (A C G T): 64 Mi ... 4 Gi symbols
+            case (14 * 16 + 13) * 4 + 2: SX_TILE_KEYS(14, 13, 2); break;
+            case (15 * 16 + 12) * 4 + 2: SX_TILE_KEYS(15, 12, 2); break;
+            case (16 * 16 + 11) * 4 + 2: SX_TILE_KEYS(16, 11, 2); break;
+            case (17 * 16 + 10) * 4 + 2: SX_TILE_KEYS(17, 10, 2); break;
+            case (18 * 16 + 9) * 4 + 2: SX_TILE_KEYS(18, 9, 2); break;
+            // base 6 (A C G N T)
+            case (13 * 16 + 8) * 4 + 3: SX_TILE_KEYS(13, 8, 3); break;
+            case (14 * 16 + 7) * 4 + 3: SX_TILE_KEYS(14, 7, 3); break;
+            case (15 * 16 + 7) * 4 + 3: SX_TILE_KEYS(15, 7, 3); break;
+            case (16 * 16 + 6) * 4 + 3: SX_TILE_KEYS(16, 6, 3); break;
+            default: SX_TILE_KEYS(0, 0, 0); break;
             }
 #undef SX_TILE_KEYS
         }

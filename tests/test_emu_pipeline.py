@@ -65,12 +65,14 @@ def test_static_key_shapes(emu_ctx):
     x = rng.integers(1, 5, size=9000, dtype=np.uint8)
     x[5000:5040] = x[200:240]  # some ties for the refinement rounds as well
     y = np.concatenate([x[:40], x[:40], x[3:2000]])  # LMS positions inside the first symbols of the text
+    z = rng.integers(1, 6, size=7000, dtype=np.uint8)  # five symbols (DNA with N): three-bit window codes
+    z[3000:3050] = z[100:150]
     try:
-        for text in (x, y):
-            want = oracle.sa_is(text, 5)
-            for C in (13, 14, 15, 16, 17, 18, 19):
+        for text, sigma in ((x, 5), (y, 5), (z, 6), (np.concatenate([z[:30], z[:30], z[:900]]), 6)):
+            want = oracle.sa_is(text, sigma)
+            for C in (12, 13, 14, 15, 16, 17, 18, 19):
                 emu_ctx.set_prefix_symbols(C)
-                assert (_sa(emu_ctx, text, 5) == want).all(), C
+                assert (_sa(emu_ctx, text, sigma) == want).all(), (sigma, C)
                 assert emu_ctx.last_stats()["key_slots"] == C
     finally:
         emu_ctx.set_prefix_symbols(0)

@@ -166,16 +166,17 @@ def test_tie_refinement_rounds(gpu_ctx):
 def test_static_key_shapes(gpu_ctx):
     """the key kernel's static forms for DNA-like texts (the prefix lengths of 64 Mi ... 4 Gi symbol inputs),
     forced on a small text, and the run-time form next to them: same suffix array, same BWT tables"""
-    x = synth(1 << 20, 5, 23)
-    x[500_000:500_060] = x[1000:1060]
-    want = oracle.sa_is(x, 5)
-    c_want, o_want = oracle.c_table(x, 5), oracle.o_table(x, want, 5)
     try:
-        for C in (12, 13, 14, 15, 16, 17, 18, 19, 20):
-            gpu_ctx.set_prefix_symbols(C)
-            sa, c, o = gpu_ctx.build_tables(x, 5)
-            assert gpu_ctx.last_stats()["key_slots"] == C
-            assert (sa == want).all() and (c == c_want).all() and (o == o_want).all(), C
+        for sigma in (5, 6):  # (A C G T: two-bit window codes; with N: three-bit ones)
+            x = synth(1 << 20, sigma, 23)
+            x[500_000:500_060] = x[1000:1060]
+            want = oracle.sa_is(x, sigma)
+            c_want, o_want = oracle.c_table(x, sigma), oracle.o_table(x, want, sigma)
+            for C in (12, 13, 14, 15, 16, 17, 18, 19, 20):
+                gpu_ctx.set_prefix_symbols(C)
+                sa, c, o = gpu_ctx.build_tables(x, sigma)
+                assert gpu_ctx.last_stats()["key_slots"] == C
+                assert (sa == want).all() and (c == c_want).all() and (o == o_want).all(), (sigma, C)
     finally:
         gpu_ctx.set_prefix_symbols(0)
 
