@@ -714,6 +714,23 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             v *= eff;
             ++C;
         }
+        // Skewed symbol frequencies (a genome with 5 % N, a GC-poor one): two suffixes agree on a symbol with
+        // probability sum p^2, not 1 / maxc.  A prefix that is too short costs a whole second sort with the longest
+        // key; one symbol too many costs at most a pass.  So the prefix is also made long enough for <= ~6 % ties
+        // under the text's own collision rate (uniform text: never the larger of the two; symbols that only occur
+        // in long runs, like N, hardly enter the rate but do enter maxc: that case needs the margin).
+        double sum_p2 = 0.0;
+        const double n_sym = (double)ti.N - 1.0;
+        for (int c = 1; c < 256 && n_sym > 0; ++c) {
+            const double pc = (double)ti.h_all[c] / n_sym;
+            sum_p2 += pc * pc;
+        }
+        if (sum_p2 > 0.0 && sum_p2 < 1.0) {
+            const double eff_c = 1.0 / sum_p2, target_c = 16.0 * (double)m;
+            uint32_t Cc = 1;
+            for (double u = eff_c; u < target_c && Cc < Cmax; u *= eff_c) ++Cc;
+            if (Cc > C) C = Cc;
+        }
     }
     if (ctx->prefix_symbols > 0) C = (uint32_t)ctx->prefix_symbols < Cmax ? (uint32_t)ctx->prefix_symbols : Cmax; // (tests)
     const uint32_t cap = (uint32_t)(m / 4 + 1024);
