@@ -766,6 +766,83 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
     }
 }
 
+// ---- very long runs -------------------------------------------------------------------------------------
+// The tail kernel's run jump writes 4096 rounds a step with one workgroup: 11 us a step, 45 ms for the 16 Mi
+// symbols of a gap in a reference assembly (runs of N of up to 30 Mbp, one or more per chromosome, all in one
+// bucket).  When a bucket's range is down to a handful of entries and the tail kernel has not finished them, the
+// whole device takes over: `run_probe` finds how many symbols c lie immediately to the left of every entry (L, the
+// minimum, looking kRunProbe symbols far), `run_fill` writes the L rounds (entries - 1, entries - 2, ...) into the
+// next L x len slots of bucket c (each with its window and symbol byte), `run_commit` advances the cursor and
+// leaves the last round as the range.  L = 0 changes nothing.
+constexpr uint32_t kRunProbe = 1u << 26;
+constexpr uint32_t kRunEntries = 64; // runs of c that are alive in the bucket at the same time (a gap per chromosome)
+__global__ __launch_bounds__(kBlock) void run_probe_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA,
+                                                          const uint32_t *__restrict__ range, uint32_t c,
+                                                          uint32_t *__restrict__ run_len /* preset to ~0 */)
+{
+    const uint32_t lo = range[0], len = range[1] - lo;
+    if (len == 0 || len > kRunEntries || blockIdx.y >= len) { // (uniform) not a handful of entries: nothing to jump over
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (len == 0 || len > kRunEntries)) atomicMin(run_len, 0u);
+        return;
+    }
+    const uint32_t p = SA[lo + blockIdx.y]; // (the minimum over the entries does not depend on their order)
+    const uint32_t d0 = (blockIdx.x * (uint32_t)kBlock + threadIdx.x) * 16u; // this thread looks at p-d0-1 ... p-d0-16
+    if (d0 >= p) {
+        if (d0 < p + 16u) atomicMin(run_len, p); // the text starts here: at most p symbols to the left
+        return;
+    }
+    const uint32_t cnt = p - d0 < 16u ? p - d0 : 16u;
+    uint32_t first_other = cnt; // symbols c in a row, going left from p - d0
+    for (uint32_t e = 0; e < cnt; ++e)
+        if (T[p - d0 - 1u - e] != (uint8_t)c) {
+            first_other = e;
+            break;
+        }
+    if (first_other < 16u) atomicMin(run_len, d0 + first_other); // (cnt < 16: the text starts there)
+}
+
+// rounds the jump covers: every entry of the range has at least that many symbols c to its left
+__device__ __forceinline__ uint32_t run_length(const uint32_t *run_len, uint32_t len)
+{
+    if (len == 0 || len > kRunEntries) return 0;
+    const uint32_t L = *run_len, most = kRunProbe / len; // (at most kRunProbe entries a jump: fits 32-bit offsets)
+    return L > most ? most : L;
+}
+
+template <class WT>
+__global__ __launch_bounds__(kBlock) void run_fill_kernel(const uint8_t *__restrict__ T, uint32_t *SA, WT *__restrict__ WN,
+                                                         uint8_t *__restrict__ BW, const uint32_t *__restrict__ range,
+                                                         const uint32_t *__restrict__ cursor, uint32_t c, int rev, int dir,
+                                                         wnd_cfg cfg, const uint32_t *__restrict__ run_len)
+{
+    const uint32_t lo = range[0], len = range[1] - lo;
+    const uint64_t total = (uint64_t)run_length(run_len, len) * len;
+    const uint32_t cur = cursor[c];
+    // round j holds the range's entries minus j, in the same order, in the next len slots (as the tail kernel's jump)
+    for (uint64_t o = (uint64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t j = (uint32_t)(o / len) + 1u, i = (uint32_t)(o % len);
+        const uint32_t v = SA[lo + (rev ? len - 1u - i : i)] - j;
+        const uint32_t dst = dir > 0 ? cur + (uint32_t)o : cur - 1u - (uint32_t)o;
+        const WT nw = v ? wnd_fill<WT>(T, v, cfg) : (WT)0;
+        SA[dst] = v;
+        WN[dst] = nw;
+        BW[dst] = wnd_symbol<WT>(nw, cfg);
+    }
+}
+
+__global__ void run_commit_kernel(uint32_t *__restrict__ range, uint32_t *__restrict__ cursor, uint32_t c, int dir,
+                                  const uint32_t *__restrict__ run_len)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t lo = range[0], len = range[1] - lo;
+    const uint32_t total = run_length(run_len, len) * len;
+    if (total == 0) return;
+    const uint32_t cur = cursor[c];
+    cursor[c] = dir > 0 ? cur + total : cur - total;
+    range[0] = dir > 0 ? cur + total - len : cur - total; // the last round written: the next round's input
+    range[1] = range[0] + len;
+}
+
 // range <- [lo, hi) given by the host, or [a, cursor[c]) / [cursor[c], b) for the first round of a bucket
 __global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, const uint32_t *cursor, int c, int which)
 {
@@ -842,6 +919,7 @@ template <class WT> struct induce_state {
     uint32_t *cursor[2]; // ping-pong: a round reads one, its last tile writes the other
     uint32_t *ranges;    // (kMaxSpec + 2) x {lo, hi}
     uint32_t *tickets;   // kMaxSpec + 2
+    uint32_t *run_len;   // symbols a device-wide run jump covers
     uint64_t *status;
     uint32_t chain_max; // rounds up to this many entries take the chained launch
     uint32_t *hist;   // [nk][stride] tile counts of the three-launch form
@@ -919,6 +997,8 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     ctx->stats.induce_rounds++;
 }
 
+// steps of the tail kernel per launch: a run that outlasts them goes to the device-wide jump (run_fill)
+constexpr uint32_t kTailIters = 64;
 template <class WT>
 void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, int mode, uint32_t c, int dir)
 {
@@ -928,11 +1008,11 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
-                  cur, nxt, dir, 4096u);
+                  cur, nxt, dir, kTailIters);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
-                  cur, nxt, dir, 4096u);
+                  cur, nxt, dir, kTailIters);
     st.par ^= 1;
 }
 
@@ -980,6 +1060,20 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         // a long run of symbol c: carry on from the last range
         sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, r[0], r[1],
                   (const uint32_t *)st.cursor[st.par], (int)c, 0);
+        if (r[1] - r[0] <= kRunEntries) {
+            // a handful of entries deep inside runs: the device-wide jump, twice (a run may be longer than one probe looks)
+            for (int rep = 0; rep < 2; ++rep) {
+                SX_CHECK(hipMemsetAsync(st.run_len, 0xFF, sizeof(uint32_t), ctx->stream));
+                const uint64_t look = st.N < (uint64_t)kRunProbe ? st.N : (uint64_t)kRunProbe; // (no run is longer than the text)
+                sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, run_probe_kernel, dim3(sx_div_up(look, 16 * kBlock), r[1] - r[0]),
+                          dim3(kBlock), st.T, (const uint32_t *)st.SA, (const uint32_t *)st.ranges, c, st.run_len);
+                sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, run_fill_kernel<WT>, dim3(4096), dim3(kBlock), st.T, st.SA, st.WN, st.BW,
+                          (const uint32_t *)st.ranges, (const uint32_t *)st.cursor[st.par], c, rev, dir, st.cfg,
+                          (const uint32_t *)st.run_len);
+                sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, run_commit_kernel, dim3(1), dim3(1), st.ranges, st.cursor[st.par], c, dir,
+                          (const uint32_t *)st.run_len);
+            }
+        }
         first = false;
     }
 }
@@ -1008,7 +1102,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.cursor[1] = arena.take<uint32_t>(256);
     st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 3));
     st.tickets = arena.take<uint32_t>(kMaxSpec + 3);
-    if (!st.WN || !st.BW || !seedW || !st.cursor[0] || !st.cursor[1] || !st.ranges || !st.tickets)
+    st.run_len = arena.take<uint32_t>(4);
+    if (!st.WN || !st.BW || !seedW || !st.cursor[0] || !st.cursor[1] || !st.ranges || !st.tickets || !st.run_len)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
 
     // bucket boundaries on the host (sa_is.c:176-201)

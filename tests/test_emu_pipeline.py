@@ -91,6 +91,18 @@ def test_long_repeats_finish_by_comparison(emu_ctx):
         assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, (copies, L, st)
 
 
+def test_very_long_run(emu_ctx):
+    """a run that outlasts the tail kernel's 256 steps of 4096 rounds: the device-wide run jump"""
+    rng = np.random.default_rng(33)
+    x = np.concatenate([rng.integers(1, 5, size=3000, dtype=np.uint8), np.full(256 * 4096 + 70_000, 3, np.uint8), [1],
+                        rng.integers(1, 5, size=3000, dtype=np.uint8)]).astype(np.uint8)
+    assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all()
+    # two runs of the same symbol alive in the bucket at once (the jump takes both entries), S-type this time
+    y = np.concatenate([x[:500], np.full(256 * 4096 + 9000, 2, np.uint8), [4], x[:700], np.full(256 * 4096 + 30_000, 2, np.uint8),
+                        [3], x[:300]]).astype(np.uint8)
+    assert (_sa(emu_ctx, y, 5) == oracle.sa_is(y, 5)).all()
+
+
 def test_both_induce_round_forms(emu_ctx):
     """large rounds (count / offsets / scatter launches) and small rounds (one chained launch)"""
     rng = np.random.default_rng(12)

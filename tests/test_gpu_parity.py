@@ -217,6 +217,30 @@ def test_long_runs(gpu_ctx):
         assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), name
 
 
+def test_very_long_runs(gpu_ctx):
+    """runs that outlast the tail kernel's steps (more than 256 x 4096 symbols): the device-wide run jump, in the L
+    pass (run followed by a smaller symbol), in the S pass (by a larger one), at the start of the text, as the whole
+    text, and two runs of the same symbol whose jumps alternate; BWT and tables through the same build"""
+    rng = np.random.default_rng(31)
+    r = lambda n, hi=5: rng.integers(1, hi, size=n, dtype=np.uint8)
+    M = 1 << 20
+    cases = {
+        "all-equal-5M": (np.full(5 * M, 1, np.uint8), 2),
+        "l-type-run": (np.concatenate([r(M), np.full(3 * M, 4, np.uint8), [1], r(M)]).astype(np.uint8), 5),
+        "s-type-run": (np.concatenate([r(M), np.full(3 * M, 2, np.uint8), [4], r(M)]).astype(np.uint8), 5),
+        "run-at-start": (np.concatenate([np.full(2 * M + 5, 3, np.uint8), r(M)]), 5),
+        "n-runs": (np.concatenate([r(M), np.full(4 * M, 5, np.uint8), r(M), np.full(2 * M + 77, 5, np.uint8), r(1000)]), 6),
+        "bytes-run": (np.concatenate([r(100_000, 200), np.full(2 * M, 77, np.uint8), r(100_000, 200)]), 200),
+    }
+    for name, (x, sigma) in cases.items():
+        want = oracle.sa_is_strict(x, sigma)
+        assert (gpu_ctx.sa_build(x, sigma) == want).all(), name
+        if sigma <= 8:
+            sa, c, o = gpu_ctx.build_tables(x, sigma)
+            assert (sa == want).all() and (c == oracle.c_table(x, sigma)).all(), name
+            assert (o == oracle.o_table(x, want, sigma)).all(), name
+
+
 def test_structured_against_oracle(gpu_ctx):
     rng = np.random.default_rng(5)
     cases = {
