@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- Msuffixes/s of suffix-array + BWT C/O-table construction on MI355X.
 
-A "step" is one pass of the hot path over one record: sa_is_construction's device
-path (sx_sa_build_dev) followed by the C/O-table build (sx_bwt_tables_dev) on a
-synthetic DNA record (sigma = 4 letters + sentinel) already resident in HBM.
-Workload at N=1: BASELINE.json configs[2], "SA-IS + BWT C/O-table build on 1 GiB
-random DNA".  With --gpus N every rank builds its own independent record (the
-per-record loop of bwt_readmapper.c:54-62 farmed one per GPU): weak scaling, no
-collective on the data path; torch.distributed is used only for the timing
-barrier and the max-over-ranks reduction.
+A "step" is one pass of the hot path over one record already resident in HBM:
 
-Prints ONE JSON line on rank 0.
+  --gpus 1 (default)   BASELINE.json configs[2]: sa_is_construction's device path with the BWT
+                       handed over by the induced-sort passes (sx_sa_bwt_build_dev), then the C/O
+                       tables (sx_bwt_tables_from_bwt_dev), on 1 GiB of synthetic DNA.
+  --gpus N > 1         BASELINE.json configs[4]: every rank builds its own FASTA record, the loop of
+                       tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62 farmed one record per
+                       GPU: FASTA image in HBM -> sx_fasta_pack_dev -> sx_remap_dev ->
+                       sx_sa_bwt_build_dev -> sx_bwt_tables_from_bwt_dev.  Weak scaling, no collective
+                       on the data path; torch.distributed only carries the timing barrier and the
+                       max / sum of the bookkeeping scalars.  (--workload fasta gives the same step at N = 1.)
+
+Run as `python bench.py --gpus N` it starts the N ranks itself (fresh child processes, before
+anything touches a GPU); under torch.distributed.run it takes RANK / LOCAL_RANK / WORLD_SIZE from the
+environment.  Rank 0 prints ONE JSON line.  After the timed region the last step's results are
+verified on the device ("verified"), and outside it the line also reports the host-buffer
+(PCIe-inclusive) rates ("end_to_end"), the FASTA-ingest-inclusive rate ("fasta_record") and the
+reference's own CPU path on a bounded sample ("cpu_baseline").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,40 +32,89 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md, chip-level parameters)
+PMC_TRAFFIC = os.path.join("profiles", "pmc_traffic.json")
 
 
-def cpu_baseline(log2_sample, sigma, seed):
-    """Oracle (single thread) on a bounded sample of the same stream: SA + C/O tables."""
-    import numpy as np
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2n", type=int, default=int(os.environ.get("STRALG_BENCH_LOG2N", "30")))
+    ap.add_argument("--n", type=int, default=0, help="symbols per record (overrides --log2n)")
+    ap.add_argument("--sigma", type=int, default=5, help="alphabet_size of the uniform workloads")
+    ap.add_argument("--workload", default=None,
+                    help="dna (default at --gpus 1) | fasta (default at --gpus > 1) | bytes | uniform | genome_like | "
+                         "n_runs | text_like | periodic")
+    ap.add_argument("--no-tables", action="store_true", help="suffix array only")
+    ap.add_argument("--cpu-log2n", type=int, default=int(os.environ.get("STRALG_BENCH_CPU_LOG2N", "25")))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last step's results")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
+    ap.add_argument("--e2e-log2n", default="28,30", help="sizes of the host-buffer measurements")
+    return ap.parse_args(argv)
+
+
+# ---- launcher: python bench.py --gpus N starts its own ranks -------------------------------------------
+
+def launch_ranks(args):
+    """N fresh child processes, one per GPU; this process never touches a GPU (it only waits)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:  # a rank failed: the others would wait at the barrier for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------
+
+def cpu_baseline(x, sigma, what):
+    """the reference's own sa_is_construction (oracle/_ref; or the oracle port) on one host core, on a bounded
+    sample of the record rank 0 built (x: numpy uint8): SA, plus C/O tables on a smaller one"""
     import oracle
-    from stralg_amd.synth import synth
-    n = 1 << log2_sample
-    x = synth(n, sigma, seed)
+    from oracle import pyoracle
+    n = int(x.size)
     t0 = time.perf_counter()
     sa = oracle.sa_is(x, sigma)
     t1 = time.perf_counter()
     levels = oracle.last_levels()
     # C/O tables on a smaller sample: the O table takes (n+2) * sigma * 4 bytes of host memory
-    o_n = min(n, 1 << 22)
-    xs = x[:o_n]
-    sas = sa if o_n == n else oracle.sa_is(xs, sigma)
-    t2 = time.perf_counter()
-    oracle.c_table(xs, sigma)
-    oracle.o_table(xs, sas, sigma)
-    t3 = time.perf_counter()
+    out = {"unit": "Msuffixes/s", "cores": 1, "host_cpus": os.cpu_count(), "levels": levels[:6]}
+    tables = ""
+    if sigma <= 128:
+        o_n = min(n, 1 << 22)
+        xs = x[:o_n]
+        sas = sa if o_n == n else oracle.sa_is(xs, sigma)
+        t2 = time.perf_counter()
+        oracle.c_table(xs, sigma)
+        oracle.o_table(xs, sas, sigma)
+        t3 = time.perf_counter()
+        tables = (f"; C/O tables on {o_n} symbols ({t3 - t2:.2f} s = "
+                  f"{(o_n + 1) / (t3 - t2) / 1e6:.1f} Mpositions/s)")
     port = (n + 1) / (t1 - t0) / 1e6
-    out = {
-        "value": round(port, 3),
-        "unit": "Msuffixes/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"oracle_sa_is on the first 2^{log2_sample} symbols of the same stream ({t1 - t0:.1f} s); "
-                  f"C/O tables on 2^{o_n.bit_length() - 1} symbols ({t3 - t2:.2f} s = "
-                  f"{(o_n + 1) / (t3 - t2) / 1e6:.1f} Mpositions/s)",
-        "host_cpus": os.cpu_count(),
-        "levels": levels[:6],
-    }
-    from oracle import pyoracle
+    out.update(value=round(port, 3), kind="port",
+               sample=f"oracle_sa_is on {what} ({t1 - t0:.1f} s)" + tables)
     if pyoracle.have_ref():
         # the unmodified reference (oracle/_ref, built from the reference's sources by oracle/Makefile): its own
         # sa_is_construction on the same sample is the baseline proper; the port's rate stays in the text
@@ -65,82 +124,151 @@ def cpu_baseline(log2_sample, sigma, seed):
         t5 = time.perf_counter()
         if not (sa_ref == sa).all():
             raise RuntimeError("reference and oracle disagree on the baseline sample")
-        out["value"] = round((n + 1) / (t5 - t4) / 1e6, 3)
-        out["kind"] = "reference"
-        out["sample"] = (f"the reference's sa_is_construction on the first 2^{log2_sample} symbols of the same stream "
-                         f"({t5 - t4:.1f} s; the oracle port: {port:.1f} Msuffixes/s); " + out["sample"].split("; ", 1)[1])
+        out.update(value=round((n + 1) / (t5 - t4) / 1e6, 3), kind="reference",
+                   sample=f"the reference's sa_is_construction on {what} "
+                          f"({t5 - t4:.1f} s; the oracle port: {port:.1f} Msuffixes/s)" + tables)
     return out
 
 
 def pmc_traffic(log2n, sigma, tables, klass):
     """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
-    same command (profiles/pmc_traffic.json, made by tools/profile.sh + tools/pmc_to_json.py); PMC
-    counters cannot be read from inside the process, so this is null for workloads not profiled."""
+    same command (profiles/pmc_traffic.json, made by tools/profile.sh + tools/pmc_to_json.py).  PMC counters
+    cannot be read from inside the process: the figure is replayed from that file, not measured in this run
+    (roofline.traffic_source says so); null for workloads that were not profiled."""
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        doc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
         c = doc[f"log2n={log2n} sigma={sigma} tables={int(tables)}"]["classes"][klass]
         return round(c["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2n", type=int, default=int(os.environ.get("STRALG_BENCH_LOG2N", "30")))
-    ap.add_argument("--sigma", type=int, default=5)
-    ap.add_argument("--no-tables", action="store_true", help="suffix array only")
-    ap.add_argument("--cpu-log2n", type=int, default=int(os.environ.get("STRALG_BENCH_CPU_LOG2N", "25")))
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+# ---- host-buffer (PCIe-inclusive) measurements, outside the timed region --------------------------------------
 
+def end_to_end(ctx, sizes, seed):
+    """What a caller of the reference API sees (stralg/bwt.c:134-161 hands over malloc'd host arrays):
+    sx_build_tables on pageable host buffers, and build_complete_table itself (remap, tables, o_indices) with and
+    without the reverse table.  Second call of each (the first pays hipMalloc of the staging slab)."""
+    import ctypes as C
+    import numpy as np
+    import psutil
+    from stralg_amd.synth import synth
+    lib = ctx.lib
+    lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
+    lib.build_complete_table.restype = C.c_void_p
+    lib.completely_free_bwt_table.argtypes = [C.c_void_p]
+    lib.completely_free_bwt_table.restype = None
+    out = {}
+    for log2n in sizes:
+        n = 1 << log2n
+        N = n + 1
+        need = (N + 1) * 5 * 4 * 2 + N * 4 + (N + 1) * 8 * 2 + 3 * n  # O + RO + SA + row pointers + strings
+        if psutil.virtual_memory().available < need * 1.25:
+            out[f"2^{log2n}"] = {"skipped": f"needs {need >> 30} GiB of free host memory"}
+            continue
+        x = synth(n, 5, seed)
+        sa = np.empty(N, dtype=np.uint32)
+        c = np.zeros(5, dtype=np.uint32)
+        o = np.empty((N + 1) * 5, dtype=np.uint32)
+        moved = n + 4 * N + 4 * 5 * (N + 1)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ctx._check(lib.sx_build_tables(ctx.h, x.ctypes.data, n, 5, sa.ctypes.data, c.ctypes.data, o.ctypes.data), "sx_build_tables")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        del sa, o
+        letters = np.frombuffer(b"\0ACGT", dtype=np.uint8)[x].tobytes()  # NUL-terminated by bytes' own terminator
+        del x
+        res = {"sx_build_tables_ms": round(best * 1e3, 1), "pcie_GBps": round(moved / best / 1e9, 2),
+               "sx_build_tables_Msuffixes_per_s": round(N / best / 1e6, 1)}
+        for key, rev in (("build_complete_table_ms", False), ("with_ro_ms", True)):
+            t0 = time.perf_counter()
+            t = lib.build_complete_table(letters, rev)
+            dt = time.perf_counter() - t0
+            lib.completely_free_bwt_table(t)
+            res[key] = round(dt * 1e3, 1)
+        res["build_complete_table_Msuffixes_per_s"] = round(N / (res["build_complete_table_ms"] * 1e-3) / 1e6, 1)
+        res["bytes_over_pcie"] = moved
+        out[f"2^{log2n}"] = res
+    out["note"] = ("pageable malloc'd host buffers as the reference's ownership rules require; build_complete_table "
+                   "includes the host remap and the o_indices row-pointer table; with_ro_ms adds the reverse table")
+    return out
+
+
+# ---- one rank ----------------------------------------------------------------------------------------------
+
+def run_rank(args):
     import torch
     import stralg_amd
+    from stralg_amd import farm, workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one process per GPU; STRALG_BENCH_BACKEND=gloo + STRALG_BENCH_SHARE_GPU=1 let the N > 1 path be
-    # exercised on a single-GPU box (tests): every rank then uses cuda:0 and the scalars travel on the CPU
-    backend = os.environ.get("STRALG_BENCH_BACKEND", "nccl")
+    # STRALG_BENCH_BACKEND=gloo + STRALG_BENCH_SHARE_GPU=1 let the N > 1 path be exercised on a single-GPU box: every
+    # rank then uses cuda:0 and the scalars travel on the CPU.  STRALG_BENCH_EMU=1 (tests, no GPU) runs the same
+    # code over the CPU execution harness of the kernels (tests/emu): torch CPU tensors, gloo.
+    emu = os.environ.get("STRALG_BENCH_EMU") == "1"
+    backend = "gloo" if emu else os.environ.get("STRALG_BENCH_BACKEND", "nccl")
     if os.environ.get("STRALG_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if emu:
+        dev = torch.device("cpu")
+        ctx = stralg_amd.Context(0, lib_path=os.path.join(ROOT, "tests", "emu", "libstralg_amd_emu.so"))
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        ctx = stralg_amd.Context(local_rank)
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world != args.gpus and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctx = stralg_amd.Context(local_rank)
+    cuda = dev.type == "cuda"
 
-    n = 1 << args.log2n
-    N = n + 1
-    sigma = args.sigma
-    tables = (not args.no_tables) and sigma <= 128
+    def sync():
+        if cuda:
+            torch.cuda.synchronize()
+
+    workload = args.workload or ("dna" if world == 1 else "fasta")
+    n = args.n if args.n > 0 else 1 << args.log2n
     seed = 42 + rank
-    text = torch.empty(n, dtype=torch.uint8, device=dev)
-    ctx.synth_dev(text, n, sigma, seed)
-    sa = torch.empty(N, dtype=torch.int32, device=dev)
-    c_tab = torch.zeros(sigma, dtype=torch.int32, device=dev)
-    o_tab = torch.empty((N + 1) * sigma, dtype=torch.int32, device=dev) if tables else None
-    bwt = torch.empty(N, dtype=torch.uint8, device=dev) if tables else None
+    gen = "dna" if workload == "fasta" else workload
+    text, sigma = workloads.make_text(ctx, gen, n, args.sigma, seed, dev)
+    N = n + 1
+    tables = (not args.no_tables) and sigma <= 128
+    cpu_n = min(n, 1 << args.cpu_log2n)
+    cpu_sample = text[:cpu_n].cpu().numpy() if rank == 0 and world == 1 and not args.no_cpu else None
+    job = None
+    if workload == "fasta":
+        image = workloads.fasta_image(text, f"record{rank}")
+        h_image = image.cpu()
+        if cuda:
+            h_image = h_image.pin_memory()
+        del image
+        job = farm.FastaRecordJob(ctx, h_image, dev, tables)
+        job.upload()
+        sa = bwt = c_tab = o_tab = None
+    else:
+        sa = torch.empty(N, dtype=torch.int32, device=dev)
+        c_tab = torch.zeros(sigma, dtype=torch.int32, device=dev)
+        o_tab = torch.empty((N + 1) * sigma, dtype=torch.int32, device=dev) if tables else None
+        bwt = torch.empty(N, dtype=torch.uint8, device=dev) if tables else None
 
     def step():
         # build_complete_table's device work (stralg/bwt.c:143,154): suffix array, then C and O.
         # The induced-sort passes hand the BWT over with the suffix array (sx_sa_bwt_build_dev).
-        if tables:
+        if job is not None:
+            job.build()
+        elif tables:
             ctx.sa_bwt_build_dev(text, n, sigma, sa, bwt)
             ctx.bwt_tables_from_bwt_dev(bwt, N, sigma, c_tab, o_tab)
         else:
             ctx.sa_build_dev(text, n, sigma, sa)
-
-    from stralg_amd import farm
 
     def profiled_step():
         """one untimed step with HIP events around every launch: the per-class table, and which class dominates"""
@@ -148,7 +276,7 @@ def main():
         ctx.profile_only(None)
         ctx.profile_enable(True)
         step()
-        torch.cuda.synchronize()
+        sync()
         ctx.profile_enable(False)
         return ctx.profile_read()
 
@@ -163,23 +291,76 @@ def main():
     ctx.profile_only(dom)
     ctx.profile_enable(True)
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps
-    elapsed = farm.timed(step, args.steps, 0, cuda=True)
+    elapsed_own = farm.timed(step, args.steps, 0, cuda=cuda)
     ctx.profile_enable(False)
     prof = ctx.profile_read()
     ctx.profile_only(None)
     stats = ctx.last_stats()
     # max time over ranks, total suffixes over ranks (the only collectives; none on the data path)
-    elapsed, total_units = farm.reduce_scalars(elapsed, args.steps * N, device=dev if backend == "nccl" else None)
+    red_dev = dev if backend == "nccl" else None
+    elapsed, total_units = farm.reduce_scalars(elapsed_own, args.steps * N, device=red_dev)
+
+    # ---- after the timed region: check the last step's results on the device ------------------------------
+    verified, checks = None, []
+    if not args.no_verify:
+        from stralg_amd import verify
+        ctx.trim()  # the checks need the memory more than the cached workspace does
+        try:
+            if job is not None:
+                checks = verify.verify_build_on_device(job.d_text, job.n, job.sigma, job.sa, job.bwt if tables else None,
+                                                       job.c if tables else None, job.o)
+                # the record that came out of the FASTA image is the record that went in
+                if job.n != n or not bool((job.d_text[:n] == text).all()):
+                    raise AssertionError("FASTA ingest changed the record")
+                checks.append("FASTA pack + remap reproduce the record")
+            else:
+                checks = verify.verify_build_on_device(text, n, sigma, sa, bwt, c_tab if tables else None, o_tab)
+            verified = True
+        except AssertionError as e:
+            verified = False
+            checks = [f"FAILED on rank {rank}: {e}"]
+            print(f"bench.py: verification failed on rank {rank}: {e}", file=sys.stderr)
+    bad_ranks, _ = farm.reduce_scalars(1.0 if verified is False else 0.0, 0, device=red_dev)
+
+    # ---- the FASTA record with its ingest, every rank at once (what limits config 5: PCIe / host) --------
+    fasta = None
+    if job is not None:
+        def ingest_step():
+            job.upload()
+            job.build()
+        t_in = farm.timed(ingest_step, max(1, min(args.steps, 3)), 0, cuda=cuda)
+        k = max(1, min(args.steps, 3))
+        t_in_max, units_in = farm.reduce_scalars(t_in, k * N, device=red_dev)
+        fasta = {"file_bytes_per_record": job.file_len, "steps": k,
+                 "kernel_only_Msuffixes_per_s": round(total_units / elapsed / 1e6, 3),
+                 "ingest_inclusive_Msuffixes_per_s": round(units_in / t_in_max / 1e6, 3),
+                 "ingest_inclusive_ms_per_record": round(t_in_max / k * 1e3, 3),
+                 "h2d_GBps_per_rank": None,
+                 "note": "ingest = H2D copy of the pinned file image, all ranks at once, then the same step"}
+        t0 = time.perf_counter()
+        job.upload()
+        fasta["h2d_GBps_per_rank"] = round(job.file_len / (time.perf_counter() - t0) / 1e9, 2)
 
     if rank == 0:
         value = total_units / elapsed / 1e6
         # dominant kernel class (by summed HIP-event time of the profiled step), measured in the timed steps
         d = prof[dom]
         achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        size_label = f"{n >> 30} GiB" if n >= (1 << 30) and n % (1 << 30) == 0 else (f"{n >> 20} MiB" if n >= (1 << 20) else f"{n} B")
-        alpha_label = "DNA" if sigma == 5 else f"sigma={sigma}"
+        size_label = (f"{n >> 30} GiB" if n >= (1 << 30) and n % (1 << 30) == 0 else
+                      (f"{n >> 20} MiB" if n >= (1 << 20) and n % (1 << 20) == 0 else f"{n} B"))
+        alpha_label = {"dna": "DNA", "fasta": "DNA, FASTA records", "bytes": "sigma=256"}.get(workload, workload if workload != "uniform" else f"sigma={sigma}")
+        what = "SA-IS + BWT C/O tables" if tables else "SA-IS"
+        if workload == "fasta":
+            wl = (f"one FASTA record of 2^{args.log2n} bases per GPU (bwt_readmapper.c:54-62): image in HBM -> pack -> remap -> "
+                  f"sa_is_construction + init_bwt_table (C, O)" if args.n == 0 else f"one FASTA record of {n} bases per GPU")
+        elif tables:
+            wl = (f"sa_is_construction + init_bwt_table (C, O) on {n} symbols ({workload}), alphabet_size={sigma}, "
+                  f"one independent record per GPU")
+        else:
+            wl = f"sa_is_construction on {n} symbols ({workload}), alphabet_size={sigma}"
+        traffic = pmc_traffic(args.log2n, sigma, tables, dom) if workload == "dna" and args.n == 0 else None
         out = {
-            "metric": f"Msuffixes/s ({'SA-IS + BWT C/O tables' if tables else 'SA-IS'}, {size_label} {alpha_label})",
+            "metric": f"Msuffixes/s ({what}, {size_label} {alpha_label})",
             "value": round(value, 3),
             "unit": "Msuffixes/s",
             "n_gpus": world,
@@ -192,12 +373,9 @@ def main():
             "dtype": "u8 text / u32 indices",
             "data": "synthetic",
             "config": {
-                "workload": f"sa_is_construction + init_bwt_table (C, O) on 2^{args.log2n} random symbols, "
-                            f"sigma={sigma - 1}+sentinel, one independent record per GPU"
-                            if tables else
-                            f"sa_is_construction on 2^{args.log2n} random symbols, alphabet_size={sigma}",
+                "workload": wl,
                 "n": n, "alphabet_size": sigma, "records_per_gpu": 1, "parallelism": f"batch x{world}, no collectives",
-                "seed": 42,
+                "seed": 42, "generator": gen,
             },
             "roofline": {
                 "bound": "hbm",
@@ -206,23 +384,50 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(args.log2n, sigma, tables, dom),
+                "traffic": traffic,
+                "traffic_source": (f"{PMC_TRAFFIC}: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed by the "
+                                   "builder; not measured in this run") if traffic is not None else None,
                 "launches": d["launches"],
                 "avg_ms": round(d["ms"] / max(1, d["launches"]), 4),
             },
+            "verified": verified if bad_ranks == 0.0 else False,
+            "verified_checks": checks,
             # per-class times of ONE untimed step with events around every launch (run between warm-up and timing)
             "kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches_per_step": v["launches"],
                             "GBps": round(v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
                         for k, v in table.items() if v["launches"]},
             "build_stats": stats,
         }
+        # whole-step algorithmic traffic over the step time: sum of the classes' bytes
+        alg_total = sum(v["alg_bytes"] for v in table.values())
+        out["whole_step"] = {"alg_GB": round(alg_total / 1e9, 2),
+                             "GBps": round(alg_total / (elapsed / args.steps) / 1e9, 1),
+                             "frac_of_peak": round(alg_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        if fasta is not None:
+            out["fasta_record"] = fasta
+        if world == 1 and not args.no_e2e and not emu and workload in ("dna", "fasta"):
+            del text, sa, bwt, c_tab, o_tab
+            job = None
+            ctx.trim()
+            if cuda:
+                torch.cuda.empty_cache()
+            out["end_to_end"] = end_to_end(ctx, [int(v) for v in args.e2e_log2n.split(",") if v], 42)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, sigma, 42)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(cpu_sample, sigma, f"the first {cpu_n} symbols of the record rank 0 built")
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return 1 if bad_ranks else 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # (this process stays off the GPU)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

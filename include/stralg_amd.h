@@ -51,6 +51,10 @@ enum {
     SX_KC_BWT_GATHER,     /* bwt[i] = text[SA[i]-1] + per-tile symbol counts bwt.c:13-20  */
     SX_KC_OTABLE,         /* O-table rows                                 bwt.c:47-65     */
     SX_KC_MISC,
+    SX_KC_FASTA,          /* FASTA image -> packed records                bioinf/fasta.c:92-135 */
+    SX_KC_REMAP,          /* presence bits + table lookup                 remap.c:8-31,102-114  */
+    SX_KC_LCP,            /* inverse + LCP                                suffix_array.c:53-85  */
+    SX_KC_SEARCH,         /* batched exact BWT search                     bwt.c:164-199         */
     SX_KC_COUNT
 };
 

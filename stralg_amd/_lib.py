@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_LIB = os.path.join(_HERE, "libstralg_amd.so")
 
 KC_NAMES = ["classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names", "doubling",
-            "induce_gather", "induce_scan", "induce_scatter", "induce_chain", "bwt_gather", "otable", "misc"]
+            "induce_gather", "induce_scan", "induce_scatter", "induce_chain", "bwt_gather", "otable", "misc",
+            "fasta", "remap", "lcp", "search"]
 
 
 class KernelStat(C.Structure):

@@ -7,6 +7,7 @@
 static const char *kClassNames[SX_KC_COUNT] = {
     "classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names",
     "doubling", "induce_gather", "induce_scan", "induce_scatter", "induce_chain", "bwt_gather", "otable", "misc",
+    "fasta", "remap", "lcp", "search",
 };
 
 int sx_fail(sx_ctx *ctx, int code, const char *what, const char *file, int line)

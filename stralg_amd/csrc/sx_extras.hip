@@ -104,7 +104,7 @@ static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, 4096));
     uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
     SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
-    sx_launch(ctx, SX_KC_MISC, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
+    sx_launch(ctx, SX_KC_LCP, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
     uint32_t h_bad = 0;
     SX_TRY(sx_readback(ctx, bad, 1, &h_bad));
     if (h_bad) return sx_fail_msg(ctx, SX_E_ARG, "sa holds an entry outside [0, N)");
@@ -123,7 +123,7 @@ static int lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uin
     SX_CHECK(hipMemsetAsync(T + n, 0, text_b - n, ctx->stream));
     SX_TRY(inverse_dev(ctx, d_sa, N, inv));
     const uint64_t chunks = (N + kLcpChunk - 1) / kLcpChunk;
-    sx_launch(ctx, SX_KC_MISC, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
+    sx_launch(ctx, SX_KC_LCP, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
               (const uint32_t *)inv, N, d_lcp);
     return 0;
 }
@@ -177,7 +177,7 @@ int sx_bwt_exact_search_dev(sx_ctx *ctx, const uint32_t *d_c_table, const uint32
         return SX_E_ARG;
     if (count == 0) return 0;
     SX_CHECK(hipSetDevice(ctx->device));
-    sx_launch(ctx, SX_KC_MISC, 0, bwt_exact_search_kernel, dim3(sx_div_up(count, kBlock)), dim3(kBlock), d_c_table,
+    sx_launch(ctx, SX_KC_SEARCH, 0, bwt_exact_search_kernel, dim3(sx_div_up(count, kBlock)), dim3(kBlock), d_c_table,
               d_o_table, N, sigma, d_patterns, d_offsets, count, d_l_out, d_r_out);
     return sx_sync(ctx);
 }

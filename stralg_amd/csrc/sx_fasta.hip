@@ -179,11 +179,12 @@ __global__ __launch_bounds__(kBlock) void remap_present_kernel(const uint8_t *__
     if (threadIdx.x < 8) seen[threadIdx.x] = 0;
     __syncthreads();
     uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool aligned = ((uintptr_t)in & 15u) == 0;
+    // (a record's sequence starts wherever its name ends in the packed image: 16-byte loads at any byte address,
+    //  sx_device.hpp load_bytes16)
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q * 16 < n; q += (uint64_t)gridDim.x * kBlock) {
-        if (aligned && q * 16 + 16 <= n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(in + q * 16);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (q * 16 + 16 <= n) {
+            uint32_t w[4];
+            __builtin_memcpy(w, in + q * 16, 16);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(kBlock) void remap_apply_kernel(const uint8_t *__re
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = table[threadIdx.x];
     __syncthreads();
-    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;
+    const bool aligned = ((uintptr_t)out & 15u) == 0; // (the input may start anywhere: unaligned 16-byte loads)
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q * 16 < n; q += (uint64_t)gridDim.x * kBlock) {
         if (aligned && q * 16 + 16 <= n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(in + q * 16);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t w[4];
+            __builtin_memcpy(w, in + q * 16, 16);
             uint32_t o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -261,22 +262,22 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
     if (file_len) {
         uint32_t grid = sx_div_up(file_len, kBlock * 16);
         if (grid > 4096) grid = 4096;
-        sx_launch(ctx, SX_KC_MISC, file_len, fasta_first_nul_kernel, dim3(grid), dim3(kBlock), d_file, file_len, scal);
+        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_first_nul_kernel, dim3(grid), dim3(kBlock), d_file, file_len, scal);
         SX_TRY(sx_readback(ctx, scal, 1, &first_nul));
     }
     const uint64_t end = first_nul < file_len ? first_nul : file_len;
     const uint64_t span = end + 1; // with the terminating NUL of the reference's buffer
     const uint32_t tiles = sx_div_up(span, kFaTile);
     const dim3 grid(tiles), block(kBlock);
-    sx_launch(ctx, SX_KC_MISC, span, fasta_tile_last_kernel, grid, block, d_file, end, tile_last);
-    SX_TRY((device_scan<OpMax>(ctx, tiles, InU32{tile_last}, OutExclusive{tile_carry}, nullptr, SX_KC_MISC, 0)));
-    sx_launch(ctx, SX_KC_MISC, span, fasta_count_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry, tile_emit,
+    sx_launch(ctx, SX_KC_FASTA, span, fasta_tile_last_kernel, grid, block, d_file, end, tile_last);
+    SX_TRY((device_scan<OpMax>(ctx, tiles, InU32{tile_last}, OutExclusive{tile_carry}, nullptr, SX_KC_FASTA, 0)));
+    sx_launch(ctx, SX_KC_FASTA, span, fasta_count_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry, tile_emit,
               tile_term, scal);
     // (tile_last is free again: the terminator offsets go there)
     uint32_t *tile_toff = tile_last;
-    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_emit}, OutExclusive{tile_eoff}, scal + 3, SX_KC_MISC, 0)));
-    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_term}, OutExclusive{tile_toff}, scal + 4, SX_KC_MISC, 0)));
-    sx_launch(ctx, SX_KC_MISC, span * 2, fasta_write_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry,
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_emit}, OutExclusive{tile_eoff}, scal + 3, SX_KC_FASTA, 0)));
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_term}, OutExclusive{tile_toff}, scal + 4, SX_KC_FASTA, 0)));
+    sx_launch(ctx, SX_KC_FASTA, span * 2, fasta_write_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry,
               (const uint32_t *)tile_eoff, (const uint32_t *)tile_toff, d_packed_out, d_term_out, d_term_out ? term_cap : 0, scal);
     uint32_t h[5];
     SX_TRY(sx_readback(ctx, scal, 5, h));
@@ -323,7 +324,7 @@ int sx_remap_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out, i
     SX_CHECK(hipMemsetAsync(present, 0, 8 * sizeof(uint32_t), ctx->stream));
     uint32_t grid = sx_div_up(n ? n : 1, kBlock * 64);
     if (grid > 2048) grid = 2048;
-    if (n) sx_launch(ctx, SX_KC_MISC, n, remap_present_kernel, dim3(grid), dim3(kBlock), d_in, n, present);
+    if (n) sx_launch(ctx, SX_KC_REMAP, n, remap_present_kernel, dim3(grid), dim3(kBlock), d_in, n, present);
     uint32_t h[8];
     SX_TRY(sx_readback(ctx, present, 8, h));
     // remap.c:8-31: symbols in increasing order get 1, 2, ...; 0 stays the sentinel
@@ -343,7 +344,7 @@ int sx_remap_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out, i
     if (h[0] & 1u) return sx_fail_msg(ctx, SX_E_ARG, "remap: the input holds the sentinel symbol 0");
     if (next > 128) return sx_fail_msg(ctx, SX_E_ARG, "remap: more than 127 distinct symbols (stralg/remap.h:14-18)");
     SX_CHECK(hipMemcpyAsync(lut, table, 256, hipMemcpyHostToDevice, ctx->stream));
-    sx_launch(ctx, SX_KC_MISC, 2 * n, remap_apply_kernel, dim3(grid), dim3(kBlock), d_in, n, (const uint8_t *)lut, d_out);
+    sx_launch(ctx, SX_KC_REMAP, 2 * n, remap_apply_kernel, dim3(grid), dim3(kBlock), d_in, n, (const uint8_t *)lut, d_out);
     return sx_sync(ctx);
 }
 

@@ -65,3 +65,55 @@ def test_two_rank_farm(emu_ctx, tmp_path):
     mp.spawn(_worker, args=(2, port, EMU_LIB, str(tmp_path)), nprocs=2, join=True)
     got = sorted(sum((open(tmp_path / f"rank{r}.ok").read().split(",") for r in range(2)), []))
     assert got == ["0", "1", "2", "3", "4"]
+
+
+def test_bench_launches_its_own_ranks_on_fasta_records(emu_ctx):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent starts two fresh ranks, each
+    builds its own FASTA record (BASELINE.json configs[4]: image -> pack -> remap -> suffix array + BWT -> C/O
+    tables, bwt_readmapper.c:54-62) over the CPU execution harness, the results are verified, and rank 0's line
+    carries n_gpus = 2 with the kernel-only and the ingest-inclusive rate."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["STRALG_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "5003", "--steps", "1",
+                          "--warmup", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["scaling"] == "weak" and doc["unit"] == "Msuffixes/s"
+    assert doc["verified"] is True and len(doc["verified_checks"]) == 4
+    assert doc["config"]["n"] == 5003 and "FASTA" in doc["config"]["workload"]
+    fr = doc["fasta_record"]
+    assert fr["kernel_only_Msuffixes_per_s"] > 0 and fr["ingest_inclusive_Msuffixes_per_s"] > 0
+    assert doc["build_stats"]["n"] == 5003
+
+
+def test_bench_reports_a_failed_verification(emu_ctx, tmp_path):
+    """the verifier is not a rubber stamp: a wrong suffix array is refused"""
+    import torch
+    from stralg_amd import verify
+    import oracle
+    from stralg_amd.synth import synth
+    x = synth(3000, 5, 3)
+    sa = oracle.sa_is(x, 5).astype(np.int64)
+    t = torch.from_numpy(x)
+    good = torch.from_numpy(sa.astype(np.int32))
+    assert verify.verify_sa_on_device(t, good, 3000)
+    bad = good.clone()
+    bad[[10, 11]] = bad[[11, 10]]
+    with pytest.raises(AssertionError):
+        verify.verify_sa_on_device(t, bad, 3000)
+    dup = good.clone()
+    dup[5] = dup[6]
+    with pytest.raises(AssertionError):
+        verify.verify_sa_on_device(t, dup, 3000)
+    bw = torch.from_numpy(oracle.bwt(x, sa.astype(np.uint32)))
+    c = torch.from_numpy(oracle.c_table(x, 5).astype(np.int32))
+    o = torch.from_numpy(oracle.o_table(x, sa.astype(np.uint32), 5).astype(np.int32).reshape(-1))
+    assert len(verify.verify_build_on_device(t, 3000, 5, good, bw, c, o)) == 3
+    o2 = o.clone()
+    o2[5 * 1000 + 2] += 1
+    with pytest.raises(AssertionError):
+        verify.verify_build_on_device(t, 3000, 5, good, bw, c, o2)
