@@ -239,6 +239,7 @@ def run_rank(args):
     seed = 42 + rank
     gen = "dna" if workload == "fasta" else workload
     text, sigma = workloads.make_text(ctx, gen, n, args.sigma, seed, dev)
+    sync()  # (torch's generators run on torch's stream, the library on its own)
     N = n + 1
     tables = (not args.no_tables) and sigma <= 128
     cpu_n = min(n, 1 << args.cpu_log2n)

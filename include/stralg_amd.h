@@ -80,6 +80,8 @@ typedef struct sx_build_stats {
 
 /* ---- context ------------------------------------------------------------ */
 int sx_device_count(void);
+/* NUMA node of the device's PCI function (/sys/bus/pci/devices/<bus id>/numa_node), or -1 when unknown */
+int sx_device_numa_node(int device);
 int sx_ctx_create(int device, sx_ctx **out);
 void sx_ctx_destroy(sx_ctx *ctx);
 const char *sx_last_error(const sx_ctx *ctx);

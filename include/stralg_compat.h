@@ -111,7 +111,18 @@ void dealloc_bwt_exact_match_iter(struct bwt_exact_match_iter *iter);
 
 /* ---- index serialisation: the reference's file format (stralg/serialise.h:8-23, string_utils.h,
  * suffix_array.h, remap.h, bwt.h write_ / read_ pairs) ------------------------------------------- */
+/* (every FILE form has its _fname sibling: string_utils.h:48-71, suffix_array.h:109-126, remap.h:89-104, bwt.h:337-354) */
 void write_string_len(FILE *f, const uint8_t *str, uint32_t len); /* string_utils.c:48-52 */
+void write_string_len_fname(const char *fname, const uint8_t *str, uint32_t len);
+void write_string_fname(const char *fname, const uint8_t *str);
+uint8_t *read_string_len_fname(const char *fname, uint32_t *len);
+uint8_t *read_string_fname(const char *fname);
+void write_suffix_array_fname(const char *fname, const struct suffix_array *sa);
+struct suffix_array *read_suffix_array_fname(const char *fname, uint8_t *string);
+void write_remap_table_fname(const char *fname, const struct remap_table *table);
+struct remap_table *read_remap_table_fname(const char *fname);
+void write_bwt_table_fname(const char *fname, const struct bwt_table *bwt_table);
+struct bwt_table *read_bwt_table_fname(const char *fname, struct suffix_array *sa, struct remap_table *remap_table);
 void write_string(FILE *f, const uint8_t *str);                   /* string_utils.c:62-66: length includes the NUL */
 uint8_t *read_string_len(FILE *f, uint32_t *len);                 /* string_utils.c:73-82 */
 uint8_t *read_string(FILE *f);
@@ -165,10 +176,15 @@ void dealloc_fasta_iter(struct fasta_iter *iter);
 int stralg_amd_set_device(int device);
 /* release the calling thread's context and its cached device memory */
 void stralg_amd_release(void);
-/* Build tables for `count` independent strings, string k on devices[k % n_devices],
- * one host thread per device; out[k] receives build_complete_table(strings[k], ...). */
+/* Build tables for `count` independent strings over the listed devices, one host thread per device, each pinned
+ * to its GPU's NUMA node; strings are dealt longest first to the least loaded device (LPT by length).
+ * out[k] receives build_complete_table(strings[k], ...). */
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out);
+/* the assignment the farm uses: assignment[k] = lane (0 .. lanes-1) of record k */
+int stralg_amd_lpt_assign(const size_t *lengths, size_t count, int lanes, int *assignment);
+/* pin the calling thread to the CPUs of `device`'s NUMA node; returns the node, or -1 when it is unknown */
+int stralg_amd_bind_thread_to_device(int device);
 /* build_complete_table(string, include_reverse) followed by write_complete_bwt_info(f, table), byte for byte,
  * but the suffix array and the O tables stream from the GPU into the file in 32 MiB chunks: no host copy of
  * the tables (20 GiB per GiB of DNA).  Returns 0, or a negative / HIP error code. */

@@ -10,6 +10,7 @@
 #include "stralg_amd.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -362,6 +363,20 @@ void write_string_len(FILE *f, const uint8_t *str, uint32_t len)
 
 void write_string(FILE *f, const uint8_t *str) { write_string_len(f, str, (uint32_t)strlen((const char *)str) + 1); }
 
+/* the _fname siblings (string_utils.c:54-71,84-96, suffix_array.c:243-267, remap.c:175-201, bwt.c:443-503):
+ * open, call the FILE form, close; like the reference they do not check fopen */
+void write_string_len_fname(const char *fname, const uint8_t *str, uint32_t len)
+{
+    FILE *f = fopen(fname, "wb");
+    write_string_len(f, str, len);
+    fclose(f);
+}
+
+void write_string_fname(const char *fname, const uint8_t *str)
+{
+    write_string_len_fname(fname, str, (uint32_t)strlen((const char *)str) + 1);
+}
+
 uint8_t *read_string_len(FILE *f, uint32_t *len)
 {
     uint32_t str_len = 0;
@@ -379,6 +394,20 @@ uint8_t *read_string(FILE *f)
     return read_string_len(f, &dummy);
 }
 
+uint8_t *read_string_len_fname(const char *fname, uint32_t *len)
+{
+    FILE *f = fopen(fname, "rb");
+    uint8_t *str = read_string_len(f, len);
+    fclose(f);
+    return str;
+}
+
+uint8_t *read_string_fname(const char *fname)
+{
+    uint32_t dummy;
+    return read_string_len_fname(fname, &dummy);
+}
+
 void write_suffix_array(FILE *f, const struct suffix_array *sa) { fwrite(sa->array, sizeof *sa->array, sa->length, f); }
 
 struct suffix_array *read_suffix_array(FILE *f, uint8_t *string)
@@ -388,12 +417,42 @@ struct suffix_array *read_suffix_array(FILE *f, uint8_t *string)
     return sa;
 }
 
+void write_suffix_array_fname(const char *fname, const struct suffix_array *sa)
+{
+    FILE *f = fopen(fname, "wb");
+    write_suffix_array(f, sa);
+    fclose(f);
+}
+
+struct suffix_array *read_suffix_array_fname(const char *fname, uint8_t *string)
+{
+    FILE *f = fopen(fname, "rb");
+    struct suffix_array *sa = read_suffix_array(f, string);
+    fclose(f);
+    return sa;
+}
+
 void write_remap_table(FILE *f, const struct remap_table *table) { fwrite(table, sizeof *table, 1, f); }
+
+void write_remap_table_fname(const char *fname, const struct remap_table *table)
+{
+    FILE *f = fopen(fname, "wb");
+    write_remap_table(f, table);
+    fclose(f);
+}
 
 struct remap_table *read_remap_table(FILE *f)
 {
     struct remap_table *table = malloc(sizeof *table);
     if (fread(table, sizeof *table, 1, f) != 1) memset(table, 0, sizeof *table);
+    return table;
+}
+
+struct remap_table *read_remap_table_fname(const char *fname)
+{
+    FILE *f = fopen(fname, "rb");
+    struct remap_table *table = read_remap_table(f);
+    fclose(f);
     return table;
 }
 
@@ -428,6 +487,21 @@ struct bwt_table *read_bwt_table(FILE *f, struct suffix_array *sa, struct remap_
         if (fread(table->ro_table, sizeof *table->ro_table, o_words, f) != o_words) memset(table->ro_table, 0, o_words * 4);
         table->ro_indices = row_pointers(table->ro_table, rows, (uint32_t)sigma);
     }
+    return table;
+}
+
+void write_bwt_table_fname(const char *fname, const struct bwt_table *bwt_table)
+{
+    FILE *f = fopen(fname, "wb");
+    write_bwt_table(f, bwt_table);
+    fclose(f);
+}
+
+struct bwt_table *read_bwt_table_fname(const char *fname, struct suffix_array *sa, struct remap_table *remap_table)
+{
+    FILE *f = fopen(fname, "rb");
+    struct bwt_table *table = read_bwt_table(f, sa, remap_table);
+    fclose(f);
     return table;
 }
 
@@ -616,24 +690,104 @@ bool next_fasta_record(struct fasta_iter *iter, struct fasta_record *rec)
 
 void dealloc_fasta_iter(struct fasta_iter *iter) { (void)iter; }
 
-/* ---- batch farm: independent records, one host thread per GPU ------------------------ */
+/* ---- batch farm: independent records, one host thread per GPU ------------------------
+ * Records are dealt longest first to the device with the least work so far (LPT by length, SURVEY.md section 8e:
+ * a build's time is close to linear in the record's length), and every worker thread is pinned to the CPUs of
+ * its GPU's NUMA node (sx_device_numa_node reads the PCI device's node from sysfs): its staging copies and the
+ * page faults of the malloc'd outputs then stay on the memory next to that GPU's PCIe root. */
 
 struct farm_job {
     const uint8_t *const *strings;
     struct bwt_table **out;
-    size_t count;
+    const size_t *mine; /* indices of this worker's records, in the order it builds them */
+    size_t n_mine;
     bool include_reverse;
-    int device, lane, lanes;
+    int device;
 };
+
+/* "0-63,128-191" -> cpu set; returns the number of CPUs */
+static int parse_cpulist(const char *list, cpu_set_t *set)
+{
+    int count = 0;
+    CPU_ZERO(set);
+    for (const char *p = list; *p && *p != '\n';) {
+        char *end;
+        long a = strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        if (*end == '-') {
+            p = end + 1;
+            b = strtol(p, &end, 10);
+            if (end == p) break;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            CPU_SET((int)c, set);
+            ++count;
+        }
+        p = *end == ',' ? end + 1 : end;
+    }
+    return count;
+}
+
+int stralg_amd_bind_thread_to_device(int device)
+{
+    const int node = sx_device_numa_node(device);
+    if (node < 0) return -1; /* unknown (no NUMA information): leave the thread where it is */
+    char path[128], list[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    const bool ok = fgets(list, sizeof list, f) != NULL;
+    fclose(f);
+    cpu_set_t set;
+    if (!ok || parse_cpulist(list, &set) == 0) return -1;
+    return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0 ? node : -1;
+}
 
 static void *farm_worker(void *arg)
 {
     struct farm_job *job = arg;
+    (void)stralg_amd_bind_thread_to_device(job->device);
     stralg_amd_set_device(job->device);
-    for (size_t k = (size_t)job->lane; k < job->count; k += (size_t)job->lanes)
-        job->out[k] = build_complete_table(job->strings[k], job->include_reverse);
+    for (size_t k = 0; k < job->n_mine; ++k)
+        job->out[job->mine[k]] = build_complete_table(job->strings[job->mine[k]], job->include_reverse);
     stralg_amd_release();
     return NULL;
+}
+
+struct lpt_item {
+    size_t index, length;
+};
+
+static int lpt_longest_first(const void *a, const void *b)
+{
+    const struct lpt_item *x = a, *y = b;
+    if (x->length != y->length) return x->length > y->length ? -1 : 1;
+    return x->index < y->index ? -1 : (x->index > y->index ? 1 : 0); /* ties keep the given order */
+}
+
+/* assignment[k] = lane of record k (longest processing time first); lanes have equal speed */
+int stralg_amd_lpt_assign(const size_t *lengths, size_t count, int lanes, int *assignment)
+{
+    if (lanes <= 0 || (count && (!lengths || !assignment))) return -1;
+    struct lpt_item *items = malloc((count ? count : 1) * sizeof *items);
+    size_t *load = calloc((size_t)lanes, sizeof *load);
+    if (!items || !load) {
+        free(items);
+        free(load);
+        return -2;
+    }
+    for (size_t k = 0; k < count; ++k) items[k] = (struct lpt_item){k, lengths[k]};
+    qsort(items, count, sizeof *items, lpt_longest_first);
+    for (size_t k = 0; k < count; ++k) {
+        int best = 0;
+        for (int l = 1; l < lanes; ++l)
+            if (load[l] < load[best]) best = l;
+        assignment[items[k].index] = best;
+        load[best] += items[k].length;
+    }
+    free(items);
+    free(load);
+    return 0;
 }
 
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
@@ -642,19 +796,34 @@ int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, b
     if (!strings || !out || n_devices <= 0 || !devices) return -1;
     pthread_t *threads = malloc((size_t)n_devices * sizeof *threads);
     struct farm_job *jobs = malloc((size_t)n_devices * sizeof *jobs);
-    if (!threads || !jobs) {
-        free(threads);
-        free(jobs);
+    size_t *lengths = malloc((count ? count : 1) * sizeof *lengths);
+    int *lane = malloc((count ? count : 1) * sizeof *lane);
+    size_t *order = malloc((count ? count : 1) * sizeof *order);
+    if (!threads || !jobs || !lengths || !lane || !order) {
+        free(threads), free(jobs), free(lengths), free(lane), free(order);
         return -2;
     }
-    for (int d = 0; d < n_devices; ++d) {
-        jobs[d] = (struct farm_job){strings, out, count, include_reverse, devices[d], d, n_devices};
-        pthread_create(&threads[d], NULL, farm_worker, &jobs[d]);
+    for (size_t k = 0; k < count; ++k) lengths[k] = strlen((const char *)strings[k]);
+    int rc = stralg_amd_lpt_assign(lengths, count, n_devices, lane);
+    if (rc == 0) {
+        /* every lane's records, longest first, as consecutive runs of `order` */
+        size_t at = 0;
+        for (int d = 0; d < n_devices; ++d) {
+            const size_t first = at;
+            for (size_t k = 0; k < count; ++k)
+                if (lane[k] == d) order[at++] = k;
+            for (size_t i = first + 1; i < at; ++i) /* insertion sort by length, descending (lanes are short) */
+                for (size_t j = i; j > first && lengths[order[j]] > lengths[order[j - 1]]; --j) {
+                    const size_t t = order[j];
+                    order[j] = order[j - 1], order[j - 1] = t;
+                }
+            jobs[d] = (struct farm_job){strings, out, order + first, at - first, include_reverse, devices[d]};
+        }
+        for (int d = 0; d < n_devices; ++d) pthread_create(&threads[d], NULL, farm_worker, &jobs[d]);
+        for (int d = 0; d < n_devices; ++d) pthread_join(threads[d], NULL);
     }
-    for (int d = 0; d < n_devices; ++d) pthread_join(threads[d], NULL);
-    free(jobs);
-    free(threads);
-    return 0;
+    free(threads), free(jobs), free(lengths), free(lane), free(order);
+    return rc;
 }
 
 int stralg_amd_fasta_tables_batch(struct fasta_records *records, bool include_reverse, const int *devices,

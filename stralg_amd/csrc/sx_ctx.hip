@@ -139,6 +139,22 @@ int sx_device_count(void)
     return n;
 }
 
+int sx_device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return -1;
+    for (char *p = bus; *p; ++p)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a'); // sysfs spells bus ids in lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 int sx_ctx_create(int device, sx_ctx **out)
 {
     if (!out) return SX_E_ARG;

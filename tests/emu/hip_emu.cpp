@@ -164,6 +164,7 @@ hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char *bus, int len, int) { if (len > 0) bus[0] = 0; return hipErrorInvalidValue; } // (no PCI device behind the harness)
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "cpu-emu"); strcpy(p->gcnArchName, "emu"); p->multiProcessorCount = 4; p->totalGlobalMem = 8ull << 30; return hipSuccess; }
 hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = 8ull << 30; *t = 8ull << 30; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }

@@ -68,6 +68,7 @@ hipError_t hipDeviceSynchronize();
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
+hipError_t hipDeviceGetPCIBusId(char *bus, int len, int device);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);
 hipError_t hipEventCreate(hipEvent_t *e);

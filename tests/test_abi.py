@@ -88,3 +88,142 @@ def test_c_harness_links_against_the_library(product_lib, tmp_path):
                            "-L", os.path.join(ROOT, "stralg_amd"), "-lstralg_amd",
                            "-Wl,-rpath," + os.path.join(ROOT, "stralg_amd")])
     assert exe.exists()
+
+
+# ---- the boundary against a real libstralg (needs the reference checkout: the build container) -----------------
+
+REF = "/root/reference"
+
+CALLER = r'''
+/* a caller written against the reference's own, unmodified headers: functions that stay in libstralg next to
+ * functions that now come from libstralg_amd.so (host-side ones only: there is no GPU where this runs) */
+#include <stralg.h>
+#include <suffix_array_internal.h>
+#include <fasta.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+int main(int argc, char **argv)
+{
+    const char *dir = argc > 1 ? argv[1] : ".";
+    char path[512];
+    uint8_t text[] = "mississippi";
+    struct remap_table *table = alloc_remap_table(text);         /* libstralg_amd.so */
+    uint8_t remapped[16], back[16];
+    remap(remapped, text, table);                                /* libstralg_amd.so */
+    rev_remap(back, remapped, table);                            /* libstralg (remap.c:133-141) */
+    if (strcmp((char *)back, (char *)text) != 0) return 2;
+    if (table->alphabet_size != 5) return 3;
+    snprintf(path, sizeof path, "%s/table.bin", dir);
+    write_remap_table_fname(path, table);                        /* libstralg_amd.so */
+    struct remap_table *again = read_remap_table_fname(path);    /* libstralg_amd.so */
+    if (!identical_remap_tables(table, again)) return 4;         /* libstralg (remap.c:224-237) */
+    snprintf(path, sizeof path, "%s/string.bin", dir);
+    write_string_fname(path, text);                              /* libstralg_amd.so */
+    uint8_t *s = read_string_fname(path);                        /* libstralg_amd.so */
+    uint8_t *r = str_rev(s);                                     /* libstralg (string_utils.c:40-43) */
+    if (strcmp((char *)r, "ippississim") != 0) return 5;
+    /* a hand-made suffix array through the serialisation pair (no construction: that needs the GPU) */
+    struct suffix_array *sa = allocate_sa_(remapped);            /* libstralg_amd.so */
+    const uint32_t want[12] = {11, 10, 7, 4, 1, 0, 9, 8, 6, 3, 5, 2};
+    memcpy(sa->array, want, sizeof want);
+    snprintf(path, sizeof path, "%s/sa.bin", dir);
+    write_suffix_array_fname(path, sa);                          /* libstralg_amd.so */
+    struct suffix_array *sa2 = read_suffix_array_fname(path, remapped); /* libstralg_amd.so */
+    if (!identical_suffix_arrays(sa, sa2)) return 6;             /* libstralg (suffix_array.c) */
+    if (lower_bound_search(sa, (uint8_t *)"\2") != 5) return 7;  /* libstralg (suffix_array.c:90-112): first suffix >= "m" */
+    printf("ok %u %u\n", table->alphabet_size, sa2->length);
+    free_suffix_array(sa);                                       /* libstralg_amd.so */
+    free_suffix_array(sa2);
+    free_remap_table(table);
+    free_remap_table(again);
+    free(s);
+    free(r);
+    /* never called, only bound: the construction entry points must come from the GPU library */
+    if (argc > 5) {
+        (void)sa_is_construction(remapped, 5);
+        (void)skew_sa_construction(text);
+        (void)build_complete_table(text, true);
+        (void)load_fasta_records("x", NULL);
+    }
+    return 0;
+}
+'''
+
+
+def _defined(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TWDBR"}
+
+
+def _undefined(lib):
+    out = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1].split("@")[0] for l in out.splitlines() if l.split()}
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "stralg")), reason="needs the reference checkout")
+def test_links_next_to_a_real_libstralg(product_lib, tmp_path):
+    """INTEGRATION.md section 2, executed: the reference with the guards of tools/stralg_guard.py, compiled
+    with -DSTRALG_WITH_MI355X and linked against libstralg_amd.so.  Every reference-named symbol is defined
+    exactly once across the two libraries, libstralg's own references to the moved functions resolve from the
+    GPU library, and a caller built against the reference's unmodified headers binds each call to the
+    intended library (LD_DEBUG=bindings)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stralg_guard
+    amd_dir = os.path.join(ROOT, "stralg_amd")
+    amd = os.path.join(amd_dir, "libstralg_amd.so")
+    report = stralg_guard.guard_tree(REF, str(tmp_path / "src"))
+    guarded_names = {name for _, _, _, name in report}
+    ours = {s for s in _defined(amd) if not s.startswith(("sx_", "stralg_amd_"))}
+    assert ours == guarded_names, (sorted(ours - guarded_names), sorted(guarded_names - ours))
+    # the library exports nothing but its C ABI
+    assert not [s for s in _defined(amd) if s.startswith("_Z")]
+
+    inc = ["-I", str(tmp_path / "src" / "stralg"), "-I", str(tmp_path / "src" / "bioinf")]
+    link = ["-L", amd_dir, "-lstralg_amd", "-Wl,-rpath," + amd_dir]
+    stralg_so, bioinf_so = str(tmp_path / "libstralg.so"), str(tmp_path / "libstralg_bioinf.so")
+    csrc = sorted(str(p) for p in (tmp_path / "src" / "stralg").glob("*.c"))
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-w", "-DSTRALG_WITH_MI355X", "-shared", "-fPIC"] +
+                          inc + csrc + ["-o", stralg_so] + link)
+    bsrc = sorted(str(p) for p in (tmp_path / "src" / "bioinf").glob("*.c"))
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-w", "-DSTRALG_WITH_MI355X", "-shared", "-fPIC"] +
+                          inc + bsrc + ["-o", bioinf_so, "-L", str(tmp_path), "-lstralg", "-Wl,-rpath," + str(tmp_path)] + link)
+    # exactly once: nothing the GPU library defines is still defined by the guarded reference libraries
+    theirs = _defined(stralg_so) | _defined(bioinf_so)
+    assert not (theirs & ours), sorted(theirs & ours)
+    # ... and what they no longer define but still use resolves from the GPU library
+    needed = (_undefined(stralg_so) | _undefined(bioinf_so)) & guarded_names
+    assert needed and needed <= ours
+    assert "allocate_sa_" in needed  # suffix_array.c's qsort construction still allocates through it
+    # without the macro the same sources still build the complete reference library (the guards change nothing else)
+    whole = str(tmp_path / "libstralg_whole.so")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-w", "-shared", "-fPIC"] + inc + csrc + ["-o", whole])
+    assert guarded_names - {n for f, _, _, n in report if f.startswith("bioinf/")} <= _defined(whole)
+
+    (tmp_path / "caller.c").write_text(CALLER)
+    exe = str(tmp_path / "caller")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-D_GNU_SOURCE", "-I", os.path.join(REF, "stralg"), "-I",
+                           os.path.join(REF, "bioinf"), str(tmp_path / "caller.c"), "-o", exe, "-L", str(tmp_path),
+                           "-lstralg_bioinf", "-lstralg", "-Wl,-rpath," + str(tmp_path)] + link)
+    env = dict(os.environ, LD_BIND_NOW="1", LD_DEBUG="bindings", LD_DEBUG_OUTPUT=str(tmp_path / "ld"))
+    run = subprocess.run([exe, str(tmp_path)], env=env, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("ok 5 12"), (run.returncode, run.stdout, run.stderr[-500:])
+    log = "".join(p.read_text(errors="replace") for p in tmp_path.glob("ld.*"))
+    bound = {}
+    for m in re.finditer(r"binding file (\S+) \[\d+\] to (\S+) \[\d+\]: normal symbol `(\w+)'", log):
+        if os.path.basename(m.group(1)) == "caller":
+            bound[m.group(3)] = os.path.basename(m.group(2))
+    for name in ("alloc_remap_table", "remap", "write_remap_table_fname", "read_remap_table_fname", "write_string_fname",
+                 "read_string_fname", "allocate_sa_", "write_suffix_array_fname", "read_suffix_array_fname",
+                 "free_suffix_array", "free_remap_table", "sa_is_construction", "skew_sa_construction",
+                 "build_complete_table", "load_fasta_records"):
+        assert bound.get(name) == "libstralg_amd.so", (name, bound.get(name))
+    for name in ("rev_remap", "identical_remap_tables", "str_rev", "identical_suffix_arrays", "lower_bound_search"):
+        assert bound.get(name) == "libstralg.so", (name, bound.get(name))
+    # libstralg's own calls into the moved functions bind to the GPU library as well
+    inner = {m.group(3): os.path.basename(m.group(2))
+             for m in re.finditer(r"binding file (\S+) \[\d+\] to (\S+) \[\d+\]: normal symbol `(\w+)'", log)
+             if os.path.basename(m.group(1)) == "libstralg.so" and m.group(3) in guarded_names}
+    assert inner and set(inner.values()) == {"libstralg_amd.so"}, inner
