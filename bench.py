@@ -222,6 +222,8 @@ def run_rank(args):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         ctx = stralg_amd.Context(local_rank)
+    # host work of a rank (staging copies, page faults of pinned and malloc'd buffers) next to its GPU's PCIe root
+    numa_node = ctx.bind_to_numa_node()
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -376,7 +378,7 @@ def run_rank(args):
             "config": {
                 "workload": wl,
                 "n": n, "alphabet_size": sigma, "records_per_gpu": 1, "parallelism": f"batch x{world}, no collectives",
-                "seed": 42, "generator": gen,
+                "seed": 42, "generator": gen, "numa_node_rank0": numa_node,
             },
             "roofline": {
                 "bound": "hbm",

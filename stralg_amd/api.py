@@ -221,6 +221,13 @@ class Context:
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 
+    def bind_to_numa_node(self):
+        """pin the calling thread (and the threads it starts later) to the CPUs next to this context's GPU
+        (stralg_amd_bind_thread_to_device); returns the NUMA node, or -1 when the box does not tell"""
+        self.lib.stralg_amd_bind_thread_to_device.argtypes = [C.c_int]
+        self.lib.stralg_amd_bind_thread_to_device.restype = C.c_int
+        return int(self.lib.stralg_amd_bind_thread_to_device(self.device))
+
 
 _tls = threading.local()
 

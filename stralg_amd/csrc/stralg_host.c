@@ -11,6 +11,8 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +28,83 @@ static void die(const char *what, int rc, const sx_ctx *ctx)
     fprintf(stderr, "stralg_amd: the reference entry points cannot report errors and there is no CPU "
                     "fallback; aborting\n");
     abort();
+}
+
+/* ---- host-side helpers: a few threads for the byte loops over whole records, large result arrays on huge pages ----
+ * A 1 GiB record means 1 GiB of remap, 4 + 20 GiB of results and 8 GiB of row pointers on the host: single-threaded
+ * byte loops and page faults cost seconds where the device work costs 30 ms. */
+
+static int host_threads(void)
+{
+    const char *env = getenv("STRALG_AMD_HOST_THREADS");
+    if (env && atoi(env) >= 1) return atoi(env) > 64 ? 64 : atoi(env);
+    const long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+    return cpus >= 32 ? 16 : (cpus >= 4 ? (int)(cpus / 2) : 1);
+}
+
+struct range_job {
+    void (*fn)(size_t lo, size_t hi, void *arg);
+    void *arg;
+    size_t lo, hi;
+};
+
+static void *range_worker(void *p)
+{
+    struct range_job *j = p;
+    j->fn(j->lo, j->hi, j->arg);
+    return NULL;
+}
+
+/* loops shorter than this run on the calling thread ($STRALG_AMD_PARALLEL_MIN: the tests force the threaded path) */
+static size_t parallel_min(void)
+{
+    const char *env = getenv("STRALG_AMD_PARALLEL_MIN");
+    return env && atol(env) >= 1 ? (size_t)atol(env) : (size_t)4 << 20;
+}
+
+/* slices a loop over [0, total) is cut into: at most one per thread, each at least a quarter of the minimum */
+static int slice_count(size_t total)
+{
+    const size_t pmin = parallel_min(), grain = pmin / 4 ? pmin / 4 : 1;
+    int nt = host_threads();
+    if (total < pmin || nt <= 1) return 1;
+    if ((size_t)nt > total / grain) nt = (int)(total / grain);
+    return nt < 1 ? 1 : nt;
+}
+
+/* fn(lo, hi, arg) over [0, total) in contiguous slices, one per thread; small totals run inline */
+static void parallel_ranges(size_t total, void (*fn)(size_t, size_t, void *), void *arg)
+{
+    const int nt = slice_count(total);
+    if (nt <= 1) {
+        fn(0, total, arg);
+        return;
+    }
+    pthread_t th[64];
+    struct range_job jobs[64];
+    bool threaded[64] = {false};
+    const size_t per = (total + (size_t)nt - 1) / (size_t)nt;
+    for (int t = 0; t < nt; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < total ? lo + per : total;
+        if (lo >= hi) break;
+        jobs[t] = (struct range_job){fn, arg, lo, hi};
+        threaded[t] = pthread_create(&th[t], NULL, range_worker, &jobs[t]) == 0;
+        if (!threaded[t]) fn(lo, hi, arg); /* no more threads: do the slice here */
+    }
+    for (int t = 0; t < nt; ++t)
+        if (threaded[t]) pthread_join(th[t], NULL);
+}
+
+/* result arrays: malloc-family memory (callers free() it); large ones are aligned to 2 MiB and advised to use
+ * transparent huge pages, which turns 6 million page faults per 24 GiB into 12 thousand */
+static void *big_alloc(size_t bytes)
+{
+    const size_t huge = (size_t)2 << 20;
+    if (bytes < 4 * huge) return malloc(bytes ? bytes : 1);
+    void *p = aligned_alloc(huge, (bytes + huge - 1) & ~(huge - 1));
+    if (!p) return malloc(bytes);
+    (void)madvise(p, (bytes + huge - 1) & ~(huge - 1), MADV_HUGEPAGE);
+    return p;
 }
 
 static sx_ctx *thread_ctx(void)
@@ -65,7 +144,7 @@ struct suffix_array *allocate_sa_(uint8_t *string)
     size_t len = strlen((const char *)string) + 1;
     sa->string = string;
     sa->length = (uint32_t)len;
-    sa->array = malloc(len * sizeof *sa->array);
+    sa->array = big_alloc(len * sizeof *sa->array);
     sa->inverse = NULL;
     sa->lcp = NULL;
     return sa;
@@ -198,10 +277,24 @@ uint32_t remap_string(uint8_t *output, uint8_t *input)
 
 /* ---- BWT tables (stralg/bwt.c:22-161) ------------------------------------------------ */
 
+struct row_fill {
+    uint32_t **idx;
+    uint32_t *table;
+    size_t sigma;
+};
+
+static void fill_rows(size_t lo, size_t hi, void *arg)
+{
+    const struct row_fill *r = arg;
+    for (size_t i = lo; i < hi; ++i) r->idx[i] = r->table + r->sigma * i;
+}
+
+/* o_indices / ro_indices (bwt.c:52-57): 8 bytes per row, filled by a few threads */
 static uint32_t **row_pointers(uint32_t *table, size_t rows, uint32_t sigma)
 {
-    uint32_t **idx = malloc(rows * sizeof *idx);
-    for (size_t i = 0; i < rows; ++i) idx[i] = table + (size_t)sigma * i;
+    uint32_t **idx = big_alloc(rows * sizeof *idx);
+    struct row_fill r = {idx, table, sigma};
+    parallel_ranges(rows, fill_rows, &r);
     return idx;
 }
 
@@ -217,14 +310,14 @@ void init_bwt_table(struct bwt_table *bwt_table, struct suffix_array *sa, struct
     bwt_table->remap_table = remap_table;
     bwt_table->sa = sa;
     bwt_table->c_table = calloc(sigma, sizeof *bwt_table->c_table);
-    bwt_table->o_table = malloc(o_words * sizeof *bwt_table->o_table);
+    bwt_table->o_table = big_alloc(o_words * sizeof *bwt_table->o_table);
     int rc = sx_bwt_tables(ctx, sa->string, sa->array, N, sigma, bwt_table->c_table, bwt_table->o_table);
     if (rc != 0) die("init_bwt_table", rc, ctx);
     bwt_table->o_indices = row_pointers(bwt_table->o_table, N + 1, sigma);
 
     if (rsa) {
         uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
-        bwt_table->ro_table = malloc(o_words * sizeof *bwt_table->ro_table);
+        bwt_table->ro_table = big_alloc(o_words * sizeof *bwt_table->ro_table);
         rc = sx_bwt_tables(ctx, rsa->string, rsa->array, rsa->length, sigma, c_tmp, bwt_table->ro_table);
         if (rc != 0) die("init_bwt_table (reverse)", rc, ctx);
         free(c_tmp);
@@ -271,17 +364,83 @@ void completely_free_bwt_table(struct bwt_table *bwt_table)
     free(bwt_table);
 }
 
+struct presence_job {
+    const uint8_t *string;
+    bool present[64][256]; /* one row per slice */
+    size_t per;
+};
+
+static void presence_slice(size_t lo, size_t hi, void *arg)
+{
+    struct presence_job *j = arg;
+    bool *present = j->present[lo / j->per];
+    for (size_t i = lo; i < hi; ++i) present[j->string[i]] = true;
+}
+
+struct lut_job {
+    const uint8_t *in;
+    uint8_t *out;
+    const signed char *table;
+    size_t n; /* reverse: out[i] = table[in[n - 1 - i]] */
+    bool reverse;
+};
+
+static void lut_slice(size_t lo, size_t hi, void *arg)
+{
+    const struct lut_job *j = arg;
+    if (j->reverse)
+        for (size_t i = lo; i < hi; ++i) j->out[i] = j->in[j->n - 1 - i];
+    else
+        for (size_t i = lo; i < hi; ++i) j->out[i] = (uint8_t)j->table[j->in[i]];
+}
+
+/* alloc_remap_table + remap (remap.c:8-41,102-114) for a record of n letters, a few threads on the byte loops */
+static struct remap_table *remap_record(const uint8_t *string, size_t n, uint8_t *remapped)
+{
+    struct remap_table *table = malloc(sizeof *table);
+    const int slices = slice_count(n);
+    if (slices <= 1) {
+        init_remap_table(table, string);
+        remap(remapped, string, table);
+        return table;
+    }
+    struct presence_job *pj = calloc(1, sizeof *pj);
+    pj->string = string;
+    pj->per = (n + (size_t)slices - 1) / (size_t)slices; /* the slicing parallel_ranges uses */
+    parallel_ranges(n, presence_slice, pj);
+    memset(table->table, -1, sizeof table->table);
+    memset(table->rev_table, -1, sizeof table->rev_table);
+    table->table[0] = 0;
+    table->rev_table[0] = 0;
+    uint32_t next = 1;
+    for (int c = 1; c < 256; ++c) {
+        bool seen = false;
+        for (int t = 0; t < 64; ++t) seen = seen || pj->present[t][c];
+        if (!seen) continue;
+        table->table[c] = (signed char)next;
+        if (next < 128) table->rev_table[next] = (signed char)c;
+        ++next;
+    }
+    table->alphabet_size = next;
+    free(pj);
+    if (next <= 128) {
+        struct lut_job lj = {string, remapped, table->table, n, false};
+        parallel_ranges(n, lut_slice, &lj);
+        remapped[n] = 0;
+    }
+    return table;
+}
+
 struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse)
 {
     const size_t n = strlen((const char *)string);
-    struct remap_table *remap_table = alloc_remap_table(string);
+    uint8_t *remapped = malloc(n + 1);
+    struct remap_table *remap_table = remap_record(string, n, remapped);
     if (remap_table->alphabet_size > 128) {
         fprintf(stderr, "stralg_amd: build_complete_table: %u distinct letters; stralg's remap table holds "
                         "at most 127 (stralg/remap.h:14-18)\n", remap_table->alphabet_size - 1);
         abort();
     }
-    uint8_t *remapped = malloc(n + 1);
-    remap(remapped, string, remap_table);
     const uint32_t sigma = remap_table->alphabet_size;
     const size_t N = n + 1;
     const size_t o_words = (size_t)sigma * (N + 1);
@@ -290,12 +449,17 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
     /* One device pass per direction (sx_build_tables): the induced sort hands the BWT over with
      * the suffix array, so init_bwt_table's gather of text[SA[i]-1] is not repeated.  The
      * results are what sa_is_construction + init_bwt_table produce (bwt.c:143-154). */
-    struct suffix_array *sa = allocate_sa_(remapped); /* ownership of `remapped` moves into sa->string */
+    struct suffix_array *sa = malloc(sizeof *sa); /* allocate_sa_ without its strlen; `remapped` moves into sa->string */
+    sa->string = remapped;
+    sa->length = (uint32_t)N;
+    sa->array = big_alloc(N * sizeof *sa->array);
+    sa->inverse = NULL;
+    sa->lcp = NULL;
     struct bwt_table *table = malloc(sizeof *table);
     table->remap_table = remap_table;
     table->sa = sa;
     table->c_table = calloc(sigma, sizeof *table->c_table);
-    table->o_table = malloc(o_words * sizeof *table->o_table);
+    table->o_table = big_alloc(o_words * sizeof *table->o_table);
     int rc = sx_build_tables(ctx, remapped, n, sigma, sa->array, table->c_table, table->o_table);
     if (rc != 0) die("build_complete_table", rc, ctx);
     table->o_indices = row_pointers(table->o_table, N + 1, sigma);
@@ -305,10 +469,11 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
     if (include_reverse) {
         /* the reverse suffix array and the reversed copy are temporary (bwt.c:147-158) */
         uint8_t *rev = malloc(n + 1);
-        for (size_t i = 0; i < n; ++i) rev[i] = remapped[n - 1 - i];
+        struct lut_job lj = {remapped, rev, NULL, n, true};
+        parallel_ranges(n, lut_slice, &lj);
         rev[n] = 0;
         uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
-        table->ro_table = malloc(o_words * sizeof *table->ro_table);
+        table->ro_table = big_alloc(o_words * sizeof *table->ro_table);
         rc = sx_build_tables(ctx, rev, n, sigma, NULL, c_tmp, table->ro_table);
         if (rc != 0) die("build_complete_table (reverse)", rc, ctx);
         free(c_tmp);

@@ -12,6 +12,7 @@
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_internal.hpp"
+#include "sx_pager.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -286,9 +287,13 @@ int sx_sa_build(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t alphabet_
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_IO, text_bytes + N * sizeof(uint32_t) + 512));
     uint8_t *d_text = (uint8_t *)ctx->slab[SX_SLAB_IO].p;
     uint32_t *d_sa = (uint32_t *)((char *)ctx->slab[SX_SLAB_IO].p + text_bytes + 256);
+    // the caller's array is paged in by host threads while the GPU builds (sx_pager.hpp)
+    sx_host_pager pager;
+    const size_t c_sa = pager.add(sa_out, N * sizeof(uint32_t));
+    pager.start();
     if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
     SX_TRY(sx_sa_build_impl(ctx, d_text, n, alphabet_size, d_sa, nullptr));
-    SX_CHECK(hipMemcpyAsync(sa_out, d_sa, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SX_TRY(pager.download(ctx, c_sa, sa_out, d_sa, N * sizeof(uint32_t)));
     return sx_sync(ctx);
 }
 
@@ -309,12 +314,19 @@ int sx_build_tables(sx_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t sigma
     uint8_t *d_bwt = (uint8_t *)(base + text_b + 256 + sa_b);
     uint32_t *d_c = (uint32_t *)(base + text_b + 256 + sa_b + bwt_b);
     uint32_t *d_o = o_out ? (uint32_t *)(base + text_b + 256 + sa_b + bwt_b + 1024) : nullptr;
+    // the caller's arrays (4 + 4 sigma bytes per suffix) are paged in by host threads while the GPU builds, in the
+    // order the copies want them (sx_pager.hpp)
+    sx_host_pager pager;
+    const size_t o_bytes = (N + 1) * (size_t)sigma * 4;
+    const size_t c_sa = sa_out ? pager.add(sa_out, N * sizeof(uint32_t)) : 0;
+    const size_t c_o = o_out ? pager.add(o_out, o_bytes) : 0;
+    pager.start();
     if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
     SX_TRY(sx_sa_build_impl(ctx, d_text, n, sigma, d_sa, d_bwt));
     SX_TRY(sx_tables_from_bwt_impl(ctx, d_bwt, N, sigma, d_c, d_o));
-    if (sa_out) SX_CHECK(hipMemcpyAsync(sa_out, d_sa, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (sa_out) SX_TRY(pager.download(ctx, c_sa, sa_out, d_sa, N * sizeof(uint32_t)));
     SX_CHECK(hipMemcpyAsync(c_out, d_c, (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (o_out) SX_CHECK(hipMemcpyAsync(o_out, d_o, (N + 1) * (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (o_out) SX_TRY(pager.download(ctx, c_o, o_out, d_o, o_bytes));
     return sx_sync(ctx);
 }
 

@@ -15,6 +15,7 @@
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
 #include "sx_internal.hpp"
+#include "sx_pager.hpp"
 
 namespace sx {
 
@@ -423,11 +424,15 @@ int sx_bwt_tables(sx_ctx *ctx, const uint8_t *text, const uint32_t *sa, uint64_t
     uint32_t *d_sa = (uint32_t *)(base + text_b + 256);
     uint32_t *d_c = (uint32_t *)(base + text_b + 256 + sa_b);
     uint32_t *d_o = o_out ? (uint32_t *)(base + text_b + 256 + sa_b + 1024) : nullptr;
+    sx_host_pager pager; // the caller's O table is paged in by host threads meanwhile (sx_pager.hpp)
+    const size_t o_bytes = (N + 1) * (size_t)sigma * 4;
+    const size_t c_o = o_out ? pager.add(o_out, o_bytes) : 0;
+    pager.start();
     if (n) SX_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx->stream));
     SX_CHECK(hipMemcpyAsync(d_sa, sa, N * 4, hipMemcpyHostToDevice, ctx->stream));
     SX_TRY(bwt_tables_dev(ctx, d_text, d_sa, nullptr, N, sigma, d_c, d_o, nullptr));
     SX_CHECK(hipMemcpyAsync(c_out, d_c, (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (o_out) SX_CHECK(hipMemcpyAsync(o_out, d_o, (N + 1) * (size_t)sigma * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (o_out) SX_TRY(pager.download(ctx, c_o, o_out, d_o, o_bytes));
     return sx_sync(ctx);
 }
 

@@ -224,3 +224,43 @@ def test_primitives(emu_ctx):
     emu_ctx.prim_exclusive_sum_dev(x, out, x.size, tot)
     ref = np.concatenate(([0], np.cumsum(x, dtype=np.uint64)[:-1])).astype(np.uint32)
     assert (out == ref).all() and tot[0] == x.sum()
+
+
+def test_threaded_host_layer(emu_ctx, golden, monkeypatch):
+    """build_complete_table's host side in its threaded form (remap by slices, reversal, row pointers, the pager
+    behind the downloads): forced onto small records through STRALG_AMD_PARALLEL_MIN / STRALG_AMD_HOST_THREADS"""
+    import ctypes as C
+
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class RT(C.Structure):
+        _fields_ = [("alphabet_size", C.c_uint32), ("table", C.c_byte * 256), ("rev_table", C.c_byte * 128)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.POINTER(RT)), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.POINTER(C.POINTER(C.c_uint32))),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.POINTER(C.POINTER(C.c_uint32)))]
+
+    lib = emu_ctx.lib
+    lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
+    lib.build_complete_table.restype = C.POINTER(BT)
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    for threads, pmin in (("5", "64"), ("3", "1"), ("64", "16")):
+        monkeypatch.setenv("STRALG_AMD_HOST_THREADS", threads)
+        monkeypatch.setenv("STRALG_AMD_PARALLEL_MIN", pmin)
+        for name in ("ref/repetitive", "ref/mississippi", "ref/fasta3"):
+            c = golden[name]
+            t = lib.build_complete_table(bytes(c["raw"]), True)
+            N, sigma = t.contents.sa.contents.length, c["sigma"]
+            assert t.contents.remap_table.contents.alphabet_size == sigma
+            assert (np.ctypeslib.as_array(t.contents.sa.contents.string, shape=(N,))[:-1] == c["sym"]).all(), name
+            assert (np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)) == c["sa"]).all(), name
+            assert (np.ctypeslib.as_array(t.contents.o_table, shape=(N + 1, sigma)) == c["o"]).all(), name
+            assert (np.ctypeslib.as_array(t.contents.ro_table, shape=(N + 1, sigma)) == c["ro"]).all(), name
+            base = C.addressof(t.contents.o_table.contents)
+            for i in (0, 1, N // 2, N):
+                assert C.addressof(t.contents.o_indices[i].contents) == base + 4 * sigma * i
+            lib.completely_free_bwt_table(t)

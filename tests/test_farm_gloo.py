@@ -23,6 +23,28 @@ def test_lpt_assignment():
     assert lpt_assign([4], 3) == [[0], [], []]
 
 
+def test_c_lpt_assignment_matches_python():
+    """stralg_amd_lpt_assign (the C farm's dealer) gives the assignment of farm.lpt_assign"""
+    import ctypes as C
+    from stralg_amd import _lib
+    from stralg_amd.farm import lpt_assign
+    lib = _lib.load()
+    lib.stralg_amd_lpt_assign.argtypes = [C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+    lib.stralg_amd_lpt_assign.restype = C.c_int
+    rng = np.random.default_rng(11)
+    for count, lanes in ((0, 3), (1, 1), (1, 4), (8, 8), (9, 2), (40, 3), (100, 8)):
+        lengths = [int(v) for v in rng.integers(1, 1000, size=count)]
+        if count > 4:
+            lengths[3] = lengths[1]  # ties keep the given order
+        arr = (C.c_size_t * max(1, count))(*lengths)
+        out = (C.c_int * max(1, count))()
+        assert lib.stralg_amd_lpt_assign(arr, count, lanes, out) == 0
+        want = lpt_assign(lengths, lanes)
+        got = [[k for k in range(count) if out[k] == lane] for lane in range(lanes)]
+        assert [sorted(g) for g in got] == [sorted(w) for w in want], (count, lanes)
+    assert lib.stralg_amd_lpt_assign(None, 0, 0, None) == -1
+
+
 def _worker(rank, world, port, emu_lib, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

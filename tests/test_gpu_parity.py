@@ -440,6 +440,59 @@ def test_c_batch_farm(gpu_ctx, golden):
         lib.completely_free_bwt_table(t)
 
 
+def test_c_batch_farm_unequal_records(gpu_ctx):
+    """records of very unequal length (3 M ... 20 k symbols) over three lanes: dealt longest first to the least loaded
+    lane (stralg_amd_lpt_assign), every worker pinned to its GPU's NUMA node; results against the oracle"""
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.c_void_p), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.c_void_p),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.c_void_p)]
+
+    lib = gpu_ctx.lib
+    lengths = [3_000_000, 20_000, 1_500_000, 700_000, 50_000, 1_400_000, 123_457]
+    letters = np.frombuffer(b"\0ACGT", dtype=np.uint8)
+    syms = [synth(n, 5, 500 + i) for i, n in enumerate(lengths)]
+    raws = [letters[x].tobytes() for x in syms]
+    arr = (C.c_char_p * len(raws))(*raws)
+    out = (C.POINTER(BT) * len(raws))()
+    devs = (C.c_int * 3)(0, 0, 0)
+    lib.stralg_amd_build_tables_batch.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_bool, C.POINTER(C.c_int), C.c_int,
+                                                  C.POINTER(C.POINTER(BT))]
+    lib.stralg_amd_build_tables_batch.restype = C.c_int
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    assert lib.stralg_amd_build_tables_batch(arr, len(raws), False, devs, 3, out) == 0
+    for x, t in zip(syms, out):
+        N = t.contents.sa.contents.length
+        assert N == x.size + 1
+        want = oracle.sa_is(x, 5)
+        assert (np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)) == want).all(), N
+        o = np.ctypeslib.as_array(t.contents.o_table, shape=(N + 1, 5))
+        assert (o[N] == np.bincount(np.concatenate((x, [0])), minlength=5)).all()
+        assert not t.contents.ro_table
+        lib.completely_free_bwt_table(t)
+    # the NUMA binding: the node the library reports for GPU 0 is the node it binds a thread to
+    lib.stralg_amd_bind_thread_to_device.argtypes = [C.c_int]
+    import threading
+    got = []
+    th = threading.Thread(target=lambda: got.append((lib.stralg_amd_bind_thread_to_device(0), os.sched_getaffinity(0))))
+    th.start()
+    th.join()
+    node = lib.sx_device_numa_node(0)
+    assert got[0][0] == node or got[0][0] == -1
+    if node >= 0 and got[0][0] == node:
+        cpus = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+        want_set = set()
+        for part in cpus.split(","):
+            a, _, b = part.partition("-")
+            want_set |= set(range(int(a), int(b or a) + 1))
+        assert got[0][1] == want_set & os.sched_getaffinity(0) or got[0][1] <= want_set
+
+
 def test_c_harness_runs(tmp_path):
     """a plain C caller of the reference-named API (restated performance/suffix_array_construction.c)"""
     import subprocess
