@@ -25,14 +25,6 @@ namespace sx {
 
 __device__ __forceinline__ bool fasta_space(uint32_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 
-// position of the first NUL byte (the reference reads a C string: io.c:15-18)
-__global__ __launch_bounds__(kBlock) void fasta_first_nul_kernel(const uint8_t *__restrict__ file, uint64_t len,
-                                                                 uint32_t *__restrict__ first)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (uint64_t)gridDim.x * kBlock)
-        if (file[i] == 0) atomicMin(first, (uint32_t)i);
-}
-
 // ---- packing: three passes over tiles of 4096 bytes, 16 bytes per thread in registers ------------------------
 constexpr int kFaPer = 16, kFaTile = kBlock * kFaPer;
 
@@ -71,40 +63,60 @@ struct fa_chunk {
     uint32_t emit, term, name_end;
     bool eof_in_name;
 };
+// The loop of fasta.c:26-70 is a two-state machine, but the state before a byte depends only on the last '\n'
+// (a sequence follows, whatever the state was) or '>' (a header follows) before it, so the 16 bytes are classified
+// without branches into bit masks, the states are filled in from the events by doubling (4 steps for 16 bits), and
+// what is emitted follows from masks: a divergent 16-step walk per thread cost 1.2 - 1.4 ms per GiB and pass.
 __device__ __forceinline__ fa_chunk fasta_walk(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end, bool in_seq)
 {
-    fa_chunk r{0, 0, 0, false};
+    uint32_t nl = 0, gt = 0, sp = 0, hdrop = 0;
 #pragma unroll
     for (int k = 0; k < kFaPer; ++k) {
-        const uint64_t i = i0 + k;
-        if (i > end) continue;
-        const uint32_t c = b[k], bit = 1u << k;
-        if (in_seq) {
-            if (c == '>' || i == end) {
-                r.emit |= bit, r.term |= bit; // the sequence's terminator
-                in_seq = false;
-            } else if (!fasta_space(c)) {
-                r.emit |= bit;
-            }
-        } else if (i == end) {
-            r.eof_in_name = true;
-        } else if (c == '\n') {
-            r.emit |= bit, r.term |= bit, r.name_end |= bit; // the header's terminator
-            in_seq = true;
-        } else if (!(c == '>' || c == ' ' || c == '\t')) {
-            r.emit |= bit;
-        }
+        const uint32_t c = b[k];
+        nl |= (c == '\n' ? 1u : 0u) << k;
+        gt |= (c == '>' ? 1u : 0u) << k;
+        sp |= ((c == ' ' || c - 9u < 5u) ? 1u : 0u) << k;        // isspace(): what a sequence drops
+        hdrop |= ((c == ' ' || c == '\t') ? 1u : 0u) << k;        // what a header line drops besides '>'
     }
+    // positions before `end`, and the position `end` itself (the terminating NUL of the reference's buffer)
+    const uint32_t lt = i0 >= end ? 0u : (end - i0 >= (uint64_t)kFaPer ? 0xFFFFu : (1u << (uint32_t)(end - i0)) - 1u);
+    const uint32_t ate = (end >= i0 && end - i0 < (uint64_t)kFaPer) ? 1u << (uint32_t)(end - i0) : 0u;
+    // state before every byte: events are "a sequence starts here" (after a newline) and "a header starts here"
+    // (after a '>'); position 0 takes the entry state
+    uint32_t val = (((nl & lt) << 1) | (in_seq ? 1u : 0u)) & 0xFFFFu;
+    uint32_t have = (val | ((gt & lt) << 1) | 1u) & 0xFFFFu;
+#pragma unroll
+    for (int s = 1; s < kFaPer; s <<= 1) {
+        const uint32_t fresh = ~have & (have << s) & 0xFFFFu;
+        val |= (val << s) & fresh;
+        have |= fresh;
+    }
+    const uint32_t seq = val, hdr = ~val & 0xFFFFu;
+    fa_chunk r;
+    const uint32_t seq_term = seq & ((gt & lt) | ate);
+    r.name_end = hdr & nl & lt;
+    r.term = seq_term | r.name_end;
+    r.emit = r.term | (seq & lt & ~sp & ~gt) | (hdr & lt & ~(gt | hdrop | nl));
+    r.eof_in_name = (hdr & ate) != 0;
     return r;
 }
 
+// also finds the first NUL byte (the reference reads a C string: io.c:15-18).  The tiles behind it are never used,
+// and the tile that holds it recomputes its states with the right end in the later passes, so `end` may still be
+// the file's length here.
 __global__ __launch_bounds__(kBlock) void fasta_tile_last_kernel(const uint8_t *__restrict__ file, uint64_t end,
-                                                                 uint32_t *__restrict__ tile_last)
+                                                                 uint32_t *__restrict__ tile_last,
+                                                                 uint32_t *__restrict__ first_nul)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
     uint32_t b[kFaPer];
     fasta_load16(file, i0, end, b);
+    uint32_t zero_at = kFaPer;
+#pragma unroll
+    for (int k = kFaPer - 1; k >= 0; --k)
+        if (b[k] == 0 && i0 + k < end) zero_at = (uint32_t)k;
+    if (zero_at < (uint32_t)kFaPer) atomicMin(first_nul, (uint32_t)(i0 + zero_at));
     const uint32_t tot = block_reduce<OpMax>(fasta_last_special(b, i0, end), lds);
     if (threadIdx.x == 0) tile_last[blockIdx.x] = tot;
 }
@@ -171,14 +183,15 @@ __global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__re
     }
 }
 
-// which byte values occur: 256 flags as 8 words
+// which byte values occur: 256 flags as 8 words.  A workgroup marks the values it sees in a byte table in LDS with
+// plain stores (every writer stores 1: the races are benign) and merges the table into the global flags once;
+// keeping the flags in registers cost eight compares per byte for the static register indices (0.68 ms per GiB).
 __global__ __launch_bounds__(kBlock) void remap_present_kernel(const uint8_t *__restrict__ in, uint64_t n,
                                                                uint32_t *__restrict__ present)
 {
-    __shared__ uint32_t seen[8];
-    if (threadIdx.x < 8) seen[threadIdx.x] = 0;
+    __shared__ uint8_t seen[256];
+    seen[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // (a record's sequence starts wherever its name ends in the packed image: 16-byte loads at any byte address,
     //  sx_device.hpp load_bytes16)
     for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q * 16 < n; q += (uint64_t)gridDim.x * kBlock) {
@@ -186,26 +199,13 @@ __global__ __launch_bounds__(kBlock) void remap_present_kernel(const uint8_t *__
             uint32_t w[4];
             __builtin_memcpy(w, in + q * 16, 16);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) // static register indices
-                    if ((b >> 5) == (uint32_t)s) mine[s] |= 1u << (b & 31u);
-            }
+            for (int k = 0; k < 16; ++k) seen[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu] = 1;
         } else {
-            for (uint64_t i = q * 16; i < n && i < q * 16 + 16; ++i) {
-                const uint32_t b = in[i];
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    if ((b >> 5) == (uint32_t)s) mine[s] |= 1u << (b & 31u);
-            }
+            for (uint64_t i = q * 16; i < n && i < q * 16 + 16; ++i) seen[in[i]] = 1;
         }
     }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-        if (mine[s]) atomicOr(&seen[s], mine[s]);
     __syncthreads();
-    if (threadIdx.x < 8 && seen[threadIdx.x]) atomicOr(&present[threadIdx.x], seen[threadIdx.x]);
+    if (seen[threadIdx.x]) atomicOr(&present[threadIdx.x >> 5], 1u << (threadIdx.x & 31u));
 }
 
 __global__ __launch_bounds__(kBlock) void remap_apply_kernel(const uint8_t *__restrict__ in, uint64_t n,
@@ -258,18 +258,21 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
              *tile_term = tile_emit + tiles_max, *tile_eoff = tile_term + tiles_max;
     const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
     SX_CHECK(hipMemcpyAsync(scal, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    // pass 1 over the whole image: last '\n' / '>' of every tile, and the first NUL (which ends the image)
     uint32_t first_nul = 0xFFFFFFFFu;
     if (file_len) {
-        uint32_t grid = sx_div_up(file_len, kBlock * 16);
-        if (grid > 4096) grid = 4096;
-        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_first_nul_kernel, dim3(grid), dim3(kBlock), d_file, file_len, scal);
+        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_tile_last_kernel, dim3(sx_div_up(file_len, kFaTile)), dim3(kBlock), d_file,
+                  file_len, tile_last, scal);
         SX_TRY(sx_readback(ctx, scal, 1, &first_nul));
     }
     const uint64_t end = first_nul < file_len ? first_nul : file_len;
     const uint64_t span = end + 1; // with the terminating NUL of the reference's buffer
     const uint32_t tiles = sx_div_up(span, kFaTile);
     const dim3 grid(tiles), block(kBlock);
-    sx_launch(ctx, SX_KC_FASTA, span, fasta_tile_last_kernel, grid, block, d_file, end, tile_last);
+    if (tiles > sx_div_up(file_len, kFaTile)) // (the span's last tile lies behind the image: it holds the terminator only)
+        SX_CHECK(hipMemsetAsync(tile_last + tiles - 1, 0, sizeof(uint32_t), ctx->stream));
+    // (the last tile's entry is never used -- the scan below is exclusive --, so the tile that holds the NUL needs no
+    //  second look although it saw the bytes behind it)
     SX_TRY((device_scan<OpMax>(ctx, tiles, InU32{tile_last}, OutExclusive{tile_carry}, nullptr, SX_KC_FASTA, 0)));
     sx_launch(ctx, SX_KC_FASTA, span, fasta_count_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry, tile_emit,
               tile_term, scal);

@@ -33,6 +33,12 @@ namespace sx {
 
 constexpr int kIndItems = 8;
 constexpr int kIndTile = kBlock * kIndItems;
+// Rounds of up to this many tiles are left to the tail kernel (one workgroup, many rounds per launch, the tiles of a
+// round one after the other): a chained launch costs ~18 us whatever it holds, a tile of the tail ~3 us.  The rounds
+// of a bucket shrink with the run length of its symbol, so texts with poly-A tracts and microsatellites spend
+// hundreds of rounds at a few thousand entries (a genome-like 1 GiB text: 489 rounds, 9 ms of chained launches).
+constexpr uint32_t kTailTiles = 4;
+constexpr uint32_t kTailEntries = kTailTiles * (uint32_t)kIndTile;
 
 enum { MODE_L_FROM_L = 0, MODE_L_FROM_LMS = 1, MODE_S_FROM_S = 2, MODE_S_FROM_L = 3 };
 
@@ -508,7 +514,8 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt, int dir, uint32_t *__restrict__ SA,
     WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch,
     uint32_t *__restrict__ ticket,
-    uint32_t chain_max /* rounds longer than this are left to the three-launch form; ~0u: take any round */)
+    uint32_t chain_max /* rounds longer than this are left to the three-launch form; ~0u: take any round */,
+    int tail_follows /* the batch ends with the tail kernel: rounds of up to kTailEntries entries are left to it */)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gpos[256];  // entries of earlier tiles per bucket
@@ -519,11 +526,13 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     const uint32_t lo = range_in[0], hi = range_in[1];
     const uint32_t len = hi - lo;
     if (len > chain_max) return; // a large round: the three-launch form handles it
-    if (len == 0) { // nothing to do: carry the cursors over, hand on an empty range
+    if (len == 0 || (range_out && tail_follows && len <= kTailEntries)) {
+        // nothing to do, or a round small enough for the tail kernel that ends the batch: carry the cursors over,
+        // hand the range on as it is
         if (blockIdx.x == 0) {
             cursor_nxt[t] = cursor_cur[t];
             if (t == 0 && range_out) {
-                range_out[0] = hi;
+                range_out[0] = len ? lo : hi;
                 range_out[1] = hi;
             }
         }
@@ -647,14 +656,14 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
     __syncthreads();
     for (uint32_t it = 0; it < max_iters; ++it) {
         const uint32_t lo = s_range[0], len = s_range[1] - lo;
-        if (len == 0 || len > (uint32_t)kIndTile) break; // uniform
+        if (len == 0 || len > kTailEntries) break; // uniform
         // ---- run jump -------------------------------------------------------------------
         // Inside a long run of symbol c every entry of the range induces its left neighbour
         // into bucket c again, round after round, in the same order.  If the L symbols to the
         // left of every entry are all c, the next L rounds are known: round j holds the same
         // entries minus j, in the next `len` slots.  They are written at once (L = 16 symbols
         // per checking thread; 4096 rounds a step for a single run) instead of one at a time.
-        if (mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) {
+        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len <= (uint32_t)kIndTile) {
             const uint32_t G = len <= (uint32_t)kBlock ? (uint32_t)kBlock / len : 1u; // threads per entry
             const uint32_t L = 16u * G;
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
@@ -695,67 +704,71 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
                 continue;
             }
         }
-        for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
-        __syncthreads();
-        const uint32_t wave0 = (uint32_t)w * (kWave * kIndItems);
-        uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
-        WT wnd[kIndItems];
-        bool ok[kIndItems];
+        // the round's tiles one after the other (the buckets' cursors move on between them, so the order of the
+        // entries is the order of the scan)
+        const uint32_t c_start = gbase[c];
+        for (uint32_t sub0 = 0; sub0 < len; sub0 += (uint32_t)kIndTile) { // uniform
+            for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+            __syncthreads();
+            const uint32_t wave0 = sub0 + (uint32_t)w * (kWave * kIndItems);
+            uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
+            WT wnd[kIndItems];
+            bool ok[kIndItems];
 #pragma unroll
-        for (int k = 0; k < kIndItems; ++k) {
-            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
-            ok[k] = false;
-            dig[k] = 0;
-            val[k] = 0;
-            wnd[k] = 0;
-            if (i < len) {
-                const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                const uint32_t p = SA[idx];
-                if (p != 0) {
-                    const WT ww = WN[idx];
-                    const uint32_t ch = wnd_first<WT>(ww, cfg);
-                    ok[k] = induce_accept(ch, c, mode);
-                    dig[k] = ch;
-                    val[k] = p - 1u;
-                    wnd[k] = wnd_pop<WT>(ww, cfg);
+            for (int k = 0; k < kIndItems; ++k) {
+                const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+                ok[k] = false;
+                dig[k] = 0;
+                val[k] = 0;
+                wnd[k] = 0;
+                if (i < len) {
+                    const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                    const uint32_t p = SA[idx];
+                    if (p != 0) {
+                        const WT ww = WN[idx];
+                        const uint32_t ch = wnd_first<WT>(ww, cfg);
+                        ok[k] = induce_accept(ch, c, mode);
+                        dig[k] = ch;
+                        val[k] = p - 1u;
+                        wnd[k] = wnd_pop<WT>(ww, cfg);
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
-        __syncthreads();
-        uint32_t cnt = 0; // entries of this round for bucket t
-        {
+            for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
+            __syncthreads();
+            uint32_t cnt = 0; // entries of this tile for bucket t
+            {
 #pragma unroll
-            for (int ww = 0; ww < kWavesPerBlock; ++ww) {
-                const uint32_t x = wcount[ww][t];
-                wcount[ww][t] = cnt;
-                cnt += x;
+                for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+                    const uint32_t x = wcount[ww][t];
+                    wcount[ww][t] = cnt;
+                    cnt += x;
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kIndItems; ++k) {
-            if (ok[k]) {
-                const uint32_t d = dig[k];
-                const uint32_t r = wcount[w][d] + rnk[k];
-                const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
-                const uint32_t j = val[k];
-                WT nw = wnd[k];
-                if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg);
-                SA[dst] = j;
-                WN[dst] = nw;
-                BW[dst] = wnd_symbol<WT>(nw, cfg);
+            for (int k = 0; k < kIndItems; ++k) {
+                if (ok[k]) {
+                    const uint32_t d = dig[k];
+                    const uint32_t r = wcount[w][d] + rnk[k];
+                    const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
+                    const uint32_t j = val[k];
+                    WT nw = wnd[k];
+                    if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg);
+                    SA[dst] = j;
+                    WN[dst] = nw;
+                    BW[dst] = wnd_symbol<WT>(nw, cfg);
+                }
             }
+            __syncthreads();
+            gbase[t] = dir > 0 ? gbase[t] + cnt : gbase[t] - cnt;
+            __syncthreads(); // (the next tile reads the cursors; LDS is reused)
         }
-        __syncthreads();
-        {
-            const uint32_t old = gbase[t];
-            gbase[t] = dir > 0 ? old + cnt : old - cnt;
-            if ((uint32_t)t == c) {
-                s_range[0] = dir > 0 ? old : old - cnt;
-                s_range[1] = dir > 0 ? old + cnt : old;
-            }
+        if ((uint32_t)t == c) { // what the round appended to bucket c is the next round's input
+            const uint32_t now = gbase[c];
+            s_range[0] = dir > 0 ? c_start : now;
+            s_range[1] = dir > 0 ? now : c_start;
         }
         __syncthreads(); // also orders this round's stores before the next round's loads
     }
@@ -932,7 +945,7 @@ template <class WT> struct induce_state {
 
 template <class WT>
 void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, int range_slot, int out_slot,
-                  uint32_t tiles_bound, uint32_t tiles_likely, int rev, int mode, uint32_t c, int dir)
+                  uint32_t tiles_bound, uint32_t tiles_likely, int rev, int mode, uint32_t c, int dir, int tail_follows)
 {
     sx_ctx *ctx = st.ctx;
     uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
@@ -984,15 +997,15 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
-                  epoch, st.tickets + range_slot, chain_max);
+                  epoch, st.tickets + range_slot, chain_max, tail_follows);
     else if (st.nk <= 32)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 5>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
-                  epoch, st.tickets + range_slot, chain_max);
+                  epoch, st.tickets + range_slot, chain_max, tail_follows);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 8>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
-                  epoch, st.tickets + range_slot, chain_max);
+                  epoch, st.tickets + range_slot, chain_max, tail_follows);
     st.par ^= 1;
     ctx->stats.induce_rounds++;
 }
@@ -1048,7 +1061,7 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             double expect = 2.0 * (double)bound_tiles;
             for (int i = 0; i < k; ++i) expect *= share;
             const uint32_t likely = expect < (double)bound_tiles ? (uint32_t)expect : bound_tiles;
-            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir);
+            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir, 1);
         }
         launch_tail<WT>(st, spec, spec + 1, rev, mode, c, dir);
         uint32_t r[2];
@@ -1155,7 +1168,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
                       (const uint32_t *)st.cursor[st.par], (int)c, 0);
             launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), sx_div_up(ti.h_lms[c], kIndTile), 0,
-                             MODE_L_FROM_LMS, c, +1);
+                             MODE_L_FROM_LMS, c, +1, 0);
         }
     }
 
@@ -1177,7 +1190,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
                       begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0);
             launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), sx_div_up(ti.h_l[c], kIndTile), 1,
-                             MODE_S_FROM_L, c, -1);
+                             MODE_S_FROM_L, c, -1, 0);
         }
     }
 
