@@ -33,12 +33,14 @@ namespace sx {
 
 constexpr int kIndItems = 8;
 constexpr int kIndTile = kBlock * kIndItems;
-// Rounds of up to this many tiles are left to the tail kernel (one workgroup, many rounds per launch, the tiles of a
-// round one after the other): a chained launch costs ~18 us whatever it holds, a tile of the tail ~3 us.  The rounds
-// of a bucket shrink with the run length of its symbol, so texts with poly-A tracts and microsatellites spend
-// hundreds of rounds at a few thousand entries (a genome-like 1 GiB text: 489 rounds, 9 ms of chained launches).
-constexpr uint32_t kTailTiles = 4;
-constexpr uint32_t kTailEntries = kTailTiles * (uint32_t)kIndTile;
+// Rounds of up to 8192 entries are left to the tail kernel (one workgroup of 1024 threads, many rounds per launch):
+// a chained launch costs ~18 us whatever it holds, a round of the tail a few.  The rounds of a bucket shrink with the
+// run length of its symbol, so texts with poly-A tracts and microsatellites spend hundreds of rounds at a few
+// thousand entries (a genome-like 1 GiB text: 489 chained launches, 9 ms).  (Four 2048-entry tiles one after the other
+// in a 256-thread workgroup were five times slower than the chained launches: every tile pays the load latency.)
+constexpr int kTailBlock = 1024, kTailWaves = kTailBlock / kWave; // the tail kernel's workgroup: 16 waves, one tile
+constexpr int kTailTile = kTailBlock * kIndItems;
+constexpr uint32_t kTailEntries = (uint32_t)kTailTile;
 
 enum { MODE_L_FROM_L = 0, MODE_L_FROM_LMS = 1, MODE_S_FROM_S = 2, MODE_S_FROM_L = 3 };
 
@@ -636,19 +638,19 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
 // Entries written in one iteration are read in the next by other waves of the same
 // workgroup: the barrier's workgroup-scope fence orders them (the waves share the CU's L1).
 template <class WT, int BITS>
-__global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *WN, uint8_t *BW, const uint32_t *__restrict__ range_in,
+__global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, WT *WN, uint8_t *BW, const uint32_t *__restrict__ range_in,
                                                              uint32_t *__restrict__ range_out, int rev, int mode,
                                                              uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
                                                              const uint32_t *__restrict__ cursor_cur,
                                                              uint32_t *__restrict__ cursor_nxt, int dir,
                                                              uint32_t max_iters)
 {
-    __shared__ uint32_t wcount[kWavesPerBlock][256];
+    __shared__ uint32_t wcount[kTailWaves][256];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t s_range[2];
     __shared__ uint32_t s_flag;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    gbase[t] = cursor_cur[t];
+    if (t < 256) gbase[t] = cursor_cur[t];
     if (t == 0) {
         s_range[0] = range_in[0];
         s_range[1] = range_in[1];
@@ -663,12 +665,12 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
         // left of every entry are all c, the next L rounds are known: round j holds the same
         // entries minus j, in the next `len` slots.  They are written at once (L = 16 symbols
         // per checking thread; 4096 rounds a step for a single run) instead of one at a time.
-        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len <= (uint32_t)kIndTile) {
-            const uint32_t G = len <= (uint32_t)kBlock ? (uint32_t)kBlock / len : 1u; // threads per entry
+        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len <= (uint32_t)kTailTile) {
+            const uint32_t G = len <= (uint32_t)kTailBlock ? (uint32_t)kTailBlock / len : 1u; // threads per entry
             const uint32_t L = 16u * G;
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
             bool all_c = true;
-            for (uint32_t e = (uint32_t)t; e < len * G; e += kBlock) {
+            for (uint32_t e = (uint32_t)t; e < len * G; e += kTailBlock) {
                 const uint32_t i = e / G, q = e % G;
                 const uint32_t p = SA[lo + (rev ? len - 1u - i : i)];
                 if (p < 16u * (q + 1u)) {
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
             __syncthreads();
             if (s_flag) { // uniform
                 const uint32_t cur = gbase[c], total = L * len;
-                for (uint32_t o = (uint32_t)t; o < total; o += kBlock) {
+                for (uint32_t o = (uint32_t)t; o < total; o += kTailBlock) {
                     const uint32_t j = o / len + 1u, i = o % len;
                     const uint32_t v = SA[lo + (rev ? len - 1u - i : i)] - j;
                     const uint32_t dst = dir > 0 ? cur + o : cur - 1u - o;
@@ -705,10 +707,10 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
             }
         }
         // the round's tiles one after the other (the buckets' cursors move on between them, so the order of the
-        // entries is the order of the scan)
+        // entries is the order of the scan); a tile is the whole round as the launch is configured now
         const uint32_t c_start = gbase[c];
-        for (uint32_t sub0 = 0; sub0 < len; sub0 += (uint32_t)kIndTile) { // uniform
-            for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
+        for (uint32_t sub0 = 0; sub0 < len; sub0 += (uint32_t)kTailTile) { // uniform
+            for (int i = t; i < kTailWaves * 256; i += kTailBlock) (&wcount[0][0])[i] = 0;
             __syncthreads();
             const uint32_t wave0 = sub0 + (uint32_t)w * (kWave * kIndItems);
             uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
@@ -738,9 +740,9 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
             for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
             __syncthreads();
             uint32_t cnt = 0; // entries of this tile for bucket t
-            {
+            if (t < 256) {
 #pragma unroll
-                for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+                for (int ww = 0; ww < kTailWaves; ++ww) {
                     const uint32_t x = wcount[ww][t];
                     wcount[ww][t] = cnt;
                     cnt += x;
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
                 }
             }
             __syncthreads();
-            gbase[t] = dir > 0 ? gbase[t] + cnt : gbase[t] - cnt;
+            if (t < 256) gbase[t] = dir > 0 ? gbase[t] + cnt : gbase[t] - cnt;
             __syncthreads(); // (the next tile reads the cursors; LDS is reused)
         }
         if ((uint32_t)t == c) { // what the round appended to bucket c is the next round's input
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(kBlock) void induce_tail_kernel(uint32_t *SA, WT *W
         }
         __syncthreads(); // also orders this round's stores before the next round's loads
     }
-    cursor_nxt[t] = gbase[t];
+    if (t < 256) cursor_nxt[t] = gbase[t];
     if (t == 0) {
         range_out[0] = s_range[0];
         range_out[1] = s_range[1];
@@ -1019,11 +1021,11 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
     const uint32_t *cur = st.cursor[st.par];
     uint32_t *nxt = st.cursor[st.par ^ 1];
     if (st.small_alphabet)
-        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kBlock), st.SA, st.WN, st.BW,
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, kTailIters);
     else
-        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kBlock), st.SA, st.WN, st.BW,
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, kTailIters);
     st.par ^= 1;
