@@ -791,8 +791,14 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
 // leaves the last round as the range.  L = 0 changes nothing.
 constexpr uint32_t kRunProbe = 1u << 26;
 constexpr uint32_t kRunEntries = 64; // runs of c that are alive in the bucket at the same time (a gap per chromosome)
+constexpr uint32_t kRunProbeChunk = (uint32_t)kBlock * 16u; // symbols a workgroup looks at per step
+constexpr uint32_t kRunProbeGrid = 256;                    // workgroups per entry
+// Workgroup x of entry y looks at the distances [k * chunk, (k + 1) * chunk), k = x, x + grid, ..., and stops as soon
+// as the run is known to end nearer than where it would look next: the probe costs what the run is long, not the
+// 64 Mi symbols it may look at most (with every workgroup reading its piece whatever the others found, a probe of 64
+// entries read 4 GB: 5.5 ms, 14 probes in a genome-like 1 GiB text whose runs are a few dozen symbols long).
 __global__ __launch_bounds__(kBlock) void run_probe_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA,
-                                                          const uint32_t *__restrict__ range, uint32_t c,
+                                                          const uint32_t *__restrict__ range, uint32_t c, uint32_t look,
                                                           uint32_t *__restrict__ run_len /* preset to ~0 */)
 {
     const uint32_t lo = range[0], len = range[1] - lo;
@@ -801,19 +807,23 @@ __global__ __launch_bounds__(kBlock) void run_probe_kernel(const uint8_t *__rest
         return;
     }
     const uint32_t p = SA[lo + blockIdx.y]; // (the minimum over the entries does not depend on their order)
-    const uint32_t d0 = (blockIdx.x * (uint32_t)kBlock + threadIdx.x) * 16u; // this thread looks at p-d0-1 ... p-d0-16
-    if (d0 >= p) {
-        if (d0 < p + 16u) atomicMin(run_len, p); // the text starts here: at most p symbols to the left
-        return;
-    }
-    const uint32_t cnt = p - d0 < 16u ? p - d0 : 16u;
-    uint32_t first_other = cnt; // symbols c in a row, going left from p - d0
-    for (uint32_t e = 0; e < cnt; ++e)
-        if (T[p - d0 - 1u - e] != (uint8_t)c) {
-            first_other = e;
-            break;
+    for (uint32_t chunk0 = blockIdx.x * kRunProbeChunk; chunk0 < look; chunk0 += gridDim.x * kRunProbeChunk) { // uniform
+        // (a relaxed agent-scope load: what another workgroup found becomes visible in time, never too early)
+        if (__hip_atomic_load(run_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= chunk0) return;
+        const uint32_t d0 = chunk0 + threadIdx.x * 16u; // this thread looks at p-d0-1 ... p-d0-16
+        if (d0 >= p) {
+            if (d0 < p + 16u) atomicMin(run_len, p); // the text starts here: at most p symbols to the left
+            continue;
         }
-    if (first_other < 16u) atomicMin(run_len, d0 + first_other); // (cnt < 16: the text starts there)
+        const uint32_t cnt = p - d0 < 16u ? p - d0 : 16u;
+        uint32_t first_other = cnt; // symbols c in a row, going left from p - d0
+        for (uint32_t e = 0; e < cnt; ++e)
+            if (T[p - d0 - 1u - e] != (uint8_t)c) {
+                first_other = e;
+                break;
+            }
+        if (first_other < 16u) atomicMin(run_len, d0 + first_other); // (cnt < 16: the text starts there)
+    }
 }
 
 // rounds the jump covers: every entry of the range has at least that many symbols c to its left
@@ -1048,7 +1058,12 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         const int sh = st.small_alphabet ? 2 : 6;
         while (spec < kMaxSpec && (bound_tiles >> (sh * spec)) >= 1) ++spec;
     }
-    for (;;) {
+    // Every batch ends with the tail kernel, which runs kTailIters rounds unless the range empties first, and a round
+    // consumes one symbol of every run it follows: a bucket cannot need more batches than this (a device fault that
+    // keeps the range alive must not keep the host here for ever).
+    const uint64_t max_batches = 2 * (st.N / kTailIters) + 64; // (rounds too long for the tail consume > 8192 symbols each)
+    for (uint64_t batch = 0;; ++batch) {
+        if (batch > max_batches) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: the rounds of a bucket did not come to an end");
         SX_CHECK(hipMemsetAsync(st.tickets, 0, (kMaxSpec + 2) * sizeof(uint32_t), ctx->stream));
         if (first)
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
@@ -1080,8 +1095,9 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             for (int rep = 0; rep < 2; ++rep) {
                 SX_CHECK(hipMemsetAsync(st.run_len, 0xFF, sizeof(uint32_t), ctx->stream));
                 const uint64_t look = st.N < (uint64_t)kRunProbe ? st.N : (uint64_t)kRunProbe; // (no run is longer than the text)
-                sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, run_probe_kernel, dim3(sx_div_up(look, 16 * kBlock), r[1] - r[0]),
-                          dim3(kBlock), st.T, (const uint32_t *)st.SA, (const uint32_t *)st.ranges, c, st.run_len);
+                sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, run_probe_kernel,
+                          dim3(sx_div_up(look, kRunProbeChunk) < kRunProbeGrid ? sx_div_up(look, kRunProbeChunk) : kRunProbeGrid, r[1] - r[0]),
+                          dim3(kBlock), st.T, (const uint32_t *)st.SA, (const uint32_t *)st.ranges, c, (uint32_t)look, st.run_len);
                 sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, run_fill_kernel<WT>, dim3(4096), dim3(kBlock), st.T, st.SA, st.WN, st.BW,
                           (const uint32_t *)st.ranges, (const uint32_t *)st.cursor[st.par], c, rev, dir, st.cfg,
                           (const uint32_t *)st.run_len);
