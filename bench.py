@@ -49,6 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-tables", action="store_true", help="suffix array only")
     ap.add_argument("--no-direct-sort", action="store_true",
                     help="wide alphabets: LMS sort + induced-sort passes even where the direct sort of all suffixes applies")
+    ap.add_argument("--sort-mode", type=int, default=0,
+                    help="prefix-key sort: 0 choose, 1 LSD passes over all key bits, 2 hybrid (top bits in HBM passes, sub-buckets in LDS)")
     ap.add_argument("--cpu-log2n", type=int, default=int(os.environ.get("STRALG_BENCH_CPU_LOG2N", "25")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last step's results")
@@ -226,6 +228,8 @@ def run_rank(args):
         ctx = stralg_amd.Context(local_rank)
     if args.no_direct_sort:
         ctx.set_no_direct_sort(True)
+    if args.sort_mode:
+        ctx.set_sort_mode(args.sort_mode)
     # host work of a rank (staging copies, page faults of pinned and malloc'd buffers) next to its GPU's PCIe root
     numa_node = ctx.bind_to_numa_node()
     if world > 1:

@@ -55,6 +55,7 @@ enum {
     SX_KC_REMAP,          /* presence bits + table lookup                 remap.c:8-31,102-114  */
     SX_KC_LCP,            /* inverse + LCP                                suffix_array.c:53-85  */
     SX_KC_SEARCH,         /* batched exact BWT search                     bwt.c:164-199         */
+    SX_KC_LOCAL_SORT,     /* hybrid LMS sort: sub-buckets ordered in LDS, ties listed          */
     SX_KC_COUNT
 };
 
@@ -75,6 +76,9 @@ typedef struct sx_build_stats {
     uint32_t induce_rounds;  /* multisplit rounds over both passes */
     uint32_t sort_passes;    /* radix passes, all sorts */
     uint32_t lms_path;       /* 1: prefix-key LMS sort resolved everything, 2: general path, 3: direct sort of all suffixes */
+    uint32_t sort_local;     /* bit 0: the prefix-key sort finished in LDS (hybrid: HBM passes on the top 24 key bits only);
+                                bit 1: some workgroup of it met crowded bins and took stable passes */
+    uint32_t reserved;
     double ms_total;         /* wall time of the last build on the device stream */
 } sx_build_stats;
 
@@ -92,7 +96,10 @@ enum {
     SX_FLAG_FORCE_GENERAL_PATH = 1, /* skip the prefix-key LMS sort: always pieces + names + prefix doubling */
     SX_FLAG_CHAIN_MAX_ENTRIES = 2,  /* induce rounds up to this many entries use the single chained launch */
     SX_FLAG_NO_DIRECT_SORT = 3,     /* wide alphabets: never sort all suffixes by prefix directly, always LMS sort + induction */
-    SX_FLAG_PREFIX_SYMBOLS = 4      /* first attempt of the prefix-key sort takes this many symbols (0: by the text's size) */
+    SX_FLAG_PREFIX_SYMBOLS = 4,     /* first attempt of the prefix-key sort takes this many symbols (0: by the text's size) */
+    SX_FLAG_RADIX_DIGIT_BITS = 5,   /* digit width of the LSD radix passes: 8 (default), 9 or 10 */
+    SX_FLAG_SORT_MODE = 6           /* prefix-key sort: 0 choose, 1 LSD passes only, 2 hybrid (HBM passes on the top bits +
+                                       sub-buckets ordered in LDS) whenever the key shape allows it, whatever the size */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

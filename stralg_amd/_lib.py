@@ -12,7 +12,7 @@ PRODUCT_LIB = os.path.join(_HERE, "libstralg_amd.so")
 
 KC_NAMES = ["classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names", "doubling",
             "induce_gather", "induce_scan", "induce_scatter", "induce_chain", "bwt_gather", "otable", "misc",
-            "fasta", "remap", "lcp", "search"]
+            "fasta", "remap", "lcp", "search", "local_sort"]
 
 
 class KernelStat(C.Structure):
@@ -23,7 +23,8 @@ class BuildStats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_lms", C.c_uint64), ("n_samples", C.c_uint64),
                 ("n_names", C.c_uint64), ("key_bits", C.c_uint32), ("key_slots", C.c_uint32),
                 ("doubling_rounds", C.c_uint32), ("induce_rounds", C.c_uint32),
-                ("sort_passes", C.c_uint32), ("lms_path", C.c_uint32), ("ms_total", C.c_double)]
+                ("sort_passes", C.c_uint32), ("lms_path", C.c_uint32), ("sort_local", C.c_uint32), ("reserved", C.c_uint32),
+                ("ms_total", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -218,6 +218,14 @@ class Context:
         """SX_FLAG_PREFIX_SYMBOLS: the prefix-key sort's first attempt takes this many symbols (0: by the size)."""
         self._check(self.lib.sx_ctx_set_flag(self.h, 4, int(symbols)), "sx_ctx_set_flag")
 
+    def set_radix_digit_bits(self, bits):
+        """SX_FLAG_RADIX_DIGIT_BITS: digit width of the LSD radix passes (8, 9, 10; 0: default)."""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 5, int(bits)), "sx_ctx_set_flag")
+
+    def set_sort_mode(self, mode):
+        """SX_FLAG_SORT_MODE: 0 choose, 1 LSD passes only, 2 hybrid sort wherever the key shape allows it."""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 6, int(mode)), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

@@ -75,6 +75,8 @@ struct sx_ctx {
     int prefix_symbols = 0;          // SX_FLAG_PREFIX_SYMBOLS; 0 = choose by the number of suffixes
     int force_general = 0; // SX_FLAG_FORCE_GENERAL_PATH
     int no_direct = 0;     // SX_FLAG_NO_DIRECT_SORT
+    int radix_digit_bits = 0; // SX_FLAG_RADIX_DIGIT_BITS; 0 = 8
+    int sort_mode = 0;        // SX_FLAG_SORT_MODE
     int prof_on = 0;
     int prof_only = -1; // >= 0: only launches of this kernel class are bracketed with events
     // first launch that the runtime refused (a bad grid, ...): reported by the next sx_sync / sx_readback

@@ -7,7 +7,7 @@
 static const char *kClassNames[SX_KC_COUNT] = {
     "classify", "samples", "keys", "radix_hist", "radix_scatter", "scan", "names",
     "doubling", "induce_gather", "induce_scan", "induce_scatter", "induce_chain", "bwt_gather", "otable", "misc",
-    "fasta", "remap", "lcp", "search",
+    "fasta", "remap", "lcp", "search", "local_sort",
 };
 
 int sx_fail(sx_ctx *ctx, int code, const char *what, const char *file, int line)
@@ -223,6 +223,16 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     }
     if (flag == SX_FLAG_PREFIX_SYMBOLS) {
         ctx->prefix_symbols = value > 0 ? value : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_SORT_MODE) {
+        if (value < 0 || value > 2) return SX_E_ARG;
+        ctx->sort_mode = value;
+        return 0;
+    }
+    if (flag == SX_FLAG_RADIX_DIGIT_BITS) {
+        if (value != 0 && (value < 8 || value > 10)) return SX_E_ARG;
+        ctx->radix_digit_bits = value;
         return 0;
     }
     if (flag == SX_FLAG_CHAIN_MAX_ENTRIES) {

@@ -5,10 +5,13 @@
 // ---- sx_radix.hip
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
                   int begin_bit, int end_bit, int *result_in_b, bool values_are_indices = false,
-                  bool first_digits_ready = false);
-// where the key generator of a sort of n pairs may leave the first pass's digit of every key ((key >> begin_bit) & 255):
-// the first histogram then reads these bytes instead of the keys (first_digits_ready)
-uint8_t *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n);
+                  bool first_digits_ready = false, int digit_bits = 0 /* 8, 9, 10; 0: the context's choice */);
+// where the key generator of a sort of n pairs may leave the first pass's digit of every key
+// ((key >> begin_bit) & (2^digit_bits - 1); one byte each for 8-bit digits, two for wider ones): the first
+// histogram then reads these instead of the keys (first_digits_ready)
+void *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n, int digit_bits = 8);
+// digit width of sorts that do not ask for one (8 unless SX_FLAG_RADIX_DIGIT_BITS says otherwise)
+int sx_sort_digit_bits(const sx_ctx *ctx);
 
 // ---- sx_classify.hip
 constexpr int kClsPerThread = 16;                     // text positions per thread
@@ -68,6 +71,20 @@ size_t sx_lms_prefix_bytes(uint64_t m);
 int sx_bwt_from_seed_windows(sx_ctx *ctx, const uint32_t *seedw, uint64_t N, uint32_t maxc, uint8_t *bwt_out);
 int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t **out,
                           const void **seed_windows, int *resolved, bool all_suffixes = false);
+
+// ---- sx_localsort.hip: the hybrid sort's last step (sub-buckets of equal top key bits ordered in LDS)
+constexpr int kSxHybridTopBits = 24; // key bits that go through HBM passes (three 8-bit passes)
+bool sx_local_sort_applies(uint64_t m, int kbits);
+uint32_t sx_local_sort_tiles(uint64_t m);
+// (kin, vin): m pairs ordered by key bits [kbits - 24, kbits).  Writes the positions in key order to vout, the keys'
+// payload bits (from kbits on) to seedw (optional), the members of groups of equal keys to (apos, ap, ahead)
+// (at most cap), their number to d_total_and_fail[0]; d_total_and_fail[1] <- bit 0 when a sub-bucket did not fit a
+// workgroup (the outputs are then unusable), bit 1 when some workgroup used stable passes (statistics).  tile_*: one u32 per workgroup (sx_local_sort_tiles); stage: m x 8
+// bytes, stage_head: m bytes of scratch.
+int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, uint32_t *vout,
+                  uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
+                  uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
+                  uint32_t *d_total_and_fail);
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);

@@ -19,6 +19,8 @@
 // If too many ties remain (repetitive text) the caller falls back to the
 // general path (pieces + names + prefix doubling, sx_reduce.hip), which is
 // O(n log n) whatever the input.  Either way the order is the unique one.
+#include <math.h>
+
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
@@ -202,7 +204,8 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
                                                                const uint32_t *__restrict__ tile_off, pkey_cfg kc,
                                                                uint32_t kbits, wnd_cfg wcfg,
                                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                               uint8_t *__restrict__ dig0)
+                                                               uint8_t *__restrict__ dig0, uint32_t dig_shift,
+                                                               uint32_t dig_mask)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     __shared__ uint32_t spos[kClsTile / 2 + 1]; // LMS positions are at least two apart
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
         // written once, next read by another kernel: streaming stores (the sort's first pass gained 4 %)
         __builtin_nontemporal_store(key, keys + dst0 + i);
         __builtin_nontemporal_store(p, vals + dst0 + i);
-        // the first radix pass's digit (its histogram reads this byte, not the key): the low 8 key bits, without payload
-        __builtin_nontemporal_store((uint8_t)(kbits >= 8 ? key : key & ((1ull << kbits) - 1ull)), dig0 + dst0 + i);
+        // the first radix pass's digit (its histogram reads this byte, not the key), without payload bits
+        __builtin_nontemporal_store((uint8_t)((uint32_t)(key >> dig_shift) & dig_mask), dig0 + dst0 + i);
     }
 }
 
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
 // the end of the text are ordered correctly and the key of position n is the smallest.
 __global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restrict__ T, uint64_t N, pkey_cfg kc,
                                                           uint32_t kbits, wnd_cfg wcfg, uint64_t *__restrict__ keys,
-                                                          uint8_t *__restrict__ dig0)
+                                                          uint8_t *__restrict__ dig0, uint32_t dig_shift, uint32_t dig_mask)
 {
     const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= N) return;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void all_keys_kernel(const uint8_t *__restr
     // the symbol before the suffix rides in the unsorted key bits (a one-symbol window): after the sort it is the BWT
     if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, (uint32_t)p, wcfg) << kbits;
     keys[p] = key; // (the position is the index: the sort's first pass fills the values in)
-    dig0[p] = (uint8_t)(kbits >= 8 ? key : key & ((1ull << kbits) - 1ull));
+    dig0[p] = (uint8_t)((uint32_t)(key >> dig_shift) & dig_mask);
 }
 
 // The same for keys of at most 12 symbols (every alphabet that qualifies for the direct sort): a thread takes 16
@@ -297,7 +300,7 @@ __device__ __forceinline__ uint64_t key_from_words(const uint32_t (&w)[12], int 
 template <int G>
 __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__restrict__ T, uint64_t N, pkey_cfg kc,
                                                             uint32_t kbits, wnd_cfg wcfg, uint64_t *__restrict__ keys,
-                                                            uint8_t *__restrict__ dig0)
+                                                            uint8_t *__restrict__ dig0, uint32_t dig_shift, uint32_t dig_mask)
 {
     const uint64_t p0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16u;
     if (p0 >= N) return;
@@ -325,9 +328,8 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
             *reinterpret_cast<uint4 *>(keys + p0 + 2 * q) = v;
         }
         uint32_t d[4] = {0, 0, 0, 0}; // the first radix pass's digits of the 16 keys
-        const uint32_t dmask = kbits >= 8 ? 0xFFu : (1u << kbits) - 1u; // (without payload bits when the key is short)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) d[i >> 2] |= ((uint32_t)key[i] & dmask) << (8 * (i & 3));
+        for (int i = 0; i < 16; ++i) d[i >> 2] |= ((uint32_t)(key[i] >> dig_shift) & dig_mask) << (8 * (i & 3)); // (without payload bits)
         uint4 v;
         v.x = d[0], v.y = d[1], v.z = d[2], v.w = d[3];
         *reinterpret_cast<uint4 *>(dig0 + p0) = v;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void all_keys16_kernel(const uint8_t *__res
         for (int i = 0; i < 16; ++i)
             if (p0 + i < N) {
                 keys[p0 + i] = key[i];
-                dig0[p0 + i] = (uint8_t)(kbits >= 8 ? key[i] : key[i] & ((1ull << kbits) - 1ull));
+                dig0[p0 + i] = (uint8_t)((uint32_t)(key[i] >> dig_shift) & dig_mask);
             }
     }
 }
@@ -686,6 +688,7 @@ size_t sx_lms_prefix_bytes(uint64_t m)
     b += 8 * (cap * 4 + a); // apos x2, ap x2, ap_new, agid, order x2
     b += 3 * (cap + a);     // heads
     b += 2 * ((m / 8192 + 2) * 4 + a); // tie counts and offsets per tile of the sorted keys
+    b += 3 * (size_t)(m / 4096 + 2) * 4 + a; // the same, and the owned range's start, per workgroup of the local sort
     return b + 4096;
 }
 
@@ -745,6 +748,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t *d_scalar = am.take<uint32_t>(16);
     const uint32_t tied_tiles = sx_div_up(m, kTiedTile);
     uint32_t *tile_cnt = am.take<uint32_t>(tied_tiles), *tile_pos = am.take<uint32_t>(tied_tiles);
+    const uint32_t ls_tiles = sx_local_sort_tiles(m);
+    uint32_t *tile_lsrt = am.take<uint32_t>(3 * (size_t)ls_tiles); // start, tied members, offset of every local-sort workgroup
     if (!tile_cnt || !tile_pos || !seedw || !ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
         !agid || !ord_a || !ord_b || !head || !head2 || !head_new || !d_scalar)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
@@ -754,7 +759,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t *tile_lms = ti.tile_u32, *tile_off = all_suffixes ? nullptr : ti.tile_u32 + 4 * (size_t)ti.ntiles;
     if (!all_suffixes) SX_TRY((device_scan<OpAdd>(ctx, ti.ntiles, InU32{tile_lms}, OutExclusive{tile_off}, nullptr)));
 
-    const uint64_t *ks = nullptr;
+    const uint64_t *ks = nullptr; // sorted keys (not kept by the hybrid sort)
     uint32_t *vs = nullptr;
     uint32_t A = 0;
     int kbits = 64;
@@ -781,12 +786,31 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         }
         wcfg.CW = embed ? wchars : 0;
         kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
-        uint8_t *dig0 = sx_sort_digit_buffer(ctx, m); // the key kernels leave the first pass's digits there
+        // the key kernels leave the first pass's digits there (one byte each: 8-bit digits only)
+        const int sort_db = sx_sort_digit_bits(ctx);
+        uint8_t *dig0 = (uint8_t *)sx_sort_digit_buffer(ctx, m, sort_db);
         if (!dig0) return sx_fail_msg(ctx, SX_E_NOMEM, "sort workspace");
+        // Hybrid sort (sx_localsort.hip): only the top 24 key bits go through HBM passes, the sub-buckets they leave are
+        // ordered in LDS.  It needs sub-buckets that fit a workgroup: a prefix of 24 / log2(base) symbols must not be too
+        // frequent.  Judged here from the text's most frequent symbol (a run of it is the most frequent prefix of a text
+        // without repeats); repeats show when the kernel finds a sub-bucket that does not fit, and LSD passes finish the job.
+        bool hybrid = ctx->sort_mode != 1 && sort_db == 8 && sx_local_sort_applies(m, kbits) && tile_lsrt != nullptr;
+        if (hybrid && ctx->sort_mode == 0) {
+            double pmax = 0.0;
+            const double n_sym = (double)ti.N - 1.0;
+            for (int c = 1; c < 256 && n_sym > 0; ++c)
+                if ((double)ti.h_all[c] / n_sym > pmax) pmax = (double)ti.h_all[c] / n_sym;
+            double expect = (double)m; // copies of the most frequent prefix the top bits tell apart
+            const double syms = (double)kSxHybridTopBits / log2((double)base);
+            for (double i = 0; i < syms; i += 1.0) expect *= pmax;
+            if (m < (1u << 22) || expect > 512.0) hybrid = false;
+        }
+        const uint32_t dig_shift = hybrid ? (uint32_t)(kbits - kSxHybridTopBits) : 0u;
+        const uint32_t dig_mask = kbits - (int)dig_shift >= 8 ? 0xFFu : (1u << (kbits - (int)dig_shift)) - 1u;
         if (all_suffixes && C <= 12) {
             const pkey_cfg kc = pkey_make(base, C);
             const dim3 grid16(sx_div_up(m, kBlock * 16));
-#define SX_KEYS16(G) sx_launch(ctx, SX_KC_KEYS, m * 10, all_keys16_kernel<G>, grid16, block, ti.T, m, kc, (uint32_t)kbits, wcfg, ka, dig0)
+#define SX_KEYS16(G) sx_launch(ctx, SX_KC_KEYS, m * 10, all_keys16_kernel<G>, grid16, block, ti.T, m, kc, (uint32_t)kbits, wcfg, ka, dig0, dig_shift, dig_mask)
             switch (kc.G) {
             case 10: SX_KEYS16(10); break;
             case 6: SX_KEYS16(6); break;
@@ -796,7 +820,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 #undef SX_KEYS16
         } else if (all_suffixes)
             sx_launch(ctx, SX_KC_KEYS, m * 13, all_keys_kernel, dim3(sx_div_up(m, kBlock)), block, ti.T, m, pkey_make(base, C),
-                      (uint32_t)kbits, wcfg, ka, dig0);
+                      (uint32_t)kbits, wcfg, ka, dig0, dig_shift, dig_mask);
         else
         {
             const pkey_cfg kc = pkey_make(base, C);
@@ -805,7 +829,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             const bool dna = kc.dot && (wcfg.B == 2 || wcfg.B == 3) && kbits >= 8;
 #define SX_TILE_KEYS(CS, WS, BS)                                                                                       \
     sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel<CS, WS, BS>, dim3(ti.ntiles), block,     \
-              ti.T, (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0)
+              ti.T, (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0, dig_shift, dig_mask)
             const uint32_t shape = dna ? (C * 16 + wcfg.CW) * 4 + wcfg.B : 0u;
             switch (shape) {
             // base 5 (A C G T): 64 Mi ... 4 Gi symbols
@@ -824,11 +848,41 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 #undef SX_TILE_KEYS
         }
         int in_b = 0;
-        SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b, all_suffixes, true)); // (all suffixes: value = index)
-        ks = in_b ? kb : ka;
-        vs = in_b ? vb : va;
+        ctx->stats.sort_local = 0;
+        bool listed = false; // the members of groups of equal keys are in (apos, ap, head), A of them
+        if (hybrid) {
+            // three stable passes on the top 24 bits, then the sub-buckets in LDS: positions, windows and ties in one go
+            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - kSxHybridTopBits, kbits, &in_b, all_suffixes, true, 8));
+            const uint64_t *kin = in_b ? kb : ka;
+            const uint32_t *vin = in_b ? vb : va;
+            uint32_t *vo = in_b ? va : vb;
+            SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
+                                 tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar));
+            uint32_t res[2] = {0, 0};
+            SX_TRY(sx_readback(ctx, d_scalar, 2, res));
+            if (!(res[1] & 1u)) {
+                A = res[0];
+                vs = vo;
+                ks = nullptr; // (the sorted keys are not written by this path; nothing below reads them)
+                listed = true;
+                ctx->stats.sort_local = 1u | (res[1] & 2u); // (bit 1: some workgroup ordered its pairs by stable passes)
+            } else {
+                // a sub-bucket too long for a workgroup (a repeated prefix): plain LSD passes over all key bits from here
+                uint64_t *k0 = in_b ? kb : ka, *k1 = in_b ? ka : kb;
+                uint32_t *v0 = in_b ? vb : va, *v1 = in_b ? va : vb;
+                int f = 0;
+                SX_TRY(sx_sort_pairs(ctx, k0, v0, k1, v1, m, 0, kbits, &f, false, false, 8));
+                ks = f ? k1 : k0;
+                vs = f ? v1 : v0;
+                in_b = (ks == kb) ? 1 : 0;
+            }
+        } else {
+            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, 0, kbits, &in_b, all_suffixes, sort_db == 8, sort_db)); // (all suffixes: value = index)
+            ks = in_b ? kb : ka;
+            vs = in_b ? vb : va;
+        }
         // members of groups with equal keys
-        {
+        if (!listed) {
             const uint32_t tiles = sx_div_up(m, kTiedTile);
             // staging in the sort's spare buffers: 8 bytes per slot in the other key array, heads in the other value array
             uint2 *stage = (uint2 *)(in_b ? ka : kb);

@@ -1,0 +1,437 @@
+// sx_localsort.hip -- the last step of the hybrid sort of the LMS suffixes' prefix keys.
+//
+// Role of stralg/sa_is.c:295-336 (the order reduce_SA reads the LMS substrings in) for the fast
+// path of sx_lmssort.hip.  An LSD radix sort of (40-bit key, window, position) pairs moves
+// 24 bytes per pair and pass through HBM, five times.  Here only the key's top kTopBits go
+// through HBM passes (three 8-bit passes of sx_radix.hip, stable, lowest digit first): after
+// them the pairs are ordered by their top 24 bits, i.e. they sit in *sub-buckets* of equal top
+// bits -- a few hundred pairs each on a text whose prefixes are spread out -- and the
+// remaining low bits only have to be ordered inside each sub-bucket.  That is done by this
+// kernel in LDS: a workgroup takes the whole sub-buckets that start in its span of the
+// array, orders them by (sub-bucket, low bits) with 8-bit LSD passes that never leave the CU,
+// and writes what the rest of the build needs: the positions in suffix order, the symbol
+// windows that rode in the keys' spare bits, and the members of groups of equal keys (the
+// ties the refinement rounds work on) -- the sorted keys themselves are never written again.
+// Per pair: 12 B read, 8 B written, against 3 x 25 B for the passes it replaces plus the
+// 13 B of the pass that looked for equal neighbours.
+//
+// A sub-bucket that does not fit a workgroup's LDS (a text with many copies of one 10-symbol
+// prefix) makes the kernel raise a flag; the caller then finishes with plain LSD passes.
+#include "sx_common.hpp"
+#include "sx_device.hpp"
+#include "sx_scan.hpp"
+#include "sx_internal.hpp"
+
+namespace sx {
+
+constexpr int kLsThreads = 512, kLsWaves = kLsThreads / kWave, kLsItems = 12;
+constexpr int kLsCap = kLsThreads * kLsItems; // pairs a workgroup can hold: 6144 (72 KiB of LDS, two workgroups a CU)
+constexpr int kLsSpan = 4096;                 // a workgroup owns the sub-buckets that start in its span of the array
+constexpr int kLsFirstItems = 10;             // loaded at once: span + 1024; the rest only when the last sub-bucket is longer
+constexpr int kLsWords = kLsCap / 32;
+constexpr int kLsBins = 8192;  // bins of the counting pass: 16 KiB of packed 16-bit counters in the (then unused) key image
+constexpr int kLsMaxBin = 16;  // a bin with more pairs than this: stable passes instead (equal keys crowd one bin)
+static_assert(kLsBins / 2 % kLsThreads == 0 && (kLsBins / 2 + 1) * 8 <= kLsCap * 8, "counter words per thread; both counter sets fit the key image");
+static_assert(kLsThreads * kLsFirstItems >= kLsSpan && kLsFirstItems <= kLsItems, "first load covers the span");
+
+// One workgroup: local indices i = global index - g0, g0 = blockIdx.x * kLsSpan.
+//   s = first sub-bucket start at i >= 0, e = first sub-bucket start (or the end of the array) at i >= kLsSpan;
+//   the workgroup owns [s, e).  Every sub-bucket starts in exactly one span, so the owned ranges tile the array.
+// kin/vin: pairs ordered by (key & kmask) >> L; the key bits from kbits on are payload (the symbol window).
+__global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
+    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
+    uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
+    uint32_t *__restrict__ tile_cnt, uint2 *__restrict__ stage, uint8_t *__restrict__ stage_head,
+    uint32_t *__restrict__ fail)
+{
+    __shared__ uint64_t K[kLsCap]; // keys; then (payload << 32 | sub-bucket rank << L | low bits); per-wave counters during a ranking
+    __shared__ uint32_t V[kLsCap]; // positions
+    __shared__ uint32_t bnd[kLsWords], bpre[kLsWords]; // sub-bucket starts as bits; starts before each word
+    __shared__ uint32_t s_first, s_end, s_scan[kLsWaves], s_kprev[2], s_max;
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t g0 = (uint64_t)blockIdx.x * kLsSpan;
+    const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+    const uint32_t avail = m - g0 < (uint64_t)kLsCap ? (uint32_t)(m - g0) : (uint32_t)kLsCap; // pairs in reach
+    const bool end_in_reach = g0 + avail == m;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+    if (t == 0) {
+        s_first = kNone;
+        s_end = kNone;
+        const uint64_t kp = g0 ? kin[g0 - 1] : 0ull;
+        s_kprev[0] = (uint32_t)kp, s_kprev[1] = (uint32_t)(kp >> 32);
+    }
+    for (int i = t; i < kLsWords; i += kLsThreads) bnd[i] = 0;
+    // ---- load the keys in reach (index order: coalesced), the part behind span + 1024 only if it is needed ----------
+    uint32_t loaded = avail < (uint32_t)(kLsThreads * kLsFirstItems) ? avail : (uint32_t)(kLsThreads * kLsFirstItems);
+    {
+        // (all loads of a thread in flight together: keys and positions of the whole reach, not only of the range the
+        // workgroup turns out to own -- a loop over that range would wait for every load before issuing the next)
+        uint64_t kk[kLsFirstItems];
+        uint32_t vv[kLsFirstItems];
+#pragma unroll
+        for (int k = 0; k < kLsFirstItems; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
+            kk[k] = i < loaded ? __builtin_nontemporal_load(kin + g0 + i) : 0ull;
+            vv[k] = i < loaded ? __builtin_nontemporal_load(vin + g0 + i) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kLsFirstItems; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
+            if (i < loaded) K[i] = kk[k], V[i] = vv[k];
+        }
+    }
+    __syncthreads();
+    const uint64_t kprev = pack64(s_kprev[0], s_kprev[1]);
+    uint32_t from = 0;
+    for (int part = 0; part < 2; ++part) { // uniform
+        // sub-bucket starts among the keys loaded in this part
+        for (uint32_t i = from + (uint32_t)t; i < loaded; i += kLsThreads) {
+            const uint64_t idc = (K[i] & kmask) >> L;
+            const bool start = i == 0 ? (g0 == 0 || ((kprev & kmask) >> L) != idc) : ((K[i - 1] & kmask) >> L) != idc;
+            if (start) {
+                atomicOr(&bnd[i >> 5], 1u << (i & 31u));
+                if (i < (uint32_t)kLsSpan) atomicMin(&s_first, i);
+                else atomicMin(&s_end, i);
+            }
+        }
+        __syncthreads();
+        if (part == 1 || s_end != kNone || loaded == avail) break; // uniform
+        from = loaded;
+#pragma unroll
+        for (int k = kLsFirstItems; k < kLsItems; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
+            if (i < avail) K[i] = kin[g0 + i], V[i] = vin[g0 + i];
+        }
+        loaded = avail;
+        __syncthreads();
+    }
+    uint32_t s = s_first, e = s_end;
+    if (e == kNone && end_in_reach) e = avail; // (a last workgroup whose reach ends inside the span)
+    if (s == kNone || s >= e) { // no sub-bucket starts in the span: nothing of its own (uniform)
+        if (t == 0) tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
+        return;
+    }
+    if (e == kNone) { // the sub-bucket across the span's end is longer than the reach (uniform)
+        if (t == 0) {
+            atomicOr(fail, 1u);
+            tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
+        }
+        return;
+    }
+    const uint32_t n_loc = e - s;
+    // ---- sub-bucket rank of every owned pair: starts in (s, i], from the bit array ---------------------------------
+    if (w == 0) { // starts before each word: one wave scans the kLsWords word counts
+        uint32_t run = 0;
+        for (int c0 = 0; c0 < kLsWords; c0 += kWave) {
+            const int i = c0 + lane;
+            const uint32_t cnt = i < kLsWords ? (uint32_t)__popc(bnd[i]) : 0u;
+            const uint32_t inc = wave_inclusive_scan<OpAdd>(cnt);
+            if (i < kLsWords) bpre[i] = run + inc - cnt;
+            run += __shfl(inc, kWave - 1, kWave);
+        }
+    }
+    __syncthreads();
+    const uint32_t starts_to_s = bpre[s >> 5] + (uint32_t)__popc(bnd[s >> 5] & ((2u << (s & 31u)) - 1u)); // incl. the one at s
+    const uint32_t last = e - 1u;
+    const uint32_t nseg = bpre[last >> 5] + (uint32_t)__popc(bnd[last >> 5] & ((2u << (last & 31u)) - 1u)) - starts_to_s + 1u;
+    // order by (rank, low L bits): that many bits, 8 a pass
+    uint32_t sort_bits = L;
+    for (uint32_t v = nseg - 1u; v; v >>= 1) ++sort_bits;
+    const uint32_t npass = sort_bits ? (sort_bits + 7u) / 8u : 0u;
+    const uint64_t lowmask = (1ull << L) - 1ull;
+    // items: K[i] <- payload << 32 | rank << L | low bits (rank < 2^13, L <= 19: 32 bits), V[i] <- position
+#pragma unroll
+    for (int k = 0; k < kLsItems; ++k) {
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
+        if (i >= s && i < e) {
+            const uint64_t key = K[i];
+            const uint32_t rank = bpre[i >> 5] + (uint32_t)__popc(bnd[i >> 5] & ((2u << (i & 31u)) - 1u)) - starts_to_s;
+            K[i] = ((key >> kbits) << 32) | ((uint64_t)rank << L) | (key & lowmask);
+        }
+    }
+    __syncthreads();
+    // ---- the owned pairs into registers, striped: q = wave * 768 + k * 64 + lane --------------------------------------
+    const uint32_t q0 = (uint32_t)w * (kWave * kLsItems) + (uint32_t)lane;
+    uint64_t key[kLsItems];
+    uint32_t val[kLsItems];
+#pragma unroll
+    for (int k = 0; k < kLsItems; ++k) {
+        const uint32_t q = q0 + (uint32_t)k * kWave;
+        key[k] = q < n_loc ? K[s + q] : 0ull;
+        val[k] = q < n_loc ? V[s + q] : 0u;
+    }
+    __syncthreads(); // K and V are free until the pairs are written back
+    // ---- one counting pass + insertion inside the bins ---------------------------------------------------------------
+    // The sort field's top bits (sub-bucket rank, then as many of the low bits as keep the number of bins within
+    // kLsBins) spread the pairs over ~8192 bins: on a text whose prefixes are spread out a bin gets less than one pair
+    // on average.  So the pairs are dropped into their bins in any order (LDS atomics: a count, a scan, a cursor each)
+    // and every pair then finds its place among the one or two others of its bin by looking at their sort fields
+    // (all 12 pairs of a thread step through their bins together, so that the LDS reads of a step overlap).  About a
+    // third of the instructions of three stable 8-bit passes (the kernel is bound by instruction issue).  A
+    // workgroup that finds a crowded bin (equal keys: the ties of a repeat) takes the stable passes below instead.
+    uint32_t bb = 0;
+    while (bb < L && ((uint64_t)nseg << (bb + 1u)) <= (uint64_t)kLsBins) ++bb;
+    const uint32_t nb = nseg << bb, bshift = L - bb, nwords = nb / 2u + 1u; // (one bin more: the end of the last one)
+    uint32_t *cw = reinterpret_cast<uint32_t *>(K);  // first slot of every bin, two 16-bit fields a word (a workgroup holds < 2^16 pairs)
+    uint32_t *cur = cw + (kLsBins / 2 + 1);           // the same, moving: the cursors
+    uint32_t *R = V;                                  // the sort fields in bin order
+    bool counted = nb <= (uint32_t)kLsBins; // (uniform; false only with more sub-buckets than bins)
+    if (counted) {
+        for (uint32_t i = (uint32_t)t; i < nwords; i += kLsThreads) cw[i] = 0;
+        if (t == 0) s_max = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kLsItems; ++k) {
+            const uint32_t q = q0 + (uint32_t)k * kWave;
+            if (q < n_loc) {
+                const uint32_t bin = (uint32_t)key[k] >> bshift;
+                atomicAdd(&cw[bin >> 1], 1u << (16u * (bin & 1u)));
+            }
+        }
+        __syncthreads();
+        { // counts -> first slots, 16 bins a thread; the fullest bin
+            constexpr int kPer = kLsBins / 2 / kLsThreads;
+            uint32_t wv[kPer], sum = 0, mx = 0;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const uint32_t idx = (uint32_t)t * kPer + (uint32_t)j;
+                wv[j] = idx < nwords ? cw[idx] : 0u;
+                const uint32_t lo = wv[j] & 0xFFFFu, hi = wv[j] >> 16;
+                mx = mx > lo ? mx : lo;
+                mx = mx > hi ? mx : hi;
+                sum += lo + hi;
+            }
+            const uint32_t inc = wave_inclusive_scan<OpAdd>(sum);
+            if (lane == kWave - 1) s_scan[w] = inc;
+            if (mx > (uint32_t)kLsMaxBin) atomicMax(&s_max, mx);
+            __syncthreads();
+            uint32_t run = inc - sum;
+            for (int ww = 0; ww < w; ++ww) run += s_scan[ww];
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const uint32_t idx = (uint32_t)t * kPer + (uint32_t)j;
+                const uint32_t lo = wv[j] & 0xFFFFu, hi = wv[j] >> 16;
+                const uint32_t packed = run | ((run + lo) << 16);
+                if (idx < nwords) cw[idx] = packed, cur[idx] = packed;
+                run += lo + hi;
+            }
+            if (t == kLsThreads - 1 && (uint32_t)kLsThreads * kPer == nwords - 1u) cw[nwords - 1u] = run; // (nb == kLsBins: the end word)
+        }
+        __syncthreads();
+        counted = s_max <= (uint32_t)kLsMaxBin; // uniform
+    }
+    if (counted) {
+        uint32_t slot[kLsItems], span[kLsItems]; // where the pair was dropped; its bin: first slot | pairs << 16
+#pragma unroll
+        for (int k = 0; k < kLsItems; ++k) {
+            const uint32_t q = q0 + (uint32_t)k * kWave;
+            slot[k] = 0, span[k] = 0;
+            if (q < n_loc) {
+                const uint32_t bin = (uint32_t)key[k] >> bshift, sh = 16u * (bin & 1u);
+                const uint32_t first = (cw[bin >> 1] >> sh) & 0xFFFFu;
+                const uint32_t next = (cw[(bin + 1u) >> 1] >> (16u * ((bin + 1u) & 1u))) & 0xFFFFu;
+                span[k] = first | ((next - first) << 16);
+                slot[k] = (atomicAdd(&cur[bin >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kLsItems; ++k) {
+            const uint32_t q = q0 + (uint32_t)k * kWave;
+            if (q < n_loc) R[slot[k]] = (uint32_t)key[k];
+        }
+        __syncthreads();
+        // a pair's final slot: first slot of its bin + the pairs of the bin that sort before it (equal fields: by slot)
+        uint32_t fin[kLsItems];
+#pragma unroll
+        for (int k = 0; k < kLsItems; ++k) fin[k] = span[k] & 0xFFFFu;
+        for (uint32_t step = 0; step < (uint32_t)kLsMaxBin; ++step) {
+            bool more = false;
+#pragma unroll
+            for (int k = 0; k < kLsItems; ++k) {
+                const uint32_t len = span[k] >> 16;
+                if (step < len) {
+                    const uint32_t j = (span[k] & 0xFFFFu) + step, r2 = R[j], rel = (uint32_t)key[k];
+                    fin[k] += (r2 < rel || (r2 == rel && j < slot[k])) ? 1u : 0u;
+                    more = more || step + 1u < len;
+                }
+            }
+            if (!__any(more ? 1 : 0)) break;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kLsItems; ++k) {
+            const uint32_t q = q0 + (uint32_t)k * kWave;
+            if (q < n_loc) K[fin[k]] = key[k], V[fin[k]] = val[k];
+        }
+        __syncthreads();
+    } else {
+        // ---- stable LSD passes inside the CU, 8 bits each (any distribution of the keys) ----------------------------
+        uint32_t *wcount = reinterpret_cast<uint32_t *>(K); // kLsWaves x 256 counters: the key image is dead while the pairs are in registers
+        if (t == 0) atomicOr(fail, 2u); // (statistics: some workgroup took the stable passes)
+        for (uint32_t pass = 0; pass < npass; ++pass) { // uniform
+            uint32_t lpos[kLsItems];
+            if (pass > 0) {
+#pragma unroll
+                for (int k = 0; k < kLsItems; ++k) {
+                    const uint32_t q = q0 + (uint32_t)k * kWave;
+                    key[k] = q < n_loc ? K[q] : 0ull;
+                    val[k] = q < n_loc ? V[q] : 0u;
+                }
+            }
+            __syncthreads();
+            for (int i = t; i < kLsWaves * 256; i += kLsThreads) wcount[i] = 0;
+            __syncthreads();
+            const uint32_t shift = 8u * pass;
+#pragma unroll
+            for (int k = 0; k < kLsItems; ++k) {
+                const uint32_t q = q0 + (uint32_t)k * kWave;
+                const uint32_t d = ((uint32_t)key[k] >> shift) & 0xFFu;
+                lpos[k] = wave_rank_inorder<8, false>(d, q < n_loc, wcount + w * 256) | (d << 16);
+            }
+            __syncthreads();
+            {
+                uint32_t tot = 0;
+                if (t < 256) {
+#pragma unroll
+                    for (int ww = 0; ww < kLsWaves; ++ww) {
+                        const uint32_t x = wcount[ww * 256 + t];
+                        wcount[ww * 256 + t] = tot;
+                        tot += x;
+                    }
+                }
+                const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
+                if (lane == kWave - 1) s_scan[w] = inc;
+                __syncthreads();
+                uint32_t base = 0;
+                for (int ww = 0; ww < w; ++ww) base += s_scan[ww];
+                const uint32_t ex = base + inc - tot;
+                if (t < 256) {
+#pragma unroll
+                    for (int ww = 0; ww < kLsWaves; ++ww) wcount[ww * 256 + t] += ex;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kLsItems; ++k) lpos[k] = (lpos[k] & 0xFFFFu) + wcount[w * 256 + (lpos[k] >> 16)];
+            __syncthreads(); // the counters are part of the key image
+#pragma unroll
+            for (int k = 0; k < kLsItems; ++k) {
+                const uint32_t q = q0 + (uint32_t)k * kWave;
+                if (q < n_loc) K[lpos[k]] = key[k], V[lpos[k]] = val[k];
+            }
+            __syncthreads();
+        }
+        if (npass == 0) { // (a single pair, or all sort fields empty: back as they came)
+#pragma unroll
+            for (int k = 0; k < kLsItems; ++k) {
+                const uint32_t q = q0 + (uint32_t)k * kWave;
+                if (q < n_loc) K[q] = key[k], V[q] = val[k];
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t base_i = 0;
+    // ---- out: positions, windows, and the members of groups of equal keys (compacted in order) ---------------------
+    const uint64_t gs = g0 + s;
+    uint32_t tied_mask = 0, head_mask = 0, wave_total = 0; // bit k: pair k of this lane is tied / opens its group
+    uint32_t pos[kLsItems];
+#pragma unroll
+    for (int k = 0; k < kLsItems; ++k) {
+        const uint32_t q = q0 + (uint32_t)k * kWave;
+        bool tied = false, head = false;
+        pos[k] = 0;
+        if (q < n_loc) {
+            const uint64_t it = K[base_i + q];
+            const uint32_t rel = (uint32_t)it;
+            pos[k] = V[base_i + q];
+            const bool eq_prev = q > 0 && (uint32_t)K[base_i + q - 1] == rel;
+            const bool eq_next = q + 1 < n_loc && (uint32_t)K[base_i + q + 1] == rel;
+            tied = eq_prev || eq_next;
+            head = !eq_prev;
+            vout[gs + q] = pos[k];
+            if (seedw) seedw[gs + q] = (uint32_t)(it >> 32);
+        }
+        if (tied) tied_mask |= 1u << k;
+        if (head) head_mask |= 1u << k;
+        wave_total += (uint32_t)__popcll(__ballot(tied ? 1 : 0));
+    }
+    if (lane == 0) s_scan[w] = wave_total;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < kLsWaves; ++ww) {
+        const uint32_t x = s_scan[ww];
+        if (ww < w) wave_base += x;
+        total += x;
+    }
+    if (t == 0) tile_start[blockIdx.x] = (uint32_t)gs, tile_cnt[blockIdx.x] = total;
+    if (total) { // uniform
+        uint32_t run = wave_base;
+#pragma unroll
+        for (int k = 0; k < kLsItems; ++k) {
+            const bool tied = (tied_mask >> k) & 1u;
+            const uint64_t bal = __ballot(tied ? 1 : 0);
+            if (tied) {
+                const uint32_t q = q0 + (uint32_t)k * kWave;
+                const uint64_t at = gs + run + (uint32_t)__popcll(bal & lanemask_lt());
+                uint2 ent;
+                ent.x = (uint32_t)(gs + q), ent.y = pos[k];
+                stage[at] = ent;
+                stage_head[at] = (uint8_t)((head_mask >> k) & 1u);
+            }
+            run += (uint32_t)__popcll(bal);
+        }
+    }
+}
+
+// every workgroup's tied members -> their place in the global list (the offsets are a scan of tile_cnt)
+__global__ __launch_bounds__(kBlock) void local_tied_gather_kernel(const uint32_t *__restrict__ tile_start,
+                                                                   const uint32_t *__restrict__ tile_cnt,
+                                                                   const uint32_t *__restrict__ tile_off,
+                                                                   const uint2 *__restrict__ stage,
+                                                                   const uint8_t *__restrict__ stage_head,
+                                                                   uint32_t *__restrict__ apos, uint32_t *__restrict__ ap,
+                                                                   uint8_t *__restrict__ ahead, uint32_t cap)
+{
+    const uint32_t tile = blockIdx.x, cnt = tile_cnt[tile], off = tile_off[tile];
+    const uint64_t start = tile_start[tile];
+    for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
+        const uint32_t slot = off + i;
+        if (slot >= cap) break;
+        const uint2 ent = stage[start + i];
+        apos[slot] = ent.x;
+        ap[slot] = ent.y;
+        ahead[slot] = stage_head[start + i];
+    }
+}
+
+} // namespace sx
+
+using namespace sx;
+
+uint32_t sx_local_sort_tiles(uint64_t m) { return sx_div_up(m, kLsSpan); }
+
+bool sx_local_sort_applies(uint64_t m, int kbits)
+{
+    // the top kSxHybridTopBits go through HBM passes, the low L = kbits - 24 bits (with up to 13 bits of sub-bucket rank)
+    // must fit the 32-bit sort field of an LDS item, the payload the other 32
+    return m >= 1 && kbits >= 32 && kbits - kSxHybridTopBits <= 19;
+}
+
+int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, uint32_t *vout,
+                  uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
+                  uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
+                  uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used */)
+{
+    const uint32_t tiles = sx_local_sort_tiles(m);
+    const uint32_t L = (uint32_t)(kbits - kSxHybridTopBits);
+    SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, sizeof(uint32_t), ctx->stream));
+    sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
+              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1);
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_cnt}, OutExclusive{tile_off}, d_total_and_fail, SX_KC_NAMES, 0)));
+    sx_launch(ctx, SX_KC_NAMES, 0, local_tied_gather_kernel, dim3(tiles), dim3(kBlock), (const uint32_t *)tile_start,
+              (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, (const uint2 *)stage, (const uint8_t *)stage_head, apos, ap,
+              ahead, cap);
+    return 0;
+}

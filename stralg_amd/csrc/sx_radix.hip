@@ -41,12 +41,25 @@ constexpr int kRadixItems = SX_RADIX_ITEMS;
 constexpr int kRT = SX_RADIX_THREADS, kRW = kRT / kWave;
 constexpr int kRadixTile = kRT * kRadixItems;
 
+// Digit width of a pass: 8 bits (256 digits: the default), 9 or 10.  Wider digits mean fewer passes over the
+// pairs (40 key bits: 4 passes of 10 instead of 5 of 8) and shorter runs per (tile, digit): 8192 pairs over 1024
+// digits leave 64-byte key runs, which only stay whole cache lines because consecutive tiles are handled by the
+// same XCD at about the same time (see the tile order in the scatter kernel).
+template <int DB> struct radix_digits {
+    static_assert(DB >= 8 && DB <= 10, "digit width");
+    static constexpr int ND = 1 << DB;
+};
+template <int DB> struct radix_dig_type { typedef uint16_t type; };
+template <> struct radix_dig_type<8> { typedef uint8_t type; };
+
+template <int DB>
 __global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
                                                             int shift, uint32_t mask,
                                                             uint32_t *__restrict__ hist, uint32_t ntiles)
 {
-    __shared__ uint32_t h[256];
-    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    constexpr int ND = 1 << DB;
+    __shared__ uint32_t h[ND];
+    for (int i = (int)threadIdx.x; i < ND; i += kRT) h[i] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile;
 #pragma unroll
@@ -55,37 +68,48 @@ __global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restr
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 256) hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+    for (int i = (int)threadIdx.x; i < ND; i += kRT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
 }
 
-// The same from the digit bytes the previous pass's scatter wrote next to its output (one byte per key, in the
-// order of that output): an eighth of the key array's traffic.
-__global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const uint8_t *__restrict__ dig, uint64_t n,
-                                                                uint32_t *__restrict__ hist)
+// The same from the digits the previous pass's scatter wrote next to its output (one byte per key for 8-bit
+// digits, two for wider ones, in the order of that output): an eighth / a quarter of the key array's traffic.
+template <int DB>
+__global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const typename radix_dig_type<DB>::type *__restrict__ dig,
+                                                                uint64_t n, uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t h[256];
-    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    constexpr int ND = 1 << DB;
+    __shared__ uint32_t h[ND];
+    for (int i = (int)threadIdx.x; i < ND; i += kRT) h[i] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)threadIdx.x * kRadixItems;
-    static_assert(kRadixItems == 16, "one 16-byte load per thread");
+    static_assert(kRadixItems == 16, "16 digits per thread: one or two 16-byte loads");
     if (base + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (DB == 8) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+            for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+        } else {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(dig + base), v1 = *reinterpret_cast<const uint4 *>(dig + base + 8);
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 1] >> (16 * (k & 1))) & (uint32_t)(ND - 1)], 1u);
+        }
     } else {
-        for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[dig[i]], 1u);
+        for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 256) hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+    for (int i = (int)threadIdx.x; i < ND; i += kRT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
 }
 
 constexpr uint32_t kRadixChunk = 256; // tiles per chunk of the column sums
 constexpr int kColBatch = 16;         // independent loads in flight per thread
 
+// The three table kernels run with one thread per digit (ND threads a workgroup).
 // column sums of one chunk of tiles: sums[chunk][digit]
-__global__ __launch_bounds__(kBlock) void radix_colsum_kernel(const uint32_t *__restrict__ hist, uint32_t ntiles,
-                                                              uint32_t *__restrict__ sums)
+template <int ND>
+__global__ __launch_bounds__(ND) void radix_colsum_kernel(const uint32_t *__restrict__ hist, uint32_t ntiles,
+                                                          uint32_t *__restrict__ sums)
 {
     const uint32_t t0 = blockIdx.x * kRadixChunk;
     const uint32_t t1 = t0 + kRadixChunk < ntiles ? t0 + kRadixChunk : ntiles;
@@ -93,48 +117,55 @@ __global__ __launch_bounds__(kBlock) void radix_colsum_kernel(const uint32_t *__
     for (uint32_t tb = t0; tb < t1; tb += kColBatch) {
         uint32_t x[kColBatch];
 #pragma unroll
-        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + threadIdx.x] : 0u;
+        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * ND + threadIdx.x] : 0u;
 #pragma unroll
         for (int i = 0; i < kColBatch; ++i) s += x[i];
     }
-    sums[(uint64_t)blockIdx.x * 256 + threadIdx.x] = s;
+    sums[(uint64_t)blockIdx.x * ND + threadIdx.x] = s;
 }
 
 // one workgroup: sums[chunk][digit] <- entries of the digit in earlier chunks; digit_base[digit] <- keys with a smaller digit
-__global__ __launch_bounds__(kBlock) void radix_bases_kernel(uint32_t *__restrict__ sums, uint32_t nchunks,
-                                                             uint32_t *__restrict__ digit_base)
+template <int ND>
+__global__ __launch_bounds__(ND) void radix_bases_kernel(uint32_t *__restrict__ sums, uint32_t nchunks,
+                                                         uint32_t *__restrict__ digit_base)
 {
-    __shared__ uint32_t lds[kWavesPerBlock];
+    __shared__ uint32_t lds[ND / kWave];
     uint32_t run = 0;
     for (uint32_t cb = 0; cb < nchunks; cb += kColBatch) {
         uint32_t x[kColBatch];
 #pragma unroll
-        for (int i = 0; i < kColBatch; ++i) x[i] = cb + i < nchunks ? sums[(uint64_t)(cb + i) * 256 + threadIdx.x] : 0u;
+        for (int i = 0; i < kColBatch; ++i) x[i] = cb + i < nchunks ? sums[(uint64_t)(cb + i) * ND + threadIdx.x] : 0u;
 #pragma unroll
         for (int i = 0; i < kColBatch; ++i) {
-            if (cb + i < nchunks) sums[(uint64_t)(cb + i) * 256 + threadIdx.x] = run;
+            if (cb + i < nchunks) sums[(uint64_t)(cb + i) * ND + threadIdx.x] = run;
             run += x[i];
         }
     }
-    uint32_t tot;
-    digit_base[threadIdx.x] = block_exclusive_scan<OpAdd>(run, lds, tot);
+    // exclusive prefix over the ND digits (one per thread)
+    const uint32_t inc = wave_inclusive_scan<OpAdd>(run);
+    if (lane_id() == kWave - 1) lds[wave_id()] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < wave_id(); ++i) base += lds[i];
+    digit_base[threadIdx.x] = base + inc - run;
 }
 
 // hist[tile][digit] <- first output index of the tile's keys with that digit
-__global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restrict__ hist, uint32_t ntiles,
-                                                             const uint32_t *__restrict__ sums,
-                                                             const uint32_t *__restrict__ digit_base)
+template <int ND>
+__global__ __launch_bounds__(ND) void radix_apply_kernel(uint32_t *__restrict__ hist, uint32_t ntiles,
+                                                         const uint32_t *__restrict__ sums,
+                                                         const uint32_t *__restrict__ digit_base)
 {
     const uint32_t t0 = blockIdx.x * kRadixChunk;
     const uint32_t t1 = t0 + kRadixChunk < ntiles ? t0 + kRadixChunk : ntiles;
-    uint32_t run = sums[(uint64_t)blockIdx.x * 256 + threadIdx.x] + digit_base[threadIdx.x];
+    uint32_t run = sums[(uint64_t)blockIdx.x * ND + threadIdx.x] + digit_base[threadIdx.x];
     for (uint32_t tb = t0; tb < t1; tb += kColBatch) {
         uint32_t x[kColBatch];
 #pragma unroll
-        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + threadIdx.x] : 0u;
+        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * ND + threadIdx.x] : 0u;
 #pragma unroll
         for (int i = 0; i < kColBatch; ++i) {
-            if (tb + i < t1) hist[(uint64_t)(tb + i) * 256 + threadIdx.x] = run;
+            if (tb + i < t1) hist[(uint64_t)(tb + i) * ND + threadIdx.x] = run;
             run += x[i];
         }
     }
@@ -142,15 +173,24 @@ __global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restric
 
 // One tile of the scatter.  FULL: the tile lies inside the input (all but the last one): no bound checks.
 // IOTA: the values of the input are its indices 0, 1, 2, ... (the first pass of a sort of all positions): not read.
-template <bool IOTA, bool FULL>
+// wcount: kRW rows of ND per-wave digit counters.  For digits wider than 8 bits the rows live in the key image
+// (they are dead before the first key is staged), so that two workgroups still fit a CU's LDS.
+template <int DB, bool IOTA, bool FULL>
 __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                    uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint64_t n,
-                                                   int shift, uint32_t mask, uint32_t tile, uint32_t first_out,
-                                                   uint8_t *__restrict__ dig_out, int next_shift, uint32_t next_mask,
-                                                   uint32_t (*wcount)[256], uint32_t *goff, uint32_t *scan_lds,
+                                                   int shift, uint32_t mask, uint32_t tile, const uint32_t *__restrict__ offs,
+                                                   typename radix_dig_type<DB>::type *__restrict__ dig_out, int next_shift,
+                                                   uint32_t next_mask, uint32_t *wcount, uint32_t *goff, uint32_t *scan_lds,
                                                    uint64_t *skey)
 {
+    constexpr int ND = 1 << DB;
+    constexpr int R = ND > kRT ? ND / kRT : 1; // digits per thread in the per-digit steps (consecutive ones)
+    typedef typename radix_dig_type<DB>::type dig_t;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const bool has_digits = t * R < ND;
+    uint32_t first_out[R]; // first output index of (tile, digit): asked for now, needed after the ranking
+#pragma unroll
+    for (int r = 0; r < R; ++r) first_out[r] = has_digits ? offs[(uint64_t)tile * ND + t * R + r] : 0u;
     const uint64_t tile0 = (uint64_t)tile * kRadixTile;
     const uint64_t wave0 = tile0 + (uint64_t)w * (kWave * kRadixItems);
     uint64_t key[kRadixItems];
@@ -166,30 +206,40 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
         const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-        lpos[k] = wave_rank_inorder<8, FULL>(d, FULL || i < n, wcount[w]) | (d << 16);
+        lpos[k] = wave_rank_inorder<DB, FULL>(d, FULL || i < n, wcount + w * ND) | (d << 16);
     }
     __syncthreads();
     {
-        const int d = t & 255; // one thread per digit (threads 256.. of a wider workgroup only take part in the scan)
-        uint32_t s = 0;
-        if (t < 256) {
+        uint32_t s[R], tot = 0;
 #pragma unroll
-            for (int ww = 0; ww < kRW; ++ww) {
-                const uint32_t x = wcount[ww][d];
-                wcount[ww][d] = s;
-                s += x;
+        for (int r = 0; r < R; ++r) {
+            s[r] = 0;
+            if (has_digits) {
+                const int d = t * R + r;
+#pragma unroll
+                for (int ww = 0; ww < kRW; ++ww) {
+                    const uint32_t x = wcount[ww * ND + d];
+                    wcount[ww * ND + d] = s[r];
+                    s[r] += x;
+                }
             }
+            tot += s[r];
         }
-        const uint32_t inc = wave_inclusive_scan<OpAdd>(s);
+        const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
         if (lane == kWave - 1) scan_lds[w] = inc;
         __syncthreads();
         uint32_t base = 0;
         for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
-        const uint32_t ex = base + inc - s; // first slot of the digit inside the tile
-        if (t < 256) {
+        uint32_t ex = base + inc - tot; // first slot of the thread's first digit inside the tile
+        if (has_digits) {
 #pragma unroll
-            for (int ww = 0; ww < kRW; ++ww) wcount[ww][d] += ex; // first slot of (wave, digit)
-            goff[d] = first_out - ex;
+            for (int r = 0; r < R; ++r) {
+                const int d = t * R + r;
+#pragma unroll
+                for (int ww = 0; ww < kRW; ++ww) wcount[ww * ND + d] += ex; // first slot of (wave, digit)
+                goff[d] = first_out[r] - ex;
+                ex += s[r];
+            }
         }
     }
     __syncthreads();
@@ -198,9 +248,11 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
     const uint64_t left = n - tile0;
     const uint32_t cnt = FULL || left >= (uint64_t)kRadixTile ? (uint32_t)kRadixTile : (uint32_t)left;
 #pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) lpos[k] = (lpos[k] & 0xFFFFu) + wcount[w * ND + (lpos[k] >> 16)];
+    if (DB > 8) __syncthreads(); // the counters share the key image: every slot is known before the first key lands
+#pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
-        lpos[k] = (lpos[k] & 0xFFFFu) + wcount[w][lpos[k] >> 16];
         if (FULL || i < n) skey[lpos[k]] = key[k];
     }
     __syncthreads();
@@ -214,7 +266,7 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
             const uint32_t d = (uint32_t)(kk >> shift) & mask;
             dstv[k] = goff[d] + i;
             kout[dstv[k]] = kk; // (streaming stores here cost 20 %: the runs of neighbouring tiles meet in L2)
-            if (dig_out) dig_out[dstv[k]] = (uint8_t)((uint32_t)(kk >> next_shift) & next_mask); // uniform test
+            if (dig_out) dig_out[dstv[k]] = (dig_t)((uint32_t)(kk >> next_shift) & next_mask); // uniform test
         }
     }
     __syncthreads();
@@ -234,17 +286,21 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
 }
 
 // (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
-template <bool IOTA>
+template <int DB, bool IOTA>
 __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
     uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
-    uint32_t ntiles, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift,
-    uint32_t next_mask)
+    uint32_t ntiles, typename radix_dig_type<DB>::type *__restrict__ dig_out /* digits of the NEXT pass, or null */,
+    int next_shift, uint32_t next_mask)
 {
-    __shared__ uint32_t wcount[kRW][256]; // per-wave digit counters, then the first slot of each (wave, digit)
-    __shared__ uint32_t goff[256];        // global offset of the digit minus its first slot inside the tile
-    __shared__ uint32_t scan_lds[kRW];
+    constexpr int ND = 1 << DB;
     __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
+    // per-wave digit counters, then the first slot of each (wave, digit)
+    __shared__ uint32_t wcount_own[DB == 8 ? kRW * ND : 1];
+    __shared__ uint32_t goff[ND];         // global offset of the digit minus its first slot inside the tile
+    __shared__ uint32_t scan_lds[kRW];
+    static_assert((size_t)kRW * ND * sizeof(uint32_t) <= sizeof(uint64_t) * kRadixTile, "the counters fit the key image");
+    uint32_t *wcount = DB == 8 ? wcount_own : reinterpret_cast<uint32_t *>(skey);
 
     const int t = (int)threadIdx.x;
     // Workgroups are dealt round robin to the 8 XCDs, each with its own L2.  Tiles that follow each other write
@@ -253,76 +309,84 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
     const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (tile >= ntiles) return; // uniform
-    const uint32_t first_out = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // asked for now, needed after the ranking
-    for (int i = t; i < kRW * 256; i += kRT) (&wcount[0][0])[i] = 0;
+    for (int i = t; i < kRW * ND; i += kRT) wcount[i] = 0;
     __syncthreads();
     if ((uint64_t)(tile + 1) * kRadixTile <= n) // uniform
-        radix_scatter_tile<IOTA, true>(kin, vin, kout, vout, n, shift, mask, tile, first_out, dig_out, next_shift, next_mask,
-                                       wcount, goff, scan_lds, skey);
+        radix_scatter_tile<DB, IOTA, true>(kin, vin, kout, vout, n, shift, mask, tile, offs, dig_out, next_shift, next_mask,
+                                           wcount, goff, scan_lds, skey);
     else
-        radix_scatter_tile<IOTA, false>(kin, vin, kout, vout, n, shift, mask, tile, first_out, dig_out, next_shift, next_mask,
-                                        wcount, goff, scan_lds, skey);
+        radix_scatter_tile<DB, IOTA, false>(kin, vin, kout, vout, n, shift, mask, tile, offs, dig_out, next_shift, next_mask,
+                                            wcount, goff, scan_lds, skey);
 }
 
 } // namespace sx
 
 using namespace sx;
 
-// workspace of a sort of n pairs: tile table, chunk sums, digit bases, then one digit byte per pair
-static size_t sort_workspace(uint64_t n, uint32_t &ntiles, uint32_t &nchunks)
+// workspace of a sort of n pairs with db-bit digits: tile table, chunk sums, digit bases, then one digit per pair
+static size_t sort_workspace(uint64_t n, int db, uint32_t &ntiles, uint32_t &nchunks)
 {
+    const size_t nd = (size_t)1 << db;
     ntiles = sx_div_up(n, kRadixTile);
     nchunks = sx_div_up(ntiles, kRadixChunk);
-    return ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t) + ((n + 255) & ~(uint64_t)255) + 256;
+    return ((size_t)ntiles + nchunks + 1) * nd * sizeof(uint32_t) + (((n + 255) & ~(uint64_t)255) + 256) * (db > 8 ? 2 : 1);
 }
 
-uint8_t *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n)
+int sx_sort_digit_bits(const sx_ctx *ctx)
+{
+    return ctx->radix_digit_bits >= 8 && ctx->radix_digit_bits <= 10 ? ctx->radix_digit_bits : 8;
+}
+
+void *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n, int digit_bits)
 {
     uint32_t ntiles, nchunks;
-    const size_t bytes = sort_workspace(n, ntiles, nchunks);
+    const size_t bytes = sort_workspace(n, digit_bits, ntiles, nchunks);
     if (sx_slab_ensure(ctx, SX_SLAB_SORT, bytes) != 0) return nullptr;
-    return (uint8_t *)ctx->slab[SX_SLAB_SORT].p + ((size_t)ntiles + nchunks + 1) * 256 * sizeof(uint32_t);
+    return (uint8_t *)ctx->slab[SX_SLAB_SORT].p + ((size_t)ntiles + nchunks + 1) * ((size_t)1 << digit_bits) * sizeof(uint32_t);
 }
 
-int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
-                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready)
+template <int DB>
+static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n, int begin_bit,
+                         int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready)
 {
-    *result_in_b = 0;
-    if (n == 0 || end_bit <= begin_bit) return 0;
-    if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
+    constexpr int ND = 1 << DB;
+    typedef typename radix_dig_type<DB>::type dig_t;
     uint32_t ntiles, nchunks;
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, sort_workspace(n, ntiles, nchunks)));
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, sort_workspace(n, DB, ntiles, nchunks)));
     uint32_t *hist = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
-    uint32_t *sums = hist + (size_t)ntiles * 256, *digit_base = sums + (size_t)nchunks * 256;
-    uint8_t *dig = (uint8_t *)(digit_base + 256); // next pass's digits, written by every scatter but the last
+    uint32_t *sums = hist + (size_t)ntiles * ND, *digit_base = sums + (size_t)nchunks * ND;
+    dig_t *dig = (dig_t *)(digit_base + ND); // next pass's digits, written by every scatter but the last
     uint64_t *kin = ka, *kout = kb;
     uint32_t *vin = va, *vout = vb;
     int flips = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+    const uint64_t dig_bytes = sizeof(dig_t);
+    for (int shift = begin_bit; shift < end_bit; shift += DB) {
+        const int bits = end_bit - shift < DB ? end_bit - shift : DB;
         const uint32_t mask = (1u << bits) - 1u;
-        const int next_shift = shift + 8;
+        const int next_shift = shift + DB;
         const bool has_next = next_shift < end_bit;
-        const int next_bits = has_next ? (end_bit - next_shift < 8 ? end_bit - next_shift : 8) : 0;
+        const int next_bits = has_next ? (end_bit - next_shift < DB ? end_bit - next_shift : DB) : 0;
         if (shift == begin_bit && !first_digits_ready)
-            sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel, dim3(ntiles), dim3(kRT), (const uint64_t *)kin, n, shift,
+            sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel<DB>, dim3(ntiles), dim3(kRT), (const uint64_t *)kin, n, shift,
                       mask, hist, ntiles);
         else
-            sx_launch(ctx, SX_KC_RADIX_HIST, n, radix_hist_digits_kernel, dim3(ntiles), dim3(kRT), (const uint8_t *)dig, n, hist);
-        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 1024, radix_colsum_kernel, dim3(nchunks), dim3(kBlock),
+            sx_launch(ctx, SX_KC_RADIX_HIST, n * dig_bytes, radix_hist_digits_kernel<DB>, dim3(ntiles), dim3(kRT), (const dig_t *)dig, n, hist);
+        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 4, radix_colsum_kernel<ND>, dim3(nchunks), dim3(ND),
                   (const uint32_t *)hist, ntiles, sums);
-        sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks * 2048, radix_bases_kernel, dim3(1), dim3(kBlock), sums, nchunks,
+        sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks * ND * 8, radix_bases_kernel<ND>, dim3(1), dim3(ND), sums, nchunks,
                   digit_base);
-        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * 2048, radix_apply_kernel, dim3(nchunks), dim3(kBlock), hist, ntiles,
+        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 8, radix_apply_kernel<ND>, dim3(nchunks), dim3(ND), hist, ntiles,
                   (const uint32_t *)sums, (const uint32_t *)digit_base);
         if (values_are_indices && shift == begin_bit)
-            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (has_next ? 21 : 20), radix_scatter_kernel<true>, dim3(((ntiles + 7) / 8) * 8),
-                      dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist,
-                      ntiles, has_next ? dig : nullptr, next_shift & 63, has_next ? (1u << next_bits) - 1u : 0u);
+            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (20 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true>,
+                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
+                      mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
+                      has_next ? (1u << next_bits) - 1u : 0u);
         else
-            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (has_next ? 25 : 24), radix_scatter_kernel<false>, dim3(((ntiles + 7) / 8) * 8),
-                      dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift, mask, (const uint32_t *)hist,
-                      ntiles, has_next ? dig : nullptr, next_shift & 63, has_next ? (1u << next_bits) - 1u : 0u);
+            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (24 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, false>,
+                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
+                      mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
+                      has_next ? (1u << next_bits) - 1u : 0u);
         uint64_t *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
         ++flips;
@@ -330,6 +394,20 @@ int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_
     }
     *result_in_b = flips & 1;
     return 0;
+}
+
+int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
+                  int begin_bit, int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready,
+                  int digit_bits)
+{
+    *result_in_b = 0;
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
+    switch (digit_bits ? digit_bits : sx_sort_digit_bits(ctx)) {
+    case 9: return sort_pairs_db<9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready);
+    case 10: return sort_pairs_db<10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready);
+    default: return sort_pairs_db<8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready);
+    }
 }
 
 extern "C" int sx_prim_sort_pairs_dev(sx_ctx *ctx, uint64_t *d_keys_a, uint32_t *d_vals_a, uint64_t *d_keys_b,

@@ -78,6 +78,55 @@ def test_static_key_shapes(emu_ctx):
         emu_ctx.set_prefix_symbols(0)
 
 
+def test_hybrid_prefix_sort(emu_ctx):
+    """SX_FLAG_SORT_MODE 2: HBM passes on the top 24 key bits, sub-buckets ordered in LDS (sx_localsort.hip), ties listed
+    by the same kernel; a sub-bucket too long for a workgroup falls back to LSD passes"""
+    rng = np.random.default_rng(11)
+    emu_ctx.set_sort_mode(2)
+    try:
+        for sigma, syms, n in ((5, 17, 9000), (5, 17, 4097), (5, 14, 20000), (6, 16, 12000), (5, 18, 30000)):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            x[700:760] = x[100:160]      # ties beyond the key: refinement rounds after the local sort
+            x[n - 300:n - 260] = x[100:140]
+            emu_ctx.set_prefix_symbols(syms)
+            sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+            emu_ctx.sa_bwt_build_dev(x, n, sigma, sa, bw)
+            st = emu_ctx.last_stats()
+            want = oracle.sa_is(x, sigma)
+            assert st["lms_path"] == 1 and st["sort_local"] == 1, (sigma, syms, n, st)
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (sigma, syms, n)
+        # 40 copies of a 60-symbol piece: equal keys crowd a bin of the counting pass, that workgroup takes stable passes
+        x = rng.integers(1, 5, size=20000, dtype=np.uint8)
+        for i in range(40):
+            x[300 + 400 * i:360 + 400 * i] = x[100:160]
+        emu_ctx.set_prefix_symbols(17)
+        sa = _sa(emu_ctx, x, 5)
+        assert emu_ctx.last_stats()["sort_local"] == 3, emu_ctx.last_stats()
+        assert (sa == oracle.sa_is(x, 5)).all()
+        # one 12-symbol prefix in front of thousands of LMS suffixes: a sub-bucket no workgroup can hold
+        unit = np.array([1, 3, 2, 4, 4, 2, 3, 1, 1, 3, 2, 4, 2, 1], np.uint8)
+        reps = 6500
+        x = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=6, dtype=np.uint8)]) for _ in range(reps)])
+        emu_ctx.set_prefix_symbols(17)
+        sa = _sa(emu_ctx, x, 5)
+        st = emu_ctx.last_stats()
+        assert st["sort_local"] == 0, st
+        assert (sa == oracle.sa_is(x, 5)).all()
+        # the direct sort of all suffixes of a wide alphabet through the same path
+        x = synth(30000, 256, 5)
+        x[100:112] = x[1000:1012]
+        emu_ctx.set_prefix_symbols(0)
+        sa, bw = np.zeros(x.size + 1, np.uint32), np.zeros(x.size + 1, np.uint8)
+        emu_ctx.sa_bwt_build_dev(x, x.size, 256, sa, bw)
+        st = emu_ctx.last_stats()
+        want = oracle.sa_is(x, 256)
+        assert st["lms_path"] == 3, st
+        assert (sa == want).all() and (bw == oracle.bwt(x, want)).all()
+    finally:
+        emu_ctx.set_sort_mode(0)
+        emu_ctx.set_prefix_symbols(0)
+
+
 def test_long_repeats_finish_by_comparison(emu_ctx):
     """duplications far longer than the refinement keys: pairs are settled by comparing the suffixes themselves
     (lms_path stays 1), a repeat with many copies goes through the sorting rounds"""
@@ -219,6 +268,22 @@ def test_primitives(emu_ctx):
     ks, vs = (kb, vb) if in_b else (ka, va)
     order = np.argsort(keys, kind="stable")
     assert (ks == keys[order]).all() and (vs == order).all()
+    # wider digits (fewer passes): 9 and 10 bits, a last pass narrower than the digit, more than one tile
+    n2 = 20000
+    keys2 = rng.integers(0, 1 << 40, size=n2, dtype=np.uint64)
+    keys2[::5] = keys2[11]
+    for bits, lo, hi in ((9, 0, 40), (10, 0, 40), (10, 3, 37), (9, 22, 40)):
+        emu_ctx.set_radix_digit_bits(bits)
+        try:
+            ka, va = keys2.copy(), np.arange(n2, dtype=np.uint32)
+            kb, vb = np.zeros_like(ka), np.zeros_like(va)
+            in_b = emu_ctx.prim_sort_pairs_dev(ka, va, kb, vb, n2, lo, hi)
+        finally:
+            emu_ctx.set_radix_digit_bits(0)
+        ks, vs = (kb, vb) if in_b else (ka, va)
+        field = (keys2 >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
+        order = np.argsort(field, kind="stable")
+        assert (ks == keys2[order]).all() and (vs == order).all(), (bits, lo, hi)
     x = rng.integers(0, 1000, size=70000, dtype=np.uint32)
     out, tot = np.zeros_like(x), np.zeros(1, np.uint32)
     emu_ctx.prim_exclusive_sum_dev(x, out, x.size, tot)

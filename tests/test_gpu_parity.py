@@ -181,6 +181,63 @@ def test_static_key_shapes(gpu_ctx):
         gpu_ctx.set_prefix_symbols(0)
 
 
+def test_hybrid_prefix_sort(gpu_ctx):
+    """the prefix-key sort's two forms against the oracle: LSD passes over all key bits (mode 1) and HBM passes on the
+    top 24 bits + sub-buckets ordered in LDS (mode 2; sx_localsort.hip), which also lists the ties; key shapes of
+    64 Mi ... 4 Gi symbol texts forced on small ones; a sub-bucket no workgroup can hold falls back to LSD passes;
+    wider radix digits (9, 10 bits) for the LSD form"""
+    import torch
+    rng = np.random.default_rng(5)
+    try:
+        for sigma, n in ((5, 1 << 22), (6, (1 << 20) + 77), (5, 4097)):
+            x = synth(n, sigma, 31)
+            if n > 100_000:
+                x[500_000:500_080] = x[1000:1080]  # ties beyond the key: refinement rounds
+                x[700_000:700_030] = x[1000:1030]
+            want = oracle.sa_is(x, sigma)
+            bw_want = oracle.bwt(x, want)
+            for C in ((14, 16, 17, 18) if sigma == 5 else (13, 16)):
+                for mode in (1, 2):
+                    gpu_ctx.set_prefix_symbols(C)
+                    gpu_ctx.set_sort_mode(mode)
+                    xd = torch.from_numpy(x).cuda()
+                    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+                    bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+                    gpu_ctx.sa_bwt_build_dev(xd, n, sigma, sa, bw)
+                    st = gpu_ctx.last_stats()
+                    assert (st["sort_local"] & 1) == (1 if mode == 2 else 0) and st["key_slots"] == C, (sigma, n, C, mode, st)
+                    assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n, C, mode)
+                    assert (bw.cpu().numpy() == bw_want).all(), (sigma, n, C, mode)
+        # 40 copies of a 60-symbol piece: equal keys crowd a bin of the counting pass, that workgroup takes stable passes
+        x = synth(1 << 20, 5, 33)
+        for i in range(40):
+            x[300 + 4000 * i:360 + 4000 * i] = x[100:160]
+        gpu_ctx.set_prefix_symbols(17)
+        gpu_ctx.set_sort_mode(2)
+        sa = gpu_ctx.sa_build(x, 5)
+        assert gpu_ctx.last_stats()["sort_local"] == 3, gpu_ctx.last_stats()
+        assert (sa == oracle.sa_is(x, 5)).all()
+        # one 14-symbol prefix in front of tens of thousands of LMS suffixes
+        unit = np.array([1, 3, 2, 4, 4, 2, 3, 1, 1, 3, 2, 4, 2, 1], np.uint8)
+        x = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=6, dtype=np.uint8)]) for _ in range(20000)])
+        gpu_ctx.set_prefix_symbols(17)
+        gpu_ctx.set_sort_mode(2)
+        sa = gpu_ctx.sa_build(x, 5)
+        assert gpu_ctx.last_stats()["sort_local"] == 0
+        assert (sa == oracle.sa_is(x, 5)).all()
+        # wider digits
+        gpu_ctx.set_sort_mode(1)
+        x = synth(1 << 21, 5, 32)
+        want = oracle.sa_is(x, 5)
+        for bits in (9, 10):
+            gpu_ctx.set_radix_digit_bits(bits)
+            assert (gpu_ctx.sa_build(x, 5) == want).all(), bits
+    finally:
+        gpu_ctx.set_prefix_symbols(0)
+        gpu_ctx.set_sort_mode(0)
+        gpu_ctx.set_radix_digit_bits(0)
+
+
 def test_both_induce_round_forms(gpu_ctx):
     """every round through the chained launch (look-back across up to thousands of tiles), every round
     through the three-launch form, and the default mix"""
