@@ -51,6 +51,8 @@ def parse_args(argv=None):
                     help="wide alphabets: LMS sort + induced-sort passes even where the direct sort of all suffixes applies")
     ap.add_argument("--sort-mode", type=int, default=0,
                     help="prefix-key sort: 0 choose, 1 LSD passes over all key bits, 2 hybrid (top bits in HBM passes, sub-buckets in LDS)")
+    ap.add_argument("--chain-max", type=int, default=-1,
+                    help="induce rounds of up to this many entries take the single chained launch (default: by alphabet size)")
     ap.add_argument("--cpu-log2n", type=int, default=int(os.environ.get("STRALG_BENCH_CPU_LOG2N", "25")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last step's results")
@@ -230,6 +232,8 @@ def run_rank(args):
         ctx.set_no_direct_sort(True)
     if args.sort_mode:
         ctx.set_sort_mode(args.sort_mode)
+    if args.chain_max >= 0:
+        ctx.set_chain_max_entries(args.chain_max)
     # host work of a rank (staging copies, page faults of pinned and malloc'd buffers) next to its GPU's PCIe root
     numa_node = ctx.bind_to_numa_node()
     if world > 1:

@@ -645,7 +645,8 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                                                              uint32_t *__restrict__ cursor_nxt, int dir,
                                                              uint32_t max_iters)
 {
-    __shared__ uint32_t wcount[kTailWaves][256];
+    constexpr int kDigits = BITS == 3 ? 8 : 256; // buckets that can receive anything
+    __shared__ uint32_t wcount[kTailWaves][kDigits];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t s_range[2];
     __shared__ uint32_t s_flag;
@@ -655,7 +656,17 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         s_range[0] = range_in[0];
         s_range[1] = range_in[1];
     }
+    for (int i = t; i < kTailWaves * kDigits; i += kTailBlock) (&wcount[0][0])[i] = 0;
     __syncthreads();
+    // The entries a round appends to bucket c are the next round's input, in the order they were appended: the
+    // threads that wrote them keep them (position, window) in registers, in place, so from the second round of a
+    // launch on nothing is read back from memory (a round then costs its barriers, not two trips to L2).
+    uint32_t val[kIndItems];
+    WT wnd[kIndItems];
+    bool live[kIndItems]; // entry k of this thread belongs to the current range (scan order: wave, k, lane)
+    bool held = false;
+    uint32_t prev_len = 0;
+    const uint32_t wave0 = (uint32_t)w * (kWave * kIndItems);
     for (uint32_t it = 0; it < max_iters; ++it) {
         const uint32_t lo = s_range[0], len = s_range[1] - lo;
         if (len == 0 || len > kTailEntries) break; // uniform
@@ -665,7 +676,8 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         // left of every entry are all c, the next L rounds are known: round j holds the same
         // entries minus j, in the next `len` slots.  They are written at once (L = 16 symbols
         // per checking thread; 4096 rounds a step for a single run) instead of one at a time.
-        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len <= (uint32_t)kTailTile) {
+        // Tried only when the last round kept every entry (the sign of runs): the check reads memory.
+        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len == prev_len) {
             const uint32_t G = len <= (uint32_t)kTailBlock ? (uint32_t)kTailBlock / len : 1u; // threads per entry
             const uint32_t L = 16u * G;
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
@@ -702,77 +714,80 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                     s_range[0] = dir > 0 ? cur + total - len : cur - total;
                     s_range[1] = dir > 0 ? cur + total : cur - total + len;
                 }
+                held = false; // the range is now what the jump wrote last
                 __syncthreads();
                 continue;
             }
         }
-        // the round's tiles one after the other (the buckets' cursors move on between them, so the order of the
-        // entries is the order of the scan); a tile is the whole round as the launch is configured now
-        const uint32_t c_start = gbase[c];
-        for (uint32_t sub0 = 0; sub0 < len; sub0 += (uint32_t)kTailTile) { // uniform
-            for (int i = t; i < kTailWaves * 256; i += kTailBlock) (&wcount[0][0])[i] = 0;
-            __syncthreads();
-            const uint32_t wave0 = sub0 + (uint32_t)w * (kWave * kIndItems);
-            uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
-            WT wnd[kIndItems];
-            bool ok[kIndItems];
+        prev_len = len;
+        if (!held) { // the range's entries from memory (the first round of a launch, or after a jump)
 #pragma unroll
             for (int k = 0; k < kIndItems; ++k) {
                 const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
-                ok[k] = false;
-                dig[k] = 0;
+                live[k] = i < len;
                 val[k] = 0;
                 wnd[k] = 0;
-                if (i < len) {
+                if (live[k]) {
                     const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                    const uint32_t p = SA[idx];
-                    if (p != 0) {
-                        const WT ww = WN[idx];
-                        const uint32_t ch = wnd_first<WT>(ww, cfg);
-                        ok[k] = induce_accept(ch, c, mode);
-                        dig[k] = ch;
-                        val[k] = p - 1u;
-                        wnd[k] = wnd_pop<WT>(ww, cfg);
-                    }
+                    val[k] = SA[idx];
+                    wnd[k] = WN[idx];
                 }
             }
-#pragma unroll
-            for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
-            __syncthreads();
-            uint32_t cnt = 0; // entries of this tile for bucket t
-            if (t < 256) {
-#pragma unroll
-                for (int ww = 0; ww < kTailWaves; ++ww) {
-                    const uint32_t x = wcount[ww][t];
-                    wcount[ww][t] = cnt;
-                    cnt += x;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kIndItems; ++k) {
-                if (ok[k]) {
-                    const uint32_t d = dig[k];
-                    const uint32_t r = wcount[w][d] + rnk[k];
-                    const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
-                    const uint32_t j = val[k];
-                    WT nw = wnd[k];
-                    if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg);
-                    SA[dst] = j;
-                    WN[dst] = nw;
-                    BW[dst] = wnd_symbol<WT>(nw, cfg);
-                }
-            }
-            __syncthreads();
-            if (t < 256) gbase[t] = dir > 0 ? gbase[t] + cnt : gbase[t] - cnt;
-            __syncthreads(); // (the next tile reads the cursors; LDS is reused)
         }
-        if ((uint32_t)t == c) { // what the round appended to bucket c is the next round's input
-            const uint32_t now = gbase[c];
-            s_range[0] = dir > 0 ? c_start : now;
-            s_range[1] = dir > 0 ? now : c_start;
+        uint32_t dig[kIndItems], rnk[kIndItems];
+        bool ok[kIndItems];
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            ok[k] = false;
+            dig[k] = 0;
+            if (live[k] && val[k] != 0) {
+                const uint32_t ch = wnd_first<WT>(wnd[k], cfg);
+                ok[k] = induce_accept(ch, c, mode);
+                dig[k] = ch;
+                val[k] -= 1u;
+                wnd[k] = wnd_pop<WT>(wnd[k], cfg);
+            }
         }
-        __syncthreads(); // also orders this round's stores before the next round's loads
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k] & (uint32_t)(kDigits - 1), ok[k], wcount[w]);
+        __syncthreads();
+        uint32_t cnt = 0; // entries of this round for bucket t
+        if (t < kDigits) {
+#pragma unroll
+            for (int ww = 0; ww < kTailWaves; ++ww) {
+                const uint32_t x = wcount[ww][t];
+                wcount[ww][t] = cnt;
+                cnt += x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            live[k] = ok[k] && dig[k] == c; // appended to bucket c itself: part of the next round
+            if (ok[k]) {
+                const uint32_t d = dig[k];
+                const uint32_t r = wcount[w][d & (uint32_t)(kDigits - 1)] + rnk[k];
+                const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
+                const uint32_t j = val[k];
+                if (j != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, j, cfg);
+                SA[dst] = j;
+                WN[dst] = wnd[k];
+                BW[dst] = wnd_symbol<WT>(wnd[k], cfg);
+            }
+        }
+        held = true;
+        __syncthreads();
+        if (t < kDigits) {
+            const uint32_t before = gbase[t], now = dir > 0 ? before + cnt : before - cnt;
+            gbase[t] = now;
+            if ((uint32_t)t == c) { // what the round appended to bucket c is the next round's input
+                s_range[0] = dir > 0 ? before : now;
+                s_range[1] = dir > 0 ? now : before;
+            }
+#pragma unroll
+            for (int ww = 0; ww < kTailWaves; ++ww) wcount[ww][t] = 0;
+        }
+        __syncthreads();
     }
     if (t < 256) cursor_nxt[t] = gbase[t];
     if (t == 0) {
