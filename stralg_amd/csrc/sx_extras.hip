@@ -8,9 +8,14 @@
 //                                                        stralg/bwt.c:164-199  init_bwt_exact_match_iter
 //
 // LCP keeps Kasai's invariant (the value drops by at most one from text position i to i+1) inside
-// chunks of 64 consecutive text positions handled by one thread; a chunk starts from 0, and
-// suffixes are compared 16 bytes at a time.  Work is O(n + chunks x typical lcp): linear on
-// ordinary text; on highly repetitive text the chunk starts dominate (documented limitation).
+// chunks of 64 consecutive text positions handled by one thread, suffixes compared 16 bytes at a
+// time.  The value a chunk starts from comes from the same invariant over longer distances: the
+// values at the chunk starts ("samples") are computed level by level, stride halving -- a new
+// sample at distance s to the right of a known one starts its comparison at (that value - s) --
+// so that no comparison ever repeats symbols a sample to its left has already matched.  Work is
+// O(n) symbol comparisons per level in the worst case (periodic text) and next to nothing on
+// ordinary text; with every chunk starting from 0 instead, a text with one long repeat paid the
+// repeat's length once per chunk (quadratic on periodic strings).
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_internal.hpp"
@@ -43,19 +48,44 @@ __device__ __forceinline__ uint32_t extend_match(const uint8_t *__restrict__ T, 
     }
 }
 
+// PLCP at the chunk starts c = first + k * step (k = 0, 1, ...), c < chunks: text position i = c * kLcpChunk is compared
+// with the suffix in front of it in the suffix array, from offset max(0, plcp[c - back] - back * kLcpChunk) on
+// (Kasai's invariant over back * kLcpChunk positions); back == 0: from 0 (the first sample of all).
+__global__ __launch_bounds__(kBlock) void lcp_samples_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ sa,
+                                                             const uint32_t *__restrict__ inv, uint64_t chunks,
+                                                             uint64_t first, uint64_t step, uint64_t back,
+                                                             uint32_t *__restrict__ plcp)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t c = first + k * step;
+    if (c >= chunks) return;
+    const uint64_t i = c * kLcpChunk;
+    const uint32_t j = inv[i];
+    uint32_t l = 0;
+    if (j != 0) {
+        if (back) {
+            const uint64_t known = plcp[c - back], dist = back * kLcpChunk;
+            l = known > dist ? (uint32_t)(known - dist) : 0u;
+        }
+        l = extend_match(T, (uint32_t)i, sa[j - 1], l);
+    }
+    plcp[c] = l;
+}
+
 __global__ __launch_bounds__(kBlock) void lcp_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ sa,
                                                      const uint32_t *__restrict__ inv, uint64_t N,
-                                                     uint32_t *__restrict__ lcp)
+                                                     const uint32_t *__restrict__ plcp, uint32_t *__restrict__ lcp)
 {
     const uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t i0 = chunk * kLcpChunk;
     if (i0 >= N) return;
     const uint64_t i1 = i0 + kLcpChunk < N ? i0 + kLcpChunk : N;
-    uint32_t l = 0;
+    uint32_t l = plcp[chunk]; // what the first position of the chunk has in common with its predecessor: known
     for (uint64_t i = i0; i < i1; ++i) {
         const uint32_t j = inv[i];
         if (j == 0) { // the sentinel suffix has no predecessor: lcp[0] = 0 (suffix_array.c:74-75)
             lcp[0] = 0;
+            l = 0;
             continue;
         }
         const uint32_t k = sa[j - 1];
@@ -123,8 +153,21 @@ static int lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uin
     SX_CHECK(hipMemsetAsync(T + n, 0, text_b - n, ctx->stream));
     SX_TRY(inverse_dev(ctx, d_sa, N, inv));
     const uint64_t chunks = (N + kLcpChunk - 1) / kLcpChunk;
+    // samples: chunk 0 from scratch, then the chunks at odd multiples of S, S halving, each from the sample S to its left
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, chunks * 4 + 4096));
+    uint32_t *plcp = (uint32_t *)((char *)ctx->slab[SX_SLAB_BWT].p + 4096); // (the first page holds inverse_dev's counter)
+    sx_launch(ctx, SX_KC_LCP, 64, lcp_samples_kernel, dim3(1), dim3(kBlock), (const uint8_t *)T, d_sa, (const uint32_t *)inv, (uint64_t)1,
+              (uint64_t)0, (uint64_t)1, (uint64_t)0, plcp);
+    uint64_t S = 1;
+    while (S * 2 < chunks) S *= 2;
+    for (; S >= 1; S /= 2) {
+        const uint64_t count = chunks > S ? (chunks - S + 2 * S - 1) / (2 * S) : 0; // chunks S, 3S, 5S, ... below `chunks`
+        if (count)
+            sx_launch(ctx, SX_KC_LCP, count * 80, lcp_samples_kernel, dim3(sx_div_up(count, kBlock)), dim3(kBlock), (const uint8_t *)T,
+                      d_sa, (const uint32_t *)inv, chunks, S, 2 * S, S, plcp);
+    }
     sx_launch(ctx, SX_KC_LCP, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
-              (const uint32_t *)inv, N, d_lcp);
+              (const uint32_t *)inv, N, (const uint32_t *)plcp, d_lcp);
     return 0;
 }
 

@@ -796,9 +796,10 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         // without repeats); repeats show when the kernel finds a sub-bucket that does not fit, and LSD passes finish the job.
         bool hybrid = ctx->sort_mode != 1 && sort_db == 8 && sx_local_sort_applies(m, kbits) && tile_lsrt != nullptr;
         if (hybrid && ctx->sort_mode == 0) {
-            // sub-buckets the top bits leave: as many as the text has prefixes of 24 / log2(base) symbols -- about
-            // (effective alphabet)^(that many), the effective alphabet being 1 / sum p^2 (A C G T in base 5: 4, not 5:
-            // a fifth of the key space per symbol is never used) -- and the copies of the most frequent one
+            // Sub-buckets the top bits leave: the low L = kbits - 24 bits span base^(L / log2 base) key values, so the
+            // top bits tell apart prefixes of C - L / log2(base) symbols (A C G T in base 5, 17 symbols, L = 16: 10.1) -- and
+            // a text has about (effective alphabet)^(that many) of those, the effective alphabet being 1 / sum p^2 (4,
+            // not 5: a fifth of the key space per symbol is never used).  Also: the copies of the most frequent one.
             double pmax = 0.0, sum_p2 = 0.0;
             const double n_sym = (double)ti.N - 1.0;
             for (int c = 1; c < 256 && n_sym > 0; ++c) {
@@ -806,10 +807,11 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 if (pc > pmax) pmax = pc;
                 sum_p2 += pc * pc;
             }
-            const double syms = (double)kSxHybridTopBits / log2((double)base);
+            const double syms = (double)C - (double)(kbits - kSxHybridTopBits) / log2((double)base);
             const double eff = sum_p2 > 0.0 ? 1.0 / sum_p2 : 1.0;
-            const double mean_bucket = (double)m / pow(eff, syms), top_bucket = (double)m * pow(pmax, syms);
-            if (m < (1u << 22) || mean_bucket > 400.0 || top_bucket > 512.0) hybrid = false;
+            const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
+            const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
+            if (m < (1u << 22) || mean_bucket > 300.0 || top_bucket > 512.0) hybrid = false;
         }
         const uint32_t dig_shift = hybrid ? (uint32_t)(kbits - kSxHybridTopBits) : 0u;
         const uint32_t dig_mask = kbits - (int)dig_shift >= 8 ? 0xFFu : (1u << (kbits - (int)dig_shift)) - 1u;

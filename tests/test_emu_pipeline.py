@@ -207,6 +207,17 @@ def test_next_rows(emu_ctx, golden):
         c = golden[name]
         inv, lcp = emu_ctx.inverse_lcp(c["sym"], c["sa"])
         assert (inv == z[name + "/inverse"]).all() and (lcp == z[name + "/lcp"]).all(), name
+    # LCP over many chunks of 64 positions, long common prefixes (the chunk starts take their values from the sampled
+    # levels): a Fibonacci string, a string of period 7, random DNA with a 3000-symbol duplication
+    fib_a, fib_b = np.array([1], np.uint8), np.array([1, 2], np.uint8)
+    while fib_b.size < 5000:
+        fib_a, fib_b = fib_b, np.concatenate([fib_b, fib_a])
+    dup = synth(9000, 5, 4)
+    dup[5000:8000] = dup[500:3500]
+    for x, sigma in ((fib_b, 3), (np.tile(np.array([1, 2, 2, 1, 3, 1, 2], np.uint8), 700), 4), (dup, 5)):
+        sa = oracle.sa_is(x, sigma)
+        inv, lcp = emu_ctx.inverse_lcp(x, sa)
+        assert (inv == oracle.inverse(sa)).all() and (lcp == oracle.lcp(x, sa)).all()
     for name in ("ref/mississippi", "ref/fasta3", "struct/periodic"):
         c = golden[name]
         pats, offs, lr = z[name + "/patterns"], z[name + "/offsets"], z[name + "/lr"]
