@@ -18,7 +18,8 @@ CLASS_OF = [
     ("fill_windows_kernel", "induce_gather"), ("induce_offsets_kernel", "induce_scan"),
     ("induce_round_kernel", "induce_chain"), ("otable_", "otable"), ("bwt_", "bwt_gather"),
     ("cls_", "classify"), ("samp_", "samples"), ("lms_prefix_keys", "keys"), ("lms_tile_keys", "keys"), ("radix_colsum", "scan"), ("radix_bases", "scan"), ("radix_apply", "scan"), ("piece_keys", "keys"),
-    ("InTied", "names"), ("InKeyBoundary", "names"),
+    ("InTied", "names"), ("InKeyBoundary", "names"), ("local_sort_kernel", "local_sort"), ("local_tied_gather", "names"),
+    ("tied_mark", "names"), ("tied_gather", "names"), ("refine_", "doubling"), ("induce_tail", "induce_chain"),
 ]
 
 
