@@ -501,6 +501,319 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
     }
 }
 
+// ---- large rounds of wide alphabets (more than 8 buckets) ------------------------------------
+// A round is a stable split by one symbol of up to 8 bits: a radix pass (sx_radix.hip) whose "digit bases" are the
+// bucket cursors and whose pairs are (window, position) instead of (key, value).  So it is built like one: tiles
+// of 8192 entries, a tile-major count table ([tile][256]: every kernel touches whole 1 KiB rows), the ranking with
+// four vector instructions per symbol bit, and the tile's output staged in LDS in bucket order so that every
+// bucket's run leaves as a contiguous block.  (The kernels above -- 2048-entry tiles, a bucket-major table read with
+// a 64-byte sector per count, one look-back thread per bucket and tile -- took 92 of 142 ms of a 1 GiB text of 255
+// symbols, whose buckets of 2 M entries they visit one after the other: 50 MB moved in 100 us and more.)
+constexpr int kWideThreads = 512, kWideWaves = kWideThreads / kWave, kWideItems = 16;
+constexpr int kWideTile = kWideThreads * kWideItems; // 8192 entries
+constexpr uint32_t kWideChunk = 256;                  // tiles per chunk of the column sums (long rounds)
+
+template <class WT>
+__global__ __launch_bounds__(kWideThreads) void induce_wide_count_kernel(const WT *__restrict__ srcW,
+                                                                      const uint8_t *__restrict__ srcB,
+                                                                      const uint32_t *__restrict__ range_in, int rev,
+                                                                      int mode, uint32_t c, wnd_cfg cfg,
+                                                                      uint32_t *__restrict__ hist /* [tile][256] */,
+                                                                      uint32_t min_len)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const bool aligned = srcB ? ((uintptr_t)srcB & 15u) == 0 : ((uintptr_t)srcW & 15u) == 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        if (threadIdx.x < 256) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t tile0 = tile * (uint32_t)kWideTile;
+        const uint32_t cnt = len - tile0 < (uint32_t)kWideTile ? len - tile0 : (uint32_t)kWideTile;
+        const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b), any order
+        if (srcB) {
+            for (uint64_t q = (uint64_t)(a >> 4) + threadIdx.x; q * 16u < b; q += kWideThreads) {
+                const uint64_t e0 = q * 16u;
+                uint32_t S[4] = {0, 0, 0, 0};
+                if (aligned && e0 >= a && e0 + 16u <= b) {
+                    load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (e0 + e >= a && e0 + e < b) S[e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t ch = (S[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                    if (ch != 0 && induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                }
+            }
+        } else {
+            for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kWideThreads) {
+                const uint64_t e0 = q * 4u;
+                WT W[4] = {0, 0, 0, 0};
+                if (aligned && e0 >= a && e0 + 4u <= b) {
+                    load_quad(srcW + e0, W);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
+                        const uint32_t ch = wnd_first<WT>(W[e], cfg);
+                        if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) hist[(uint64_t)tile * 256 + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// counts -> entries of earlier tiles, per bucket; the cursors move on; the range appended to bucket c.
+// One workgroup, a thread per bucket (rounds of up to a few hundred tiles: whole 1 KiB rows, 16 in flight).
+__global__ __launch_bounds__(kBlock) void induce_wide_offsets_kernel(uint32_t *__restrict__ hist,
+                                                                     const uint32_t *__restrict__ range_in,
+                                                                     uint32_t *__restrict__ range_out,
+                                                                     const uint32_t *__restrict__ cursor_cur,
+                                                                     uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
+                                                                     uint32_t min_len)
+{
+    const uint32_t len = range_in[1] - range_in[0];
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile, d = threadIdx.x;
+    constexpr int kBatch = 16;
+    uint32_t run = 0;
+    for (uint32_t tb = 0; tb < ntiles; tb += kBatch) {
+        uint32_t x[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < ntiles ? hist[(uint64_t)(tb + i) * 256 + d] : 0u;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            if (tb + i < ntiles) hist[(uint64_t)(tb + i) * 256 + d] = run;
+            run += x[i];
+        }
+    }
+    const uint32_t cur = cursor_cur[d];
+    cursor_nxt[d] = dir > 0 ? cur + run : cur - run;
+    if (d == c && range_out) {
+        range_out[0] = dir > 0 ? cur : cur - run;
+        range_out[1] = dir > 0 ? cur + run : cur;
+    }
+}
+
+// The same for long rounds in three launches: column sums of chunks of 256 tiles, their prefix (one workgroup; also
+// the cursors and the range), and the prefix inside every chunk.
+__global__ __launch_bounds__(kBlock) void induce_wide_colsum_kernel(const uint32_t *__restrict__ hist,
+                                                                    const uint32_t *__restrict__ range_in,
+                                                                    uint32_t *__restrict__ sums, uint32_t min_len)
+{
+    const uint32_t len = range_in[1] - range_in[0];
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const uint32_t t0 = blockIdx.x * kWideChunk;
+    if (t0 >= ntiles) return;
+    const uint32_t t1 = t0 + kWideChunk < ntiles ? t0 + kWideChunk : ntiles;
+    constexpr int kBatch = 16;
+    uint32_t sacc = 0;
+    for (uint32_t tb = t0; tb < t1; tb += kBatch) {
+        uint32_t x[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) sacc += x[i];
+    }
+    sums[(uint64_t)blockIdx.x * 256 + threadIdx.x] = sacc;
+}
+__global__ __launch_bounds__(kBlock) void induce_wide_bases_kernel(uint32_t *__restrict__ sums,
+                                                                   const uint32_t *__restrict__ range_in,
+                                                                   uint32_t *__restrict__ range_out,
+                                                                   const uint32_t *__restrict__ cursor_cur,
+                                                                   uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
+                                                                   uint32_t min_len)
+{
+    const uint32_t len = range_in[1] - range_in[0];
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile, nchunks = (ntiles + kWideChunk - 1) / kWideChunk;
+    const uint32_t d = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t cb = 0; cb < nchunks; ++cb) {
+        const uint32_t x = sums[(uint64_t)cb * 256 + d];
+        sums[(uint64_t)cb * 256 + d] = run;
+        run += x;
+    }
+    const uint32_t cur = cursor_cur[d];
+    cursor_nxt[d] = dir > 0 ? cur + run : cur - run;
+    if (d == c && range_out) {
+        range_out[0] = dir > 0 ? cur : cur - run;
+        range_out[1] = dir > 0 ? cur + run : cur;
+    }
+}
+__global__ __launch_bounds__(kBlock) void induce_wide_apply_kernel(uint32_t *__restrict__ hist,
+                                                                   const uint32_t *__restrict__ range_in,
+                                                                   const uint32_t *__restrict__ sums, uint32_t min_len)
+{
+    const uint32_t len = range_in[1] - range_in[0];
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const uint32_t t0 = blockIdx.x * kWideChunk;
+    if (t0 >= ntiles) return;
+    const uint32_t t1 = t0 + kWideChunk < ntiles ? t0 + kWideChunk : ntiles;
+    constexpr int kBatch = 16;
+    uint32_t run = sums[(uint64_t)blockIdx.x * 256 + threadIdx.x];
+    for (uint32_t tb = t0; tb < t1; tb += kBatch) {
+        uint32_t x[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            if (tb + i < t1) hist[(uint64_t)(tb + i) * 256 + threadIdx.x] = run;
+            run += x[i];
+        }
+    }
+}
+
+template <class WT>
+__global__ __launch_bounds__(kWideThreads) void induce_wide_scatter_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev, int mode,
+    uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs /* [tile][256] */,
+    const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA, WT *__restrict__ WN,
+    uint8_t *__restrict__ BW, uint32_t min_len)
+{
+    __shared__ uint64_t swnd[kWideTile]; // the tile's output in bucket order: windows first, then reused for the positions;
+                                         // the per-wave counters live here while the entries are still in registers
+    __shared__ uint8_t sdig[kWideTile];  // bucket of every staged slot
+    __shared__ uint32_t goff[256];       // destination of the bucket's first staged slot, minus (plus) that slot
+    __shared__ uint32_t scan_lds[kWideWaves];
+    uint32_t *wcount = reinterpret_cast<uint32_t *>(swnd);
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const uint32_t base_d = t < 256 ? cursor_cur[t] : 0u;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        for (int i = t; i < kWideWaves * 256; i += kWideThreads) wcount[i] = 0;
+        const uint32_t pre = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // asked for now, needed after the ranking
+        __syncthreads();
+        const uint32_t wave0 = tile * (uint32_t)kWideTile + (uint32_t)w * (kWave * kWideItems);
+        uint32_t val[kWideItems], lpos[kWideItems]; // position - 1; [12:0] rank, then staged slot, [31:16] bucket, bit 15: taken
+        WT wnd[kWideItems];
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            val[k] = 0;
+            wnd[k] = 0;
+            bool ok = false;
+            uint32_t dig = 0;
+            if (i < len) {
+                const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                const uint32_t p = srcP[idx];
+                const WT ww = srcW[idx];
+                if (p != 0) {
+                    dig = wnd_first<WT>(ww, cfg);
+                    ok = induce_accept(dig, c, mode);
+                    val[k] = p - 1u;
+                    wnd[k] = wnd_pop<WT>(ww, cfg);
+                }
+            }
+            lpos[k] = ok ? (dig & 0xFFu) << 16 | 0x8000u : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k) {
+            const bool ok = (lpos[k] & 0x8000u) != 0;
+            lpos[k] |= wave_rank_inorder<8, false>(lpos[k] >> 16, ok, wcount + w * 256);
+        }
+        __syncthreads();
+        {
+            uint32_t tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int ww = 0; ww < kWideWaves; ++ww) {
+                    const uint32_t x = wcount[ww * 256 + t];
+                    wcount[ww * 256 + t] = tot;
+                    tot += x;
+                }
+            }
+            const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
+            if (lane == kWave - 1) scan_lds[w] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
+            const uint32_t ex = base + inc - tot; // the bucket's first staged slot
+            if (t < 256) {
+#pragma unroll
+                for (int ww = 0; ww < kWideWaves; ++ww) wcount[ww * 256 + t] += ex;
+                // staged slot i of bucket t lands at goff + i (L pass) / goff - i (S pass)
+                goff[t] = dir > 0 ? base_d + pre - ex : base_d - 1u - pre + ex;
+            }
+        }
+        __syncthreads();
+        uint32_t produced = 0;
+        for (int ww = 0; ww < kWideWaves; ++ww) produced += scan_lds[ww];
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k)
+            if (lpos[k] & 0x8000u) lpos[k] = (lpos[k] & 0xFFFF0000u) | 0x8000u | ((lpos[k] & 0x1FFFu) + wcount[w * 256 + (lpos[k] >> 16)]);
+        __syncthreads(); // the counters are part of the staging image
+        // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
+        // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
+        // a seventh of the entries of a byte alphabet, 16 to a thread).
+        {
+            WT fresh[kWideItems];
+            uint32_t dry = 0;
+#pragma unroll
+            for (int k = 0; k < kWideItems; ++k) {
+                fresh[k] = 0;
+                if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) {
+                    dry |= 1u << k;
+                    fresh[k] = wnd_fill<WT>(T, val[k], cfg);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kWideItems; ++k)
+                if ((dry >> k) & 1u) wnd[k] = fresh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k) {
+            if (lpos[k] & 0x8000u) {
+                const uint32_t slot = lpos[k] & 0x1FFFu;
+                swnd[slot] = (uint64_t)wnd[k];
+                sdig[slot] = (uint8_t)(lpos[k] >> 16);
+            }
+        }
+        __syncthreads();
+        uint32_t dstv[kWideItems];
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
+            dstv[k] = 0;
+            if (i < produced) {
+                const WT nw = (WT)swnd[i];
+                const uint32_t g = goff[sdig[i]];
+                dstv[k] = dir > 0 ? g + i : g - i;
+                WN[dstv[k]] = nw;
+                BW[dstv[k]] = wnd_symbol<WT>(nw, cfg);
+            }
+        }
+        __syncthreads();
+        uint32_t *sval = reinterpret_cast<uint32_t *>(swnd);
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k)
+            if (lpos[k] & 0x8000u) sval[lpos[k] & 0x1FFFu] = val[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kWideItems; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
+            if (i < produced) SA[dstv[k]] = sval[i];
+        }
+        __syncthreads(); // LDS is reused by the next tile
+    }
+}
+
 // ---- one round = one launch -----------------------------------------------------------
 // Stable multi-way split of the entries in range_in (read from device memory, so rounds
 // can be queued without the host knowing their sizes): entry p with window w induces
@@ -943,7 +1256,9 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 {
     // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + symbol bytes + control block
     const uint64_t ntiles = (N + kIndTile - 1) / kIndTile + 1;
-    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 + 16384;
+    const uint64_t wtiles = N / 8192 + 4; // wide alphabets: [tile][256] counts of 8192-entry tiles + chunk sums
+    return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 +
+           (sigma > 8 ? (size_t)(wtiles + wtiles / 256 + 4) * 1024 + 512 : 0) + 16384;
 }
 
 namespace {
@@ -962,7 +1277,9 @@ template <class WT> struct induce_state {
     uint32_t *run_len;   // symbols a device-wide run jump covers
     uint64_t *status;
     uint32_t chain_max; // rounds up to this many entries take the chained launch
-    uint32_t *hist;   // [nk][stride] tile counts of the three-launch form
+    uint32_t *hist;   // [nk][stride] tile counts of the three-launch form (at most 8 buckets)
+    uint32_t *whist;  // [tile][256] the same for wide alphabets, tiles of 8192 entries
+    uint32_t *wsums;  // [chunk][256] column sums of chunks of 256 tiles
     uint32_t stride;
     uint32_t nk;
     int small_alphabet;
@@ -986,20 +1303,16 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     // a round that turns out longer is still handled, by the chained form alone if need be.
     const bool both = (uint64_t)tiles_likely * kIndTile > st.chain_max;
     const uint32_t chain_max = both ? st.chain_max : ~0u;
-    if (both) {
+    if (both && st.small_alphabet) {
         // the round may be a large one: queue the three-launch form as well
         // (entries of the suffix array have their symbol bytes next to them; the LMS seeds only their windows)
         const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
         const uint64_t src_len = srcP == st.SA ? st.N : st.m;
-        if (st.small_alphabet)
-            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
-        else
-            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcW, srcB,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
+                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
-        if (st.small_alphabet) {
+        {
 #define SX_SCATTER_SMALL(M)                                                                                            \
     sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_small_kernel<WT, M>, dim3(grid), dim3(kBlock), srcP, srcW, \
               (const uint32_t *)rin, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, st.SA, st.WN, st.BW, st.nk, \
@@ -1011,14 +1324,30 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
             default: SX_SCATTER_SMALL(MODE_S_FROM_L); break;
             }
 #undef SX_SCATTER_SMALL
-        } else if (st.nk <= 32) // five ballots per match instead of eight
-            sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 5>, dim3(grid), dim3(kBlock), srcP, srcW,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
-                      st.SA, st.WN, st.BW, st.nk, chain_max);
-        else
-            sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_kernel<WT, 8>, dim3(grid), dim3(kBlock), srcP, srcW,
-                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.hist, st.stride, cur, dir,
-                      st.SA, st.WN, st.BW, st.nk, chain_max);
+        }
+    }
+    if (both && !st.small_alphabet) {
+        // wide alphabets: the round as a radix pass over tiles of 8192 entries (count, offsets, scatter)
+        const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
+        const uint32_t wtiles = sx_div_up((uint64_t)(tiles_bound < 1 ? 1 : tiles_bound) * kIndTile, kWideTile);
+        const uint32_t wgrid = wtiles > 2048 ? 2048 : wtiles;
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_wide_count_kernel<WT>, dim3(wgrid), dim3(kWideThreads), srcW, srcB,
+                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.whist, chain_max);
+        if (wtiles <= 512) {
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_offsets_kernel, dim3(1), dim3(kBlock), st.whist,
+                      (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
+        } else {
+            const uint32_t nchunks = sx_div_up(wtiles, kWideChunk);
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 1024, induce_wide_colsum_kernel, dim3(nchunks), dim3(kBlock),
+                      (const uint32_t *)st.whist, (const uint32_t *)rin, st.wsums, chain_max);
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)nchunks * 2048, induce_wide_bases_kernel, dim3(1), dim3(kBlock), st.wsums,
+                      (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_apply_kernel, dim3(nchunks), dim3(kBlock), st.whist,
+                      (const uint32_t *)rin, (const uint32_t *)st.wsums, chain_max);
+        }
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_wide_scatter_kernel<WT>, dim3(wgrid), dim3(kWideThreads), srcP, srcW,
+                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.whist, cur, dir, st.SA, st.WN, st.BW,
+                  chain_max);
     }
     uint32_t cgrid = grid > 1024 ? 1024 : grid;
     if (st.small_alphabet)
@@ -1165,15 +1494,23 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     // look-back status words: one per (tile, bucket) of the largest round
     // The look-back walk costs a few microseconds per tile, so long rounds are better off with
     // the three launches: beyond 256 tiles when a wave walks back for each of <= 8 buckets,
-    // beyond 2048 tiles with one thread per bucket (wide alphabets have short rounds -- a bucket
-    // holds ~N/sigma entries -- that are latency-bound either way; three launches cost more:
-    // measured 183 vs 163 ms at sigma = 256, 1 GiB).
+    // With more than 8 buckets every round beyond what the tail kernel takes (8192 entries) goes to the radix-pass
+    // form (induce_wide_*): one look-back thread per bucket and tile made a 2 M-entry round of a 255-symbol text cost
+    // 100 us and more.
     st.chain_max = ctx->chain_max_override >= 0 ? (uint32_t)ctx->chain_max_override
-                                                : (st.small_alphabet ? 256u : 2048u) * (uint32_t)kIndTile;
+                                                : (st.small_alphabet ? 256u * (uint32_t)kIndTile : kTailEntries);
     const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 2) * nk + kChainHeader; // any round may be chained
     st.stride = sx_div_up(largest, kIndTile) + 1;
-    st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
-    if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
+    st.hist = st.whist = st.wsums = nullptr;
+    if (st.small_alphabet) {
+        st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
+        if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
+    } else {
+        const size_t wt = (size_t)sx_div_up(largest, kWideTile) + 2;
+        st.whist = arena.take<uint32_t>(wt * 256);
+        st.wsums = arena.take<uint32_t>((wt / kWideChunk + 2) * 256);
+        if (!st.whist || !st.wsums) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
+    }
     SX_TRY(sx_chain_slab(ctx, SX_SLAB_CHAIN, status_words * 8));
     st.status = (uint64_t *)ctx->slab[SX_SLAB_CHAIN].p;
     SX_CHECK(hipMemsetAsync(st.status, 0, sizeof(uint64_t), ctx->stream)); // the time-out word

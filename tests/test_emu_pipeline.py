@@ -153,16 +153,31 @@ def test_very_long_run(emu_ctx):
 
 
 def test_both_induce_round_forms(emu_ctx):
-    """large rounds (count / offsets / scatter launches) and small rounds (one chained launch)"""
+    """large rounds (count / offsets / scatter launches; for more than 8 buckets the radix-pass form over tiles of 8192
+    entries, with its one-launch and its three-launch offsets) and small rounds (one chained launch, the tail kernel)"""
     rng = np.random.default_rng(12)
     x = np.concatenate([np.full(5000, 1, np.uint8), rng.integers(1, 5, size=9000, dtype=np.uint8)])
     want = oracle.sa_is(x, 5)
+    y = rng.integers(1, 12, size=60000, dtype=np.uint8)  # 11 symbols: 32-bit windows, buckets of ~5500 entries
+    y[20000:20040] = y[100:140]
+    want_y = oracle.sa_is(y, 12)
+    z = rng.integers(1, 40, size=30000, dtype=np.uint8)  # 39 symbols: 64-bit windows
+    z[10000:13000] = 7                                   # a bucket of 3000 entries with a long run
+    want_z = oracle.sa_is(z, 40)
     try:
         for thr in (0, 2048, 5000, 1 << 19):
             emu_ctx.set_chain_max_entries(thr)
             assert (_sa(emu_ctx, x, 5) == want).all(), thr
+        for thr in (0, 1000, -1):
+            emu_ctx.set_chain_max_entries(thr)
+            emu_ctx.set_no_direct_sort(True)
+            for t, sg, w in ((y, 12, want_y), (z, 40, want_z)):
+                sa, bw = np.zeros(t.size + 1, np.uint32), np.zeros(t.size + 1, np.uint8)
+                emu_ctx.sa_bwt_build_dev(t, t.size, sg, sa, bw)
+                assert (sa == w).all() and (bw == oracle.bwt(t, w)).all(), (thr, sg)
     finally:
-        emu_ctx.set_chain_max_entries(256 * 2048)
+        emu_ctx.set_chain_max_entries(-1)
+        emu_ctx.set_no_direct_sort(False)
 
 
 def test_bwt_tables(emu_ctx, golden):

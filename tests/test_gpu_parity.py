@@ -245,13 +245,19 @@ def test_both_induce_round_forms(gpu_ctx):
     want = oracle.sa_is(x, 5)
     y = synth(1 << 20, 200, 78)
     want_y = oracle.sa_is(y, 200)
+    z = synth(1 << 22, 12, 79)  # 11 symbols: 32-bit windows, buckets of 380 k entries (the radix-pass form, 47 tiles a round)
+    z[1_000_000:1_020_000] = 3  # and a run that keeps the tail kernel busy
+    want_z = oracle.sa_is(z, 12)
     try:
-        for thr in (0, 1 << 14, 1 << 30):
+        for thr in (0, 1 << 14, 1 << 30, -1):
             gpu_ctx.set_chain_max_entries(thr)
+            gpu_ctx.set_no_direct_sort(True)
             assert (gpu_ctx.sa_build(x, 5) == want).all(), thr
             assert (gpu_ctx.sa_build(y, 200) == want_y).all(), thr
+            assert (gpu_ctx.sa_build(z, 12) == want_z).all(), thr
     finally:
-        gpu_ctx.set_chain_max_entries(256 * 2048)
+        gpu_ctx.set_chain_max_entries(-1)
+        gpu_ctx.set_no_direct_sort(False)
 
 
 def test_long_runs(gpu_ctx):
@@ -589,6 +595,36 @@ def test_beyond_31_bits(gpu_ctx):
 
 
 # BASELINE.json configs[1..3] at their sizes: 256 MiB DNA, 1 GiB DNA (SA + BWT + C/O), 1 GiB sigma = 256.
+def test_induced_passes_of_wide_alphabets_at_size(gpu_ctx):
+    """LMS sort + induced-sort passes where the direct sort would apply, at sizes whose buckets take the radix-pass
+    round form with its one-launch offsets (255 symbols: 2 M entries a bucket) and its three-launch offsets (11
+    symbols: 12 M entries a bucket, 1500 tiles a round): suffix array, BWT and tables checked on the device"""
+    import torch
+    from stralg_amd import verify
+    try:
+        gpu_ctx.set_no_direct_sort(True)
+        for log2n, sigma in ((27, 12), (28, 256)):
+            n = 1 << log2n
+            N = n + 1
+            text = torch.empty(n, dtype=torch.uint8, device="cuda")
+            gpu_ctx.synth_dev(text, n, sigma, 5 + log2n)
+            sa = torch.empty(N, dtype=torch.int32, device="cuda")
+            bwt = torch.empty(N, dtype=torch.uint8, device="cuda")
+            gpu_ctx.sa_bwt_build_dev(text, n, sigma, sa, bwt)
+            assert gpu_ctx.last_stats()["lms_path"] == 1
+            tables = sigma <= 128
+            c = torch.zeros(sigma, dtype=torch.int32, device="cuda") if tables else None
+            o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda") if tables else None
+            if tables:
+                gpu_ctx.bwt_tables_from_bwt_dev(bwt, N, sigma, c, o)
+            gpu_ctx.trim()
+            verify.verify_build_on_device(text, n, sigma, sa, bwt, c, o)
+            del text, sa, bwt, c, o
+            torch.cuda.empty_cache()
+    finally:
+        gpu_ctx.set_no_direct_sort(False)
+
+
 @pytest.mark.parametrize("log2n,sigma", [(28, 5), (30, 5), (28, 256), (30, 256)])
 def test_full_size_properties(gpu_ctx, log2n, sigma):
     import torch
