@@ -16,6 +16,60 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+# ---- the AddressSanitizer run of the kernel harness (tests/test_emu_asan.py) -----------------------------------------
+# It repeats tests/test_emu_pipeline.py in a child process under the sanitizer, which takes four minutes: the child is
+# started as soon as the collection shows that the test is part of this run, works beside the other CPU tests on
+# another core, and the test itself only waits for it and reads its output.
+_asan = {"proc": None, "log": None, "skip": None}
+
+
+def start_asan_child():
+    if _asan["proc"] is not None or _asan["skip"] is not None:
+        return
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        _asan["skip"] = "no libasan in this toolchain"
+        return
+    import tempfile
+    log = tempfile.NamedTemporaryFile(prefix="stralg_asan_", suffix=".log", delete=False)
+    env = dict(os.environ, STRALG_EMU_ASAN="1", STRALG_ASAN_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0")
+    # build first (no preload: the compiler is not to be sanitized), then every kernel-level test of the harness once
+    # more with the sanitizer watching
+    cmd = ("make -s -C '%s' emu-asan && LD_PRELOAD=\"$STRALG_ASAN_PRELOAD\" '%s' -m pytest '%s' -x -q -p no:cacheprovider"
+           % (os.path.join(ROOT, "stralg_amd", "csrc"), sys.executable, os.path.join(ROOT, "tests", "test_emu_pipeline.py")))
+    _asan["log"] = log.name
+    _asan["proc"] = subprocess.Popen(["bash", "-c", cmd], env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
+
+
+def wait_asan_child(timeout=2400):
+    """(return code, output) of the sanitizer run, or (None, reason) when it cannot run here"""
+    start_asan_child()
+    if _asan["skip"] is not None:
+        return None, _asan["skip"]
+    rc = _asan["proc"].wait(timeout=timeout)
+    with open(_asan["log"]) as f:
+        out = f.read()
+    os.unlink(_asan["log"])
+    _asan["proc"] = None
+    return rc, out
+
+
+def pytest_collection_modifyitems(config, items):
+    # the test that collects the sanitizer child goes last: the child works while the others run
+    items.sort(key=lambda it: "test_kernels_under_address_sanitizer" in it.nodeid)
+
+
+def pytest_collection_finish(session):
+    if any("test_kernels_under_address_sanitizer" in it.nodeid for it in session.items):
+        start_asan_child()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _asan["proc"] is not None and _asan["proc"].poll() is None:  # (the run stopped early: -x)
+        _asan["proc"].kill()
+
+
 def golden_cases():
     """name -> dict(sym, sigma, sa[, raw, c, o, ro]) from tests/golden/golden.npz."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))

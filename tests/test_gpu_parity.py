@@ -439,6 +439,29 @@ def test_reference_named_c_api(gpu_ctx, golden):
     assert np.ctypeslib.as_array(b.contents.array, shape=(11,)).tolist() == [10, 0, 6, 2, 8, 4, 1, 7, 3, 9, 5]
     lib.free_suffix_array(a)
     lib.free_suffix_array(b)
+    # sa_is_mem_construction (sa_is_mem.c:471-494) and skew_sa_construction (skew.c:388-395) against the oracle, not
+    # against each other: a remapped text for the first, raw bytes (sigma = 256, skew.c:375) for the second
+    lib.sa_is_mem_construction.argtypes = [C.c_char_p, C.c_uint32]
+    lib.sa_is_mem_construction.restype = C.POINTER(SA)
+    for name in ("ref/mississippi", "ref/modest-proposal", "struct/fibonacci", "rand/s5/n65536"):
+        if name not in golden:
+            continue
+        c = golden[name]
+        buf = C.create_string_buffer(bytes(c["sym"]))
+        a = lib.sa_is_mem_construction(buf, c["sigma"])
+        assert (np.ctypeslib.as_array(a.contents.array, shape=(c["sa"].size,)) == c["sa"]).all(), name
+        lib.free_suffix_array(a)
+    x = synth(300_000, 5, 8)
+    buf = C.create_string_buffer(bytes(x))
+    want = oracle.sa_is(x, 5)
+    a = lib.sa_is_mem_construction(buf, 5)
+    assert (np.ctypeslib.as_array(a.contents.array, shape=(x.size + 1,)) == want).all()
+    lib.free_suffix_array(a)
+    raw = np.frombuffer(b"the modest proposal of a text with blanks, UPPER case and 8-bit bytes \xe9\xff " * 500, np.uint8)
+    buf = C.create_string_buffer(bytes(raw))
+    b = lib.skew_sa_construction(buf)
+    assert (np.ctypeslib.as_array(b.contents.array, shape=(raw.size + 1,)) == oracle.sa_is(raw, 256)).all()
+    lib.free_suffix_array(b)
 
 
 def test_next_rows_inverse_lcp_search(gpu_ctx, golden):
