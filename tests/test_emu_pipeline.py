@@ -240,6 +240,29 @@ def test_next_rows(emu_ctx, golden):
         emu_ctx.bwt_exact_search_dev(np.ascontiguousarray(c["c"]), np.ascontiguousarray(c["o"]), c["sa"].size, c["sigma"],
                                      pats, offs, lr.shape[0], l, r)
         assert (l == lr[:, 0]).all() and (r == lr[:, 1]).all(), name
+    # thousands of patterns at once: they are searched in the order of their last symbols (a radix sort of the pattern
+    # numbers); patterns of the text, mutated patterns, a one-symbol and an empty one, each against the oracle's search
+    x = synth(6000, 5, 9)
+    sa = oracle.sa_is(x, 5)
+    ct, ot = oracle.c_table(x, 5), oracle.o_table(x, sa, 5)
+    rng = np.random.default_rng(3)
+    pats, offs = [], [0]
+    for k in range(5000):
+        m = int(rng.integers(0, 24)) if k % 50 else int(k % 3 == 0)
+        a = int(rng.integers(0, x.size - 24))
+        pt = x[a:a + m].copy()
+        if k % 3 == 0 and m:
+            pt[int(rng.integers(0, m))] = int(rng.integers(1, 5))
+        pats.append(pt)
+        offs.append(offs[-1] + m)
+    flat = np.concatenate(pats).astype(np.uint8) if offs[-1] else np.zeros(1, np.uint8)
+    offs = np.array(offs, np.uint32)
+    l, r = np.zeros(5000, np.uint32), np.zeros(5000, np.uint32)
+    emu_ctx.bwt_exact_search_dev(np.ascontiguousarray(ct), np.ascontiguousarray(ot), sa.size, 5, flat, offs, 5000, l, r)
+    for k in range(0, 5000, 7):
+        want = oracle.bwt_exact_search(ct, ot, 5, pats[k])
+        got = (int(l[k]), int(r[k]))
+        assert got == want or (got[0] >= got[1] and want[0] >= want[1]), (k, got, want)
 
 
 def test_fasta_ingest_and_remap(emu_ctx, golden_fasta):

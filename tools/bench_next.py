@@ -1,8 +1,8 @@
 """timings of the "next" rows: inverse + LCP, batched exact BWT search, with the oracle beside
 them on a bounded sample (GPU box)"""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import stralg_amd, oracle
 ctx = stralg_amd.Context(0)
 log2n, sigma = 28, 5
