@@ -1262,6 +1262,12 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 }
 
 namespace {
+#ifndef SX_INDUCE_GRID_CAP
+#define SX_INDUCE_GRID_CAP 16384
+#endif
+// workgroups of a round's launches (they loop over the round's tiles).  1 GiB DNA, induce_scatter per step: 4096
+// workgroups 5.55 ms, 16384: 4.99, 65536: 5.06, 262144: 5.12 (a device copy is fastest with many short workgroups too).
+constexpr uint32_t kInduceGridCap = SX_INDUCE_GRID_CAP;
 constexpr int kMaxSpec = 16; // rounds queued per batch (then the tail kernel) before the host looks at the range
 
 template <class WT> struct induce_state {
@@ -1293,7 +1299,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
 {
     sx_ctx *ctx = st.ctx;
     uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
-    if (grid > 4096) grid = 4096; // tiles are handed out by ticket: any grid size is correct
+    if (grid > kInduceGridCap) grid = kInduceGridCap; // (every kernel loops over its tiles: any grid size is correct)
     const uint32_t epoch = sx_chain_next_epoch(ctx);
     uint32_t *rin = st.ranges + 2 * range_slot;
     uint32_t *rout = out_slot >= 0 ? st.ranges + 2 * out_slot : nullptr;

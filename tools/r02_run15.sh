@@ -1,0 +1,11 @@
+#!/bin/bash
+# O-table kernel variants
+cd "${GRAFT_REPO_ROOT:-.}"
+for v in "-DSX_OT_ROWS=4" "-DSX_OT_ROWS=8" "-DSX_OT_ROWS=4 -DSX_OT_PLAIN_STORES" "-DSX_OT_ROWS=8 -DSX_OT_PLAIN_STORES"; do
+  touch stralg_amd/csrc/sx_bwt.hip
+  make -s -C stralg_amd/csrc -j8 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off $v" 2>&1 | grep -E "error" | head -3
+  echo "== $v"
+  timeout 200 python bench.py --no-e2e --no-cpu --steps 5 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['verified'], {k:v['ms_per_step'] for k,v in d['kernels'].items() if k in ('otable','bwt_gather','induce_scatter')})"
+done
