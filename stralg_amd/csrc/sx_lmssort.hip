@@ -906,7 +906,10 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         ctx->stats.key_slots = C;
         ctx->stats.key_bits = (uint32_t)kbits;
         if (A <= cap - 1024) break;
-        if (attempt == 0 && C < Cmax) { // skewed symbol frequencies: once more with the longest key
+        // skewed symbol frequencies leave a good quarter of the suffixes tied: once more with the longest key.  With
+        // more than half of them tied the text repeats itself (words of a vocabulary, periods): a longer key would
+        // tie them again, so the general path takes over without the second sort (8 passes over all pairs).
+        if (attempt == 0 && C < Cmax && (uint64_t)A * 2 <= m) {
             C = Cmax;
             continue;
         }

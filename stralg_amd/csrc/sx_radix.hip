@@ -65,7 +65,14 @@ __global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restr
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = base + (uint64_t)k * kRT + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+        const uint32_t d = i < n ? (uint32_t)(keys[i] >> shift) & mask : 0u;
+        // (a wave of equal digits adds once: see radix_hist_digits_kernel)
+        const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        if (__all((i < n && d == lead) ? 1 : 0)) {
+            if (lane_id() == 0) atomicAdd(&h[d], (uint32_t)kWave);
+        } else if (i < n) {
+            atomicAdd(&h[d], 1u);
+        }
     }
     __syncthreads();
     for (int i = (int)threadIdx.x; i < ND; i += kRT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
@@ -83,18 +90,36 @@ __global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const typename r
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)threadIdx.x * kRadixItems;
     static_assert(kRadixItems == 16, "16 digits per thread: one or two 16-byte loads");
-    if (base + 16 <= n) {
-        if (DB == 8) {
+    const bool full = base + 16 <= n;
+    if (DB == 8) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (full) {
             const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+        }
+        // Sorted or repetitive input (the keys of a tie-refinement round, a periodic text) has long runs of one
+        // digit, and 64 lanes adding to one LDS word are served one after the other: a wave whose 1024 digits are
+        // all the same adds once, a thread whose 16 digits are adds once (250 us a pass for 10^8 equal keys before).
+        // (The wave-wide tests are reached by every lane: no collective under a branch.)
+        const uint32_t first = w[0] & 0xFFu, rep = first * 0x01010101u;
+        const bool mono = full && w[0] == rep && w[1] == rep && w[2] == rep && w[3] == rep;
+        const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        const bool wave_mono = __all((mono && first == lead) ? 1 : 0);
+        if (wave_mono) {
+            if (lane_id() == 0) atomicAdd(&h[first], 16u * kWave);
+        } else if (mono) {
+            atomicAdd(&h[first], 16u);
+        } else if (full) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
         } else {
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(dig + base), v1 = *reinterpret_cast<const uint4 *>(dig + base + 8);
-            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 1] >> (16 * (k & 1))) & (uint32_t)(ND - 1)], 1u);
+            for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
         }
+    } else if (full) {
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(dig + base), v1 = *reinterpret_cast<const uint4 *>(dig + base + 8);
+        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 1] >> (16 * (k & 1))) & (uint32_t)(ND - 1)], 1u);
     } else {
         for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
     }
@@ -166,6 +191,39 @@ __global__ __launch_bounds__(ND) void radix_apply_kernel(uint32_t *__restrict__ 
 #pragma unroll
         for (int i = 0; i < kColBatch; ++i) {
             if (tb + i < t1) hist[(uint64_t)(tb + i) * ND + threadIdx.x] = run;
+            run += x[i];
+        }
+    }
+}
+
+// The three table kernels in one for sorts of at most kRadixChunk tiles (2 M pairs): one workgroup, a thread per
+// digit.  A pass of a small sort is all launch and latency (five dependent launches: ~100 us for 10^6 pairs; the tie
+// refinement of a repetitive text runs sixty such passes), so three of its launches become one.
+template <int ND>
+__global__ __launch_bounds__(ND) void radix_offsets_small_kernel(uint32_t *__restrict__ hist, uint32_t ntiles)
+{
+    __shared__ uint32_t lds[ND / kWave];
+    const uint32_t d = threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t tb = 0; tb < ntiles; tb += kColBatch) {
+        uint32_t x[kColBatch];
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < ntiles ? hist[(uint64_t)(tb + i) * ND + d] : 0u;
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) total += x[i];
+    }
+    const uint32_t inc = wave_inclusive_scan<OpAdd>(total);
+    if (lane_id() == kWave - 1) lds[wave_id()] = inc;
+    __syncthreads();
+    uint32_t run = inc - total; // keys with a smaller digit
+    for (int i = 0; i < wave_id(); ++i) run += lds[i];
+    for (uint32_t tb = 0; tb < ntiles; tb += kColBatch) {
+        uint32_t x[kColBatch];
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) x[i] = tb + i < ntiles ? hist[(uint64_t)(tb + i) * ND + d] : 0u;
+#pragma unroll
+        for (int i = 0; i < kColBatch; ++i) {
+            if (tb + i < ntiles) hist[(uint64_t)(tb + i) * ND + d] = run;
             run += x[i];
         }
     }
@@ -371,12 +429,16 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
                       mask, hist, ntiles);
         else
             sx_launch(ctx, SX_KC_RADIX_HIST, n * dig_bytes, radix_hist_digits_kernel<DB>, dim3(ntiles), dim3(kRT), (const dig_t *)dig, n, hist);
-        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 4, radix_colsum_kernel<ND>, dim3(nchunks), dim3(ND),
-                  (const uint32_t *)hist, ntiles, sums);
-        sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks * ND * 8, radix_bases_kernel<ND>, dim3(1), dim3(ND), sums, nchunks,
-                  digit_base);
-        sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 8, radix_apply_kernel<ND>, dim3(nchunks), dim3(ND), hist, ntiles,
-                  (const uint32_t *)sums, (const uint32_t *)digit_base);
+        if (nchunks == 1) {
+            sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 12, radix_offsets_small_kernel<ND>, dim3(1), dim3(ND), hist, ntiles);
+        } else {
+            sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 4, radix_colsum_kernel<ND>, dim3(nchunks), dim3(ND),
+                      (const uint32_t *)hist, ntiles, sums);
+            sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks * ND * 8, radix_bases_kernel<ND>, dim3(1), dim3(ND), sums, nchunks,
+                      digit_base);
+            sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 8, radix_apply_kernel<ND>, dim3(nchunks), dim3(ND), hist, ntiles,
+                      (const uint32_t *)sums, (const uint32_t *)digit_base);
+        }
         if (values_are_indices && shift == begin_bit)
             sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (20 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true>,
                       dim3(((ntiles + 7) / 8) * 8), dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
