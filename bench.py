@@ -189,11 +189,16 @@ def end_to_end(ctx, sizes, seed):
         res = {"sx_build_tables_ms": round(best * 1e3, 1), "pcie_GBps": round(moved / best / 1e9, 2),
                "sx_build_tables_Msuffixes_per_s": round(N / best / 1e6, 1)}
         for key, rev in (("build_complete_table_ms", False), ("with_ro_ms", True)):
-            t0 = time.perf_counter()
-            t = lib.build_complete_table(letters, rev)
-            dt = time.perf_counter() - t0
-            lib.completely_free_bwt_table(t)
-            res[key] = round(dt * 1e3, 1)
+            best = None
+            for _ in range(2):  # (the first call of a size pays the host's first touch of 30 GiB of result arrays)
+                t0 = time.perf_counter()
+                t = lib.build_complete_table(letters, rev)
+                dt = time.perf_counter() - t0
+                lib.completely_free_bwt_table(t)
+                best = dt if best is None else min(best, dt)
+                if rev:
+                    break
+            res[key] = round(best * 1e3, 1)
         res["build_complete_table_Msuffixes_per_s"] = round(N / (res["build_complete_table_ms"] * 1e-3) / 1e6, 1)
         res["bytes_over_pcie"] = moved
         out[f"2^{log2n}"] = res
