@@ -152,6 +152,24 @@ def test_very_long_run(emu_ctx):
     assert (_sa(emu_ctx, y, 5) == oracle.sa_is(y, 5)).all()
 
 
+def test_runs_of_many_lengths(emu_ctx):
+    """poly-A tracts and runs of every symbol with lengths 1 ... 60 scattered over a random text: the shrinking rounds of
+    a bucket, where entries leave after different numbers of rounds (the tail kernel takes eight rounds at once from
+    the entries' windows; the all-in-a-run jump never applies here), for 4, 5 and 7 symbols"""
+    rng = np.random.default_rng(21)
+    for sigma in (5, 6, 8):
+        n = 30000
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        starts = rng.integers(0, n - 64, size=n // 40)
+        lens = rng.integers(1, 61, size=starts.size)
+        syms = rng.integers(1, sigma, size=starts.size)
+        for a, l, c in zip(starts.tolist(), lens.tolist(), syms.tolist()):
+            x[a:a + l] = c
+        x[:50] = 1  # a run at the very start of the text (windows shorter than the batch)
+        x[n - 45:] = sigma - 1
+        assert (_sa(emu_ctx, x, sigma) == oracle.sa_is(x, sigma)).all(), sigma
+
+
 def test_both_induce_round_forms(emu_ctx):
     """large rounds (count / offsets / scatter launches; for more than 8 buckets the radix-pass form over tiles of 8192
     entries, with its one-launch and its three-launch offsets) and small rounds (one chained launch, the tail kernel)"""

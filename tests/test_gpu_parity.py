@@ -238,6 +238,24 @@ def test_hybrid_prefix_sort(gpu_ctx):
         gpu_ctx.set_radix_digit_bits(0)
 
 
+def test_runs_of_many_lengths(gpu_ctx):
+    """poly-A tracts and runs of every symbol with lengths 1 ... 60 scattered over a random text: the shrinking rounds of
+    a bucket, where entries leave after different numbers of rounds (the tail kernel takes eight rounds at once from
+    the entries' windows; the all-in-a-run jump never applies here), for 4, 5 and 7 symbols"""
+    rng = np.random.default_rng(21)
+    for sigma in (5, 6, 8):
+        n = 3000000
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        starts = rng.integers(0, n - 64, size=n // 40)
+        lens = rng.integers(1, 61, size=starts.size)
+        syms = rng.integers(1, sigma, size=starts.size)
+        for a, l, c in zip(starts.tolist(), lens.tolist(), syms.tolist()):
+            x[a:a + l] = c
+        x[:50] = 1  # a run at the very start of the text (windows shorter than the batch)
+        x[n - 45:] = sigma - 1
+        assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is(x, sigma)).all(), sigma
+
+
 def test_both_induce_round_forms(gpu_ctx):
     """every round through the chained launch (look-back across up to thousands of tiles), every round
     through the three-launch form, and the default mix"""
