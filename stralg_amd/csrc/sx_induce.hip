@@ -1226,6 +1226,267 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
     }
 }
 
+// ---- the same for at most 8 buckets, without a ballot ---------------------------------------------------------
+// The ranking of the kernel above costs ~30 vector instructions per entry and round (a match over the wave), and a
+// workgroup of 16 waves issues them one wave at a time: 4 us a round.  With at most 8 buckets a thread can count on
+// its own: it holds 8 *consecutive* entries of the scan order, counts their buckets in the 8-bit fields of one
+// register pair (the rank inside the thread is the field's value at that moment), and the fields, widened to 16 bits,
+// are prefix-summed over the workgroup as two 64-bit words (as induce_scatter_small does).  And because an entry's
+// window already says where its descendants of the next rounds go -- the j-th symbol to its left is the bucket of the
+// j-th one, and they exist as long as the symbols before were c -- up to kTailBatch rounds are taken in one step
+// (when the range shrinks slowly: poly-A tracts and microsatellites of differing lengths, where the all-in-a-run jump
+// never applies): one set of counters per round, one prefix over threads and rounds, one scatter.
+constexpr int kTailBatch = 8;
+template <class WT>
+__global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t *SA, WT *WN, uint8_t *BW,
+                                                                       const uint32_t *__restrict__ range_in,
+                                                                       uint32_t *__restrict__ range_out, int rev, int mode,
+                                                                       uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
+                                                                       const uint32_t *__restrict__ cursor_cur,
+                                                                       uint32_t *__restrict__ cursor_nxt, int dir,
+                                                                       uint32_t max_iters)
+{
+    constexpr uint64_t kField16 = 0x00FF00FF00FF00FFull;
+    __shared__ uint64_t wsum[kTailBatch][2][kTailWaves];  // per round and half (even / odd buckets): the waves' totals, then their prefix
+    __shared__ uint32_t s_tot[kTailBatch][8], s_base[kTailBatch][8];
+    __shared__ uint32_t gbase[8];
+    __shared__ uint32_t s_range[2];
+    __shared__ uint32_t s_flag;
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    if (t < 8) gbase[t] = cursor_cur[t];
+    if (t == 0) {
+        s_range[0] = range_in[0];
+        s_range[1] = range_in[1];
+    }
+    __syncthreads();
+    const uint32_t B = cfg.B, cmask = cfg.mask;
+    uint32_t val[kIndItems]; // entries t * per .. t * per + per - 1 of the range as it was loaded, in scan order
+    WT wnd[kIndItems];
+    uint32_t live = 0;       // bit k: entry k belongs to the current range
+    uint32_t per = kIndItems; // entries a thread took when the range was loaded: as few as spread it over all the threads
+    bool held = false;
+    uint32_t prev_len = 0, last_in = ~0u; // the range of the round before (for the jump); of the last step taken (for the batch)
+    for (uint32_t it = 0; it < max_iters;) {
+        const uint32_t lo = s_range[0], len = s_range[1] - lo;
+        if (len == 0 || len > kTailEntries) break; // uniform
+        // ---- run jump (as in induce_tail_kernel) --------------------------------------------------------------------
+        if (len == prev_len) {
+            const uint32_t G = len <= (uint32_t)kTailBlock ? (uint32_t)kTailBlock / len : 1u; // threads per entry
+            const uint32_t L = 16u * G;
+            const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
+            bool all_c = true;
+            for (uint32_t e = (uint32_t)t; e < len * G; e += kTailBlock) {
+                const uint32_t i = e / G, q = e % G;
+                const uint32_t p = SA[lo + (rev ? len - 1u - i : i)];
+                if (p < 16u * (q + 1u)) {
+                    all_c = false;
+                } else {
+                    uint64_t o0, o1;
+                    load_bytes16(T, (uint64_t)(p - 16u * (q + 1u)), o0, o1);
+                    if (o0 != cpat || o1 != cpat) all_c = false;
+                }
+            }
+            if (t == 0) s_flag = 1;
+            __syncthreads();
+            if (!all_c) s_flag = 0; // benign race: every writer stores 0
+            __syncthreads();
+            if (s_flag) { // uniform
+                const uint32_t cur = gbase[c], total = L * len;
+                for (uint32_t o = (uint32_t)t; o < total; o += kTailBlock) {
+                    const uint32_t j = o / len + 1u, i = o % len;
+                    const uint32_t v = SA[lo + (rev ? len - 1u - i : i)] - j;
+                    const uint32_t dst = dir > 0 ? cur + o : cur - 1u - o;
+                    const WT nw = v ? wnd_fill<WT>(T, v, cfg) : (WT)0;
+                    SA[dst] = v;
+                    WN[dst] = nw;
+                    BW[dst] = wnd_symbol<WT>(nw, cfg);
+                }
+                __syncthreads();
+                if ((uint32_t)t == c) {
+                    gbase[c] = dir > 0 ? cur + total : cur - total;
+                    s_range[0] = dir > 0 ? cur + total - len : cur - total;
+                    s_range[1] = dir > 0 ? cur + total : cur - total + len;
+                }
+                held = false; // the range is now what the jump wrote last
+                ++it;
+                __syncthreads();
+                continue;
+            }
+        }
+        prev_len = len;
+        if (!held) { // the range's entries from memory (the first round of a launch, or after a jump)
+            live = 0;
+            // (a range of 1700 entries as 8 to a thread would keep four waves busy, one to a SIMD, every wait of theirs
+            // in the open: two to a thread spread it over all sixteen)
+            per = (len + (uint32_t)kTailBlock - 1u) / (uint32_t)kTailBlock;
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                const uint32_t i = (uint32_t)t * per + (uint32_t)k;
+                val[k] = 0;
+                wnd[k] = 0;
+                if ((uint32_t)k < per && i < len) {
+                    const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                    val[k] = SA[idx];
+                    wnd[k] = WN[idx];
+                    live |= 1u << k;
+                }
+            }
+            held = true;
+        }
+        // rounds of this step: eight when the last step kept at least an eighth of its entries (runs), else one
+        const uint32_t nr = (uint64_t)len * 8 >= last_in ? (uint32_t)kTailBatch : 1u; // uniform
+        last_in = len;
+        if (nr > 1) { // windows that do not reach nr + 1 symbols deep are refilled first, all of a thread's refills in flight together
+            WT fresh[kIndItems];
+            uint32_t dry = 0;
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                fresh[k] = 0;
+                if ((uint32_t)k < per && ((live >> k) & 1u) && val[k] != 0) { // (k < per: uniform)
+                    const uint32_t need = val[k] < (uint32_t)(kTailBatch + 1) ? val[k] : (uint32_t)(kTailBatch + 1);
+                    if (wnd_count<WT>(wnd[k]) < need) {
+                        dry |= 1u << k;
+                        fresh[k] = wnd_fill<WT>(T, val[k], cfg);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k)
+                if ((dry >> k) & 1u) wnd[k] = fresh[k];
+        }
+        // A range of a few hundred entries keeps one or two waves busy; the others only take part in the barriers
+        // (every instruction a wave of this 16-wave workgroup issues costs the CU a slot).
+        const bool wave_live = __any(live != 0u ? 1 : 0); // uniform per wave
+        // ---- count: per round, the thread's entries per bucket (8-bit fields), and each entry's rank inside the thread ----
+        uint64_t cnt[kTailBatch];
+        uint32_t emask[kIndItems]; // bit j: the round-j descendant exists and is accepted; bits 8 + 3 j ..: its rank in the thread
+        uint32_t alive_after = 0;  // bit k: entry k's descendant of the last round stayed in bucket c
+        uint64_t ex0[kTailBatch], ex1[kTailBatch];
+#pragma unroll
+        for (int j = 0; j < kTailBatch; ++j) cnt[j] = 0, ex0[j] = 0, ex1[j] = 0;
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) emask[k] = 0;
+        if (wave_live) {
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                if ((uint32_t)k >= per) break; // uniform
+                bool alive = (live >> k) & 1u;
+                const WT codes = wnd[k] >> kCntBits;
+#pragma unroll
+                for (int j = 0; j < kTailBatch; ++j) {
+                    if ((uint32_t)j < nr) { // uniform
+                        const uint32_t sym = ((uint32_t)(codes >> (j * B)) & cmask) + 1u;
+                        const bool ok = alive && val[k] > (uint32_t)j && induce_accept(sym, c, mode);
+                        if (ok) {
+                            const uint32_t sh = 8u * (sym & 7u);
+                            emask[k] |= (1u << j) | (((uint32_t)(cnt[j] >> sh) & 7u) << (8 + 3 * j));
+                            cnt[j] += 1ull << sh;
+                        }
+                        alive = ok && sym == c;
+                    }
+                }
+                if (alive) alive_after |= 1u << k;
+            }
+            // ---- entries of earlier threads, per round and bucket: two 64-bit words of 16-bit fields, scanned over the workgroup ----
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) {
+                if ((uint32_t)j < nr) { // uniform
+                    uint64_t inc0 = cnt[j] & kField16, inc1 = (cnt[j] >> 8) & kField16;
+                    const uint64_t own0 = inc0, own1 = inc1;
+#pragma unroll
+                    for (int d = 1; d < kWave; d <<= 1) {
+                        const uint64_t a = __shfl_up(inc0, (unsigned)d, kWave), b = __shfl_up(inc1, (unsigned)d, kWave);
+                        if (lane >= d) inc0 += a, inc1 += b;
+                    }
+                    if (lane == kWave - 1) wsum[j][0][w] = inc0, wsum[j][1][w] = inc1;
+                    ex0[j] = inc0 - own0, ex1[j] = inc1 - own1;
+                }
+            }
+        } else if (lane < kTailBatch * 2) {
+            wsum[lane >> 1][lane & 1][w] = 0;
+        }
+        __syncthreads();
+        if (t < kTailBatch * 2 * kTailWaves) { // (round, half, wave): the 16 wave totals of a (round, half) scanned by 16 lanes
+            const int j = t / (2 * kTailWaves), h = (t / kTailWaves) & 1, ww = t % kTailWaves;
+            static_assert(kTailWaves == 16, "a (round, half) is scanned by a 16-lane segment");
+            const uint64_t own = (uint32_t)j < nr ? wsum[j][h][ww] : 0ull;
+            uint64_t inc = own;
+#pragma unroll
+            for (int d = 1; d < kTailWaves; d <<= 1) {
+                const uint64_t a = __shfl_up(inc, (unsigned)d, kTailWaves);
+                if ((lane & (kTailWaves - 1)) >= d) inc += a;
+            }
+            if ((uint32_t)j < nr) {
+                wsum[j][h][ww] = inc - own;
+                if (ww == kTailWaves - 1) { // the round's totals of four buckets
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) s_tot[j][2 * f + h] = (uint32_t)(inc >> (16 * f)) & 0xFFFFu;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < 8) { // the bucket's cursor before every round of the step
+            uint32_t b = gbase[t];
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) {
+                if ((uint32_t)j < nr) {
+                    s_base[j][t] = b;
+                    b = dir > 0 ? b + s_tot[j][t] : b - s_tot[j][t];
+                }
+            }
+            gbase[t] = b;
+            if ((uint32_t)t == c) { // the last round's entries for bucket c are the next range
+                const uint32_t sb = s_base[nr - 1u][t], n_last = s_tot[nr - 1u][t];
+                s_range[0] = dir > 0 ? sb : sb - n_last;
+                s_range[1] = dir > 0 ? sb + n_last : sb;
+            }
+        }
+        __syncthreads();
+        // ---- scatter ---------------------------------------------------------------------------------------------------
+        uint32_t live_next = 0;
+        if (wave_live) {
+#pragma unroll
+        for (int j = 0; j < kTailBatch; ++j) // entries of earlier waves: all of the step's reads in flight together
+            if ((uint32_t)j < nr) ex0[j] += wsum[j][0][w], ex1[j] += wsum[j][1][w];
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            if ((uint32_t)k >= per) break; // uniform
+            const WT codes = wnd[k] >> kCntBits;
+            const uint32_t wcnt = wnd_count<WT>(wnd[k]);
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) {
+                if ((uint32_t)j < nr && ((emask[k] >> j) & 1u)) {
+                    const uint32_t d = (((uint32_t)(codes >> (j * B)) & cmask) + 1u) & 7u;
+                    const uint64_t exw = (d & 1u) ? ex1[j] : ex0[j];
+                    const uint32_t r = ((uint32_t)(exw >> (16u * (d >> 1))) & 0xFFFFu) + ((emask[k] >> (8 + 3 * j)) & 7u);
+                    const uint32_t sb = s_base[j][d];
+                    const uint32_t dst = dir > 0 ? sb + r : sb - 1u - r;
+                    const uint32_t pos = val[k] - (uint32_t)(j + 1);
+                    WT nw = (((codes >> (j * B)) >> B) << kCntBits) | (WT)(wcnt - (uint32_t)(j + 1)); // j + 1 symbols popped
+                    if (pos != 0 && wcnt == (uint32_t)(j + 1)) nw = wnd_fill<WT>(T, pos, cfg); // window ran dry: back to the text
+                    SA[dst] = pos;
+                    WN[dst] = nw;
+                    BW[dst] = wnd_symbol<WT>(nw, cfg);
+                    if ((uint32_t)j == nr - 1u && ((alive_after >> k) & 1u)) { // stays in bucket c: the entry of the next step
+                        live_next |= 1u << k;
+                        val[k] = pos;
+                        wnd[k] = nw;
+                    }
+                }
+            }
+        }
+        }
+        live = live_next;
+        it += nr;
+        __syncthreads(); // (s_range, s_base and wsum are rewritten by the next step)
+    }
+    if (t < 8) cursor_nxt[t] = gbase[t];
+    if (t == 0) {
+        range_out[0] = s_range[0];
+        range_out[1] = s_range[1];
+    }
+}
+
 // ---- very long runs -------------------------------------------------------------------------------------
 // The tail kernel's run jump writes 4096 rounds a step with one workgroup: 11 us a step, 45 ms for the 16 Mi
 // symbols of a gap in a reference assembly (runs of N of up to 30 Mbp, one or more per chromosome, all in one
@@ -1498,7 +1759,7 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
     const uint32_t *cur = st.cursor[st.par];
     uint32_t *nxt = st.cursor[st.par ^ 1];
     if (st.small_alphabet)
-        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 3>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
+        sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_small_kernel<WT>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, kTailIters);
     else
