@@ -278,82 +278,6 @@ __global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__rest
     }
 }
 
-template <class WT, int BITS>
-__global__ __launch_bounds__(kBlock) void induce_scatter_kernel(
-    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev,
-    int mode, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs,
-    uint32_t stride, const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA,
-    WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t nkeys, uint32_t chain_max)
-{
-    __shared__ uint32_t wcount[kWavesPerBlock][256];
-    __shared__ uint32_t gpos[256]; // destination index of the tile's first entry, per bucket
-    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint32_t lo = range_in[0], len = range_in[1] - lo;
-    if (len <= chain_max) return;
-    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
-    const uint32_t base_d = t < (int)nkeys ? cursor_cur[t] : 0u;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
-        for (int i = t; i < kWavesPerBlock * 256; i += kBlock) (&wcount[0][0])[i] = 0;
-        __syncthreads();
-        // this tile's first destination per bucket: asked for now, needed after the ranking
-        const uint32_t pre = t < (int)nkeys ? offs[(uint64_t)t * stride + tile] : 0u;
-        const uint32_t wave0 = tile * (uint32_t)kIndTile + (uint32_t)w * (kWave * kIndItems);
-        uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
-        WT wnd[kIndItems];
-        bool ok[kIndItems];
-#pragma unroll
-        for (int k = 0; k < kIndItems; ++k) {
-            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
-            ok[k] = false;
-            dig[k] = 0;
-            val[k] = 0;
-            wnd[k] = 0;
-            if (i < len) {
-                const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                const uint32_t p = srcP[idx];
-                const WT ww = srcW[idx];
-                if (p != 0) {
-                    const uint32_t ch = wnd_first<WT>(ww, cfg);
-                    ok[k] = induce_accept(ch, c, mode);
-                    dig[k] = ch;
-                    val[k] = p - 1u;
-                    wnd[k] = wnd_pop<WT>(ww, cfg);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kIndItems; ++k) rnk[k] = wave_rank_step<BITS>(dig[k], ok[k], wcount[w]);
-        __syncthreads();
-        {
-            const uint32_t d = (uint32_t)t;
-            uint32_t sum = 0;
-#pragma unroll
-            for (int ww = 0; ww < kWavesPerBlock; ++ww) {
-                const uint32_t x = wcount[ww][d];
-                wcount[ww][d] = sum;
-                sum += x;
-            }
-            gpos[d] = dir > 0 ? base_d + pre : base_d - 1u - pre;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kIndItems; ++k) {
-            if (ok[k]) {
-                const uint32_t d = dig[k];
-                const uint32_t r = wcount[w][d] + rnk[k];
-                const uint32_t dst = dir > 0 ? gpos[d] + r : gpos[d] - r;
-                const uint32_t j = val[k];
-                WT nw = wnd[k];
-                if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
-                SA[dst] = j;
-                WN[dst] = nw;
-                BW[dst] = wnd_symbol<WT>(nw, cfg);
-            }
-        }
-        __syncthreads(); // LDS is reused by the next tile
-    }
-}
-
 // The scatter for at most 8 buckets (DNA, and every alphabet of up to 7 symbols): the ranking of
 // the general kernel above costs ~100 vector instructions per entry (a match over the wave per
 // item), which is what bounds it, not memory.  Here every thread owns 8 consecutive entries of
@@ -959,11 +883,6 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                                                              uint32_t max_iters)
 {
     constexpr int kDigits = BITS == 3 ? 8 : 256; // buckets that can receive anything
-    constexpr int kBatch = 8;                    // rounds taken at once when the entries are at hand (<= 8 buckets)
-    constexpr int kBW = BITS == 3 ? kTailWaves : 1, kBR = BITS == 3 ? kBatch : 1;
-    __shared__ uint32_t bcount[kBW][kBR][8]; // per wave, round of the batch and bucket: entries, then entries of earlier waves
-    __shared__ uint32_t brank[kBW][kBR][8];  // the same counters once more: the ranks are taken twice, not kept (registers)
-    __shared__ uint32_t s_tot[kBR][8], s_base[kBR][8], s_newbase[8];
     __shared__ uint32_t wcount[kTailWaves][kDigits];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t s_range[2];
@@ -975,7 +894,6 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         s_range[1] = range_in[1];
     }
     for (int i = t; i < kTailWaves * kDigits; i += kTailBlock) (&wcount[0][0])[i] = 0;
-    for (int i = t; i < kBW * kBR * 8; i += kTailBlock) (&bcount[0][0][0])[i] = 0, (&brank[0][0][0])[i] = 0;
     __syncthreads();
     // The entries a round appends to bucket c are the next round's input, in the order they were appended: the
     // threads that wrote them keep them (position, window) in registers, in place, so from the second round of a
@@ -984,7 +902,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
     WT wnd[kIndItems];
     bool live[kIndItems]; // entry k of this thread belongs to the current range (scan order: wave, k, lane)
     bool held = false;
-    uint32_t prev_len = 0, last_in = ~0u; // the range of the round before (for the jump); of the last step taken (for the batch)
+    uint32_t prev_len = 0; // the range of the round before (for the jump)
     const uint32_t wave0 = (uint32_t)w * (kWave * kIndItems);
     for (uint32_t it = 0; it < max_iters; ++it) {
         const uint32_t lo = s_range[0], len = s_range[1] - lo;
@@ -1039,116 +957,6 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
             }
         }
         prev_len = len;
-        // (taken when the last round kept at least an eighth of its entries: runs; a range that collapses is cheaper round by round)
-        if (BITS == 3 && held && (mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && (uint64_t)len * 8 >= last_in) { // uniform
-            // ---- kBatch rounds at once --------------------------------------------------------------------------------
-            // An entry's window already says what its descendants of the next rounds are: the j-th symbol to its left
-            // is where the j-th of them goes, and they exist as long as the symbols before were c.  So the entries at
-            // hand are walked kBatch symbols deep in one go: ranks per (round, bucket) in scan order, one prefix over
-            // waves and rounds, one scatter -- four barriers for eight rounds instead of four a round (a genome-like
-            // text spends 1800 rounds here: poly-A tracts and microsatellites whose lengths differ, so the all-in-a-run
-            // jump above never applies).
-            const uint32_t B = cfg.B, cmask = cfg.mask;
-            { // windows that do not reach kBatch + 1 symbols deep are refilled first, all of a thread's refills in flight together
-                WT fresh[kIndItems];
-                uint32_t dry = 0;
-#pragma unroll
-                for (int k = 0; k < kIndItems; ++k) {
-                    fresh[k] = 0;
-                    if (live[k] && val[k] != 0) {
-                        const uint32_t need = val[k] < (uint32_t)(kBatch + 1) ? val[k] : (uint32_t)(kBatch + 1);
-                        if (wnd_count<WT>(wnd[k]) < need) {
-                            dry |= 1u << k;
-                            fresh[k] = wnd_fill<WT>(T, val[k], cfg);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < kIndItems; ++k)
-                    if ((dry >> k) & 1u) wnd[k] = fresh[k];
-            }
-            uint32_t emask[kIndItems]; // bit j: the round-j descendant exists and is accepted; bit 16: alive after the batch
-#pragma unroll
-            for (int k = 0; k < kIndItems; ++k) {
-                bool alive = live[k];
-                emask[k] = 0;
-                const WT codes = wnd[k] >> kCntBits;
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const uint32_t sym = ((uint32_t)(codes >> (j * B)) & cmask) + 1u;
-                    const bool ok = alive && val[k] > (uint32_t)j && induce_accept(sym, c, mode);
-                    (void)wave_rank_step<3>(sym & 7u, ok, bcount[BITS == 3 ? w : 0][BITS == 3 ? j : 0]); // (counted; ranked below)
-                    if (ok) emask[k] |= 1u << j;
-                    alive = ok && sym == c;
-                }
-                if (alive) emask[k] |= 1u << 16;
-            }
-            __syncthreads();
-            if (t < kBatch * 8) { // (round, bucket): entries of earlier waves, and the total
-                const int j = t >> 3, d = t & 7;
-                uint32_t run = 0;
-#pragma unroll
-                for (int ww = 0; ww < kBW; ++ww) {
-                    const uint32_t x = bcount[ww][BITS == 3 ? j : 0][d];
-                    bcount[ww][BITS == 3 ? j : 0][d] = run;
-                    run += x;
-                }
-                s_tot[BITS == 3 ? j : 0][d] = run;
-            }
-            __syncthreads();
-            if (t < 8) { // the bucket's cursor before every round of the batch
-                uint32_t b = gbase[t];
-#pragma unroll
-                for (int j = 0; j < kBR; ++j) {
-                    s_base[j][t] = b;
-                    b = dir > 0 ? b + s_tot[j][t] : b - s_tot[j][t];
-                }
-                s_newbase[t] = b;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kIndItems; ++k) {
-                const WT codes = wnd[k] >> kCntBits;
-                const uint32_t cnt = wnd_count<WT>(wnd[k]);
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const bool ok = (emask[k] >> j) & 1u;
-                    const uint32_t d = (((uint32_t)(codes >> (j * B)) & cmask) + 1u) & 7u;
-                    const uint32_t rk = wave_rank_step<3>(d, ok, brank[BITS == 3 ? w : 0][BITS == 3 ? j : 0]); // (every lane: a wave-wide step)
-                    if (ok) {
-                        const uint32_t r = bcount[BITS == 3 ? w : 0][BITS == 3 ? j : 0][d] + rk;
-                        const uint32_t sb = s_base[BITS == 3 ? j : 0][d];
-                        const uint32_t dst = dir > 0 ? sb + r : sb - 1u - r;
-                        const uint32_t pos = val[k] - (uint32_t)(j + 1);
-                        WT nw = (((codes >> (j * B)) >> B) << kCntBits) | (WT)(cnt - (uint32_t)(j + 1)); // j + 1 symbols popped
-                        if (pos != 0 && cnt == (uint32_t)(j + 1)) nw = wnd_fill<WT>(T, pos, cfg); // (only near the start of the text)
-                        SA[dst] = pos;
-                        WN[dst] = nw;
-                        BW[dst] = wnd_symbol<WT>(nw, cfg);
-                    }
-                }
-                // what is left of the entry: its descendant of the last round, if that one stayed in bucket c
-                live[k] = (emask[k] >> 16) & 1u;
-                if (live[k]) {
-                    val[k] -= (uint32_t)kBatch;
-                    wnd[k] = (((codes >> ((kBatch - 1) * B)) >> B) << kCntBits) | (WT)(cnt - (uint32_t)kBatch);
-                }
-            }
-            __syncthreads();
-            if (t < 8) {
-                gbase[t] = s_newbase[t];
-                if ((uint32_t)t == c) { // the last round's entries for bucket c are the next range
-                    const uint32_t sb = s_base[kBR - 1][t], n_last = s_tot[kBR - 1][t];
-                    s_range[0] = dir > 0 ? sb : sb - n_last;
-                    s_range[1] = dir > 0 ? sb + n_last : sb;
-                }
-            }
-            for (int i = t; i < kBW * kBR * 8; i += kTailBlock) (&bcount[0][0][0])[i] = 0, (&brank[0][0][0])[i] = 0;
-            last_in = len;
-            it += (uint32_t)kBatch - 1u;
-            __syncthreads();
-            continue;
-        }
         if (!held) { // the range's entries from memory (the first round of a launch, or after a jump)
 #pragma unroll
             for (int k = 0; k < kIndItems; ++k) {
@@ -1205,7 +1013,6 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
             }
         }
         held = true;
-        last_in = len;
         __syncthreads();
         if (t < kDigits) {
             const uint32_t before = gbase[t], now = dir > 0 ? before + cnt : before - cnt;
