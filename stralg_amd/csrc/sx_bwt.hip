@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
                                                               const uint32_t *__restrict__ tilepre,
                                                               uint32_t ntiles, uint32_t *__restrict__ o_out)
 {
-    __shared__ uint64_t lds[kWavesPerBlock];
+    __shared__ uint64_t lds[2 * kWavesPerBlock];
     constexpr int kRows = small_cfg<SIG>::rows, kTile = small_cfg<SIG>::tile;
     __shared__ __attribute__((aligned(16))) uint32_t rows[kTile * SIG];
     const int t = (int)threadIdx.x;
@@ -197,15 +197,16 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
         else if (sym[k] < (uint32_t)SIG) pk[1] += one;
     }
     uint32_t run[SIG];
-#pragma unroll
-    for (int h = 0; h < (SIG + 3) / 4; ++h) {
-        uint64_t ex = 0, tot;
-        if ((uint32_t)(4 * h) < sigma) ex = block_exclusive_sum64(pk[h], lds, tot); // sigma is uniform
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const int a = 4 * h + f;
-            if (a < SIG) run[a] = (uint32_t)((ex >> (16 * f)) & 0xFFFFull) + pre[a];
+    {
+        uint64_t ex[2] = {pk[0], pk[1]};
+        if (SIG > 4) {
+            block_exclusive_sum64x2(ex[0], ex[1], lds); // both words behind one pair of barriers
+        } else {
+            uint64_t tot;
+            ex[0] = block_exclusive_sum64(pk[0], lds, tot);
         }
+#pragma unroll
+        for (int a = 0; a < SIG; ++a) run[a] = (uint32_t)((ex[a >> 2] >> (16 * (a & 3))) & 0xFFFFull) + pre[a];
     }
     if (sigma == (uint32_t)SIG && (kRows * SIG) % 4 == 0) {
         // the thread's rows are kRows * SIG consecutive words of the tile: build them in

@@ -86,6 +86,28 @@ __device__ __forceinline__ uint64_t block_exclusive_sum64(uint64_t v, uint64_t *
     return base + inc - v;
 }
 
+// two packed words at once (one pair of barriers instead of two)
+__device__ __forceinline__ void block_exclusive_sum64x2(uint64_t &a, uint64_t &b, uint64_t *lds /* 2 * kWavesPerBlock */)
+{
+    const int lane = lane_id(), w = wave_id();
+    uint64_t ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint64_t ta = __shfl_up(ia, (unsigned)d, kWave), tb = __shfl_up(ib, (unsigned)d, kWave);
+        if (lane >= d) ia += ta, ib += tb;
+    }
+    if (lane == kWave - 1) lds[w] = ia, lds[kWavesPerBlock + w] = ib;
+    __syncthreads();
+    uint64_t ba = 0, bb = 0;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) {
+        if (i < w) ba += lds[i], bb += lds[kWavesPerBlock + i];
+    }
+    __syncthreads();
+    a = ba + ia - a;
+    b = bb + ib - b;
+}
+
 template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v, uint32_t *lds)
 {
     uint32_t total;
