@@ -603,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void induce_wide_apply_kernel(uint32_t *__r
 }
 
 template <class WT>
-__global__ __launch_bounds__(kWideThreads) void induce_wide_scatter_kernel(
+__global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev, int mode,
     uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs /* [tile][256] */,
     const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA, WT *__restrict__ WN,
@@ -686,21 +686,9 @@ __global__ __launch_bounds__(kWideThreads) void induce_wide_scatter_kernel(
         // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
         // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
         // a seventh of the entries of a byte alphabet, 16 to a thread).
-        {
-            WT fresh[kWideItems];
-            uint32_t dry = 0;
 #pragma unroll
-            for (int k = 0; k < kWideItems; ++k) {
-                fresh[k] = 0;
-                if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) {
-                    dry |= 1u << k;
-                    fresh[k] = wnd_fill<WT>(T, val[k], cfg);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kWideItems; ++k)
-                if ((dry >> k) & 1u) wnd[k] = fresh[k];
-        }
+        for (int k = 0; k < kWideItems; ++k)
+            if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, val[k], cfg);
 #pragma unroll
         for (int k = 0; k < kWideItems; ++k) {
             if (lpos[k] & 0x8000u) {

@@ -85,9 +85,13 @@ __global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const typename r
                                                                 uint64_t n, uint32_t *__restrict__ hist)
 {
     constexpr int ND = 1 << DB;
-    __shared__ uint32_t h[ND];
-    for (int i = (int)threadIdx.x; i < ND; i += kRT) h[i] = 0;
+    // four copies of the counters, a lane adds to copy (lane & 3): digits of natural text are skewed (a third of the keys
+    // of a word-like text share one), and lanes adding to one LDS word are served one after the other
+    constexpr int kCopies = DB == 8 ? 4 : 1;
+    __shared__ uint32_t hh[kCopies][ND];
+    for (int i = (int)threadIdx.x; i < kCopies * ND; i += kRT) (&hh[0][0])[i] = 0;
     __syncthreads();
+    uint32_t *h = hh[threadIdx.x & (kCopies - 1)];
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)threadIdx.x * kRadixItems;
     static_assert(kRadixItems == 16, "16 digits per thread: one or two 16-byte loads");
     const bool full = base + 16 <= n;
@@ -124,7 +128,12 @@ __global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const typename r
         for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
     }
     __syncthreads();
-    for (int i = (int)threadIdx.x; i < ND; i += kRT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
+    for (int i = (int)threadIdx.x; i < ND; i += kRT) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int cpy = 0; cpy < kCopies; ++cpy) sum += hh[cpy][i];
+        hist[(uint64_t)blockIdx.x * ND + i] = sum;
+    }
 }
 
 constexpr uint32_t kRadixChunk = 256; // tiles per chunk of the column sums
