@@ -811,7 +811,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             const double eff = sum_p2 > 0.0 ? 1.0 / sum_p2 : 1.0;
             const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
             const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
-            if (m < (1u << 22) || mean_bucket > 300.0 || top_bucket > 512.0) hybrid = false;
+            if (m < (1u << 22) || mean_bucket > 300.0 || top_bucket > 400.0) hybrid = false; // (a workgroup holds a sub-bucket of up to 1024)
         }
         const uint32_t dig_shift = hybrid ? (uint32_t)(kbits - kSxHybridTopBits) : 0u;
         const uint32_t dig_mask = kbits - (int)dig_shift >= 8 ? 0xFFu : (1u << (kbits - (int)dig_shift)) - 1u;

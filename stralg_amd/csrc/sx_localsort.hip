@@ -26,8 +26,16 @@ namespace sx {
 
 constexpr int kLsThreads = 512, kLsWaves = kLsThreads / kWave, kLsItems = 12;
 constexpr int kLsCap = kLsThreads * kLsItems; // pairs a workgroup can hold: 6144 (72 KiB of LDS, two workgroups a CU)
-constexpr int kLsSpan = 4096;                 // a workgroup owns the sub-buckets that start in its span of the array
-constexpr int kLsFirstItems = 10;             // loaded at once: span + 1024; the rest only when the last sub-bucket is longer
+// (span 3584: 4.10 ms, 4096: 3.88, 4608: 3.64, 5120: 3.40 at 1 GiB of DNA: the per-workgroup costs -- zeroing and
+// scanning the 8192 counters -- are spread over more pairs; what is left of the reach bounds the sub-bucket that fits)
+#ifndef SX_LS_SPAN
+#define SX_LS_SPAN 5120
+#endif
+constexpr int kLsSpan = SX_LS_SPAN;           // a workgroup owns the sub-buckets that start in its span of the array
+#ifndef SX_LS_FIRST
+#define SX_LS_FIRST 12
+#endif
+constexpr int kLsFirstItems = SX_LS_FIRST;    // loaded at once (all of the reach now; a smaller first load is followed by the rest only when needed)
 constexpr int kLsWords = kLsCap / 32;
 constexpr int kLsBins = 8192;  // bins of the counting pass: 16 KiB of packed 16-bit counters in the (then unused) key image
 constexpr int kLsMaxBin = 16;  // a bin with more pairs than this: stable passes instead (equal keys crowd one bin)
