@@ -36,7 +36,9 @@ for k in range(cases):
     elif kind == 4 and sigma > 3: # skewed
         x = np.where(rng.random(n) < 0.9, 1, x).astype(np.uint8)
     flag = int(rng.integers(0, 4))
-    ctx.set_chain_max_entries(int(rng.choice([2048, 8192, 65536, 524288, 4194304])))  # which induce rounds are chained
+    ctx.set_chain_max_entries(int(rng.choice([-1, -1, 0, 2048, 8192, 65536, 524288, 4194304])))  # which induce rounds are chained
+    ctx.set_sort_mode(int(rng.choice([0, 1, 2, 2])))  # LSD passes / top bits in HBM passes + sub-buckets in LDS (where the key shape allows)
+    ctx.set_radix_digit_bits(int(rng.choice([0, 0, 0, 9, 10])))
     ctx.force_general_path(flag == 1)
     ctx.set_no_direct_sort(flag == 2)
     ctx.set_prefix_symbols(int(rng.choice([0, 0, 0, 12, 14, 15, 16, 17, 18, 19, 23])))  # the key kernel's static forms too
@@ -45,7 +47,7 @@ for k in range(cases):
     sa = np.zeros(n + 1, np.uint32)
     got = ctx.sa_build(x, sigma)
     st = ctx.last_stats()
-    paths[st["lms_path"]] = paths.get(st["lms_path"], 0) + 1
+    paths[(st["lms_path"], st["sort_local"])] = paths.get((st["lms_path"], st["sort_local"]), 0) + 1
     assert (got == want).all(), ("SA", k, sigma, n, kind, flag)
     if sigma <= 128 and n < 70000:
         want_c, want_o = oracle.c_table(x, sigma), oracle.o_table(x, want, sigma).ravel()
@@ -54,5 +56,6 @@ for k in range(cases):
         assert (o.ravel() == want_o).all(), ("O", k, sigma, n, kind)
         sa2, c2, o2 = ctx.build_tables(x, sigma)  # the fused build: BWT from the induction windows / the sort payload
         assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
-ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(524288); ctx.set_prefix_symbols(0)
+ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(-1); ctx.set_prefix_symbols(0)
+ctx.set_sort_mode(0); ctx.set_radix_digit_bits(0)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
