@@ -27,15 +27,41 @@ struct OpMax {
     __device__ __forceinline__ static uint32_t apply(uint32_t a, uint32_t b) { return a > b ? a : b; }
 };
 
+// Inclusive scan over the 64 lanes of a wave in six data-parallel-primitive steps: inside every row of 16 lanes the
+// value of the lane 1, 2, 4, 8 places to the left comes in through the DPP operand path (row_shr; lanes that have no
+// such neighbour read the identity, 0), then lane 15 of rows 0 and 2 is broadcast into rows 1 and 3 (row_bcast:15) and
+// lane 31 into rows 2 and 3 (row_bcast:31).  The compiler folds each step into one v_add_u32_dpp / v_max_u32_dpp:
+// six instructions and no LDS traffic, against six ds_bpermute round trips with their address arithmetic for a scan
+// by __shfl_up.  Both operators here have the identity 0.
+template <class Op, int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_scan_step(uint32_t x)
+{
+    return Op::apply((uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true), x);
+}
+template <class Op> __device__ __forceinline__ uint32_t row_inclusive_scan(uint32_t v) // inside rows of 16 lanes
+{
+    v = dpp_scan_step<Op, 0x111, 0xF>(v); // row_shr:1
+    v = dpp_scan_step<Op, 0x112, 0xF>(v); // row_shr:2
+    v = dpp_scan_step<Op, 0x114, 0xF>(v); // row_shr:4
+    v = dpp_scan_step<Op, 0x118, 0xF>(v); // row_shr:8
+    return v;
+}
 template <class Op> __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        uint32_t t = __shfl_up(v, (unsigned)d, kWave);
-        if (lane >= d) v = Op::apply(t, v);
-    }
+    v = row_inclusive_scan<Op>(v);
+    v = dpp_scan_step<Op, 0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_scan_step<Op, 0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3
     return v;
+}
+// Sums of 16-bit fields packed in a 64-bit word (no field ever overflows, so the two halves never exchange a carry)
+__device__ __forceinline__ uint64_t wave_inclusive_sum_packed(uint64_t v)
+{
+    const uint32_t lo = wave_inclusive_scan<OpAdd>((uint32_t)v), hi = wave_inclusive_scan<OpAdd>((uint32_t)(v >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t row_inclusive_sum_packed(uint64_t v) // inside rows of 16 lanes
+{
+    const uint32_t lo = row_inclusive_scan<OpAdd>((uint32_t)v), hi = row_inclusive_scan<OpAdd>((uint32_t)(v >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 // Exclusive scan over the kBlock threads of a workgroup.  `lds` needs
@@ -66,12 +92,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
 __device__ __forceinline__ uint64_t block_exclusive_sum64(uint64_t v, uint64_t *lds /* kWavesPerBlock */, uint64_t &total)
 {
     const int lane = lane_id(), w = wave_id();
-    uint64_t inc = v;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint64_t t = __shfl_up(inc, (unsigned)d, kWave);
-        if (lane >= d) inc += t;
-    }
+    const uint64_t inc = wave_inclusive_sum_packed(v); // (every caller's word holds 16-bit fields)
     if (lane == kWave - 1) lds[w] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;
@@ -90,12 +111,7 @@ __device__ __forceinline__ uint64_t block_exclusive_sum64(uint64_t v, uint64_t *
 __device__ __forceinline__ void block_exclusive_sum64x2(uint64_t &a, uint64_t &b, uint64_t *lds /* 2 * kWavesPerBlock */)
 {
     const int lane = lane_id(), w = wave_id();
-    uint64_t ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint64_t ta = __shfl_up(ia, (unsigned)d, kWave), tb = __shfl_up(ib, (unsigned)d, kWave);
-        if (lane >= d) ia += ta, ib += tb;
-    }
+    const uint64_t ia = wave_inclusive_sum_packed(a), ib = wave_inclusive_sum_packed(b);
     if (lane == kWave - 1) lds[w] = ia, lds[kWavesPerBlock + w] = ib;
     __syncthreads();
     uint64_t ba = 0, bb = 0;

@@ -347,13 +347,8 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
             cnt += (uint64_t)(ok[k] ? 1u : 0u) << (8u * ch);
         }
         // exclusive prefix over the threads, both words at once
-        uint64_t inc0 = cnt & kField16, inc1 = (cnt >> 8) & kField16;
-        const uint64_t own0 = inc0, own1 = inc1;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint64_t a = __shfl_up(inc0, (unsigned)d, kWave), b = __shfl_up(inc1, (unsigned)d, kWave);
-            if (lane >= d) inc0 += a, inc1 += b;
-        }
+        const uint64_t own0 = cnt & kField16, own1 = (cnt >> 8) & kField16;
+        const uint64_t inc0 = wave_inclusive_sum_packed(own0), inc1 = wave_inclusive_sum_packed(own1);
         if (lane == kWave - 1) wsum[0][w] = inc0, wsum[1][w] = inc1;
         __syncthreads();
         uint64_t ex0 = inc0 - own0, ex1 = inc1 - own1, tot0 = 0, tot1 = 0;
@@ -1186,13 +1181,8 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
 #pragma unroll
             for (int j = 0; j < kTailBatch; ++j) {
                 if ((uint32_t)j < nr) { // uniform
-                    uint64_t inc0 = cnt[j] & kField16, inc1 = (cnt[j] >> 8) & kField16;
-                    const uint64_t own0 = inc0, own1 = inc1;
-#pragma unroll
-                    for (int d = 1; d < kWave; d <<= 1) {
-                        const uint64_t a = __shfl_up(inc0, (unsigned)d, kWave), b = __shfl_up(inc1, (unsigned)d, kWave);
-                        if (lane >= d) inc0 += a, inc1 += b;
-                    }
+                    const uint64_t own0 = cnt[j] & kField16, own1 = (cnt[j] >> 8) & kField16;
+                    const uint64_t inc0 = wave_inclusive_sum_packed(own0), inc1 = wave_inclusive_sum_packed(own1);
                     if (lane == kWave - 1) wsum[j][0][w] = inc0, wsum[j][1][w] = inc1;
                     ex0[j] = inc0 - own0, ex1[j] = inc1 - own1;
                 }
@@ -1205,12 +1195,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
             const int j = t / (2 * kTailWaves), h = (t / kTailWaves) & 1, ww = t % kTailWaves;
             static_assert(kTailWaves == 16, "a (round, half) is scanned by a 16-lane segment");
             const uint64_t own = (uint32_t)j < nr ? wsum[j][h][ww] : 0ull;
-            uint64_t inc = own;
-#pragma unroll
-            for (int d = 1; d < kTailWaves; d <<= 1) {
-                const uint64_t a = __shfl_up(inc, (unsigned)d, kTailWaves);
-                if ((lane & (kTailWaves - 1)) >= d) inc += a;
-            }
+            const uint64_t inc = row_inclusive_sum_packed(own); // (a segment of 16 lanes is a DPP row)
             if ((uint32_t)j < nr) {
                 wsum[j][h][ww] = inc - own;
                 if (ww == kTailWaves - 1) { // the round's totals of four buckets

@@ -152,6 +152,21 @@ static inline int __builtin_amdgcn_readfirstlane(int x)
     return (int)(unsigned)v[__builtin_ctzll(live)];
 }
 
+// data-parallel-primitive moves used by the wave scans (sx_device.hpp): row_shr:n (0x110 + n), row_bcast:15 (0x142),
+// row_bcast:31 (0x143); old where the row / bank mask disables the lane; 0 (bound_ctrl) or old where there is no source
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    unsigned long long live; const unsigned long long *v = emu_wave_gather((unsigned long long)(unsigned)src, &live);
+    const int lane = emu_lane(), row = lane >> 4, bank = (lane >> 2) & 3;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if ((lane & 15) >= n) from = lane - n; }
+    else if (ctrl == 0x142) { if (row >= 1) from = row * 16 - 1; }
+    else if (ctrl == 0x143) { if (row >= 2) from = 31; }
+    if (from < 0 || !((live >> from) & 1)) return bound_ctrl ? 0 : old;
+    return (int)(unsigned)v[from];
+}
+
 // wave-level helpers of the ranking code: a scheduling barrier is a rendezvous of the wave's fibers here
 static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(0); }
 static inline unsigned emu_bitop3(unsigned a, unsigned b, unsigned c, unsigned tt)
