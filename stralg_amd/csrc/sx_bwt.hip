@@ -117,11 +117,8 @@ __global__ __launch_bounds__(kBlock) void bwt_count_wave_kernel(const uint8_t *_
 #undef SX_BWT_COUNT
     uint64_t even = (uint64_t)n_of[0] | (uint64_t)n_of[2] << 16 | (uint64_t)n_of[4] << 32 | (uint64_t)n_of[6] << 48; // 16-bit fields
     uint64_t odd = (uint64_t)n_of[1] | (uint64_t)n_of[3] << 16 | (uint64_t)n_of[5] << 32 | (uint64_t)n_of[7] << 48;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        even += __shfl_xor(even, o, kWave);
-        odd += __shfl_xor(odd, o, kWave);
-    }
+    even = wave_total_packed(even);
+    odd = wave_total_packed(odd);
     if ((uint32_t)lane < sigma && lane < 8)
         tilehist[(uint64_t)lane * ntiles + tile] = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
 }

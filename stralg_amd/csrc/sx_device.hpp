@@ -58,6 +58,13 @@ __device__ __forceinline__ uint64_t wave_inclusive_sum_packed(uint64_t v)
     const uint32_t lo = wave_inclusive_scan<OpAdd>((uint32_t)v), hi = wave_inclusive_scan<OpAdd>((uint32_t)(v >> 32));
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
+// the wave's total of such a word, in every lane (the scan's last lane, read through a scalar register)
+__device__ __forceinline__ uint64_t wave_total_packed(uint64_t v)
+{
+    const uint32_t lo = wave_inclusive_scan<OpAdd>((uint32_t)v), hi = wave_inclusive_scan<OpAdd>((uint32_t)(v >> 32));
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, kWave - 1) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, kWave - 1) << 32);
+}
 __device__ __forceinline__ uint64_t row_inclusive_sum_packed(uint64_t v) // inside rows of 16 lanes
 {
     const uint32_t lo = row_inclusive_scan<OpAdd>((uint32_t)v), hi = row_inclusive_scan<OpAdd>((uint32_t)(v >> 32));

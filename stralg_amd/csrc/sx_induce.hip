@@ -147,11 +147,8 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
             }
             uint64_t even = (uint64_t)n_of[2] << 16 | (uint64_t)n_of[4] << 32 | (uint64_t)n_of[6] << 48; // 16-bit fields
             uint64_t odd = (uint64_t)n_of[1] | (uint64_t)n_of[3] << 16 | (uint64_t)n_of[5] << 32 | (uint64_t)n_of[7] << 48;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                even += __shfl_xor(even, o, kWave);
-                odd += __shfl_xor(odd, o, kWave);
-            }
+            even = wave_total_packed(even);
+            odd = wave_total_packed(odd);
             if ((uint32_t)lane < nkeys && lane < 8) {
                 const uint32_t v = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
                 hist[(uint64_t)lane * stride + tile] = lane != 0 && induce_accept((uint32_t)lane, c, mode) ? v : 0u;
@@ -194,11 +191,8 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
                 }
             }
             uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                even += __shfl_xor(even, o, kWave);
-                odd += __shfl_xor(odd, o, kWave);
-            }
+            even = wave_total_packed(even);
+            odd = wave_total_packed(odd);
             if ((uint32_t)lane < nkeys && lane < 8)
                 hist[(uint64_t)lane * stride + tile] = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
         }

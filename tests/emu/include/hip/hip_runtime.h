@@ -152,6 +152,11 @@ static inline int __builtin_amdgcn_readfirstlane(int x)
     return (int)(unsigned)v[__builtin_ctzll(live)];
 }
 
+static inline int __builtin_amdgcn_readlane(int x, int lane)
+{
+    unsigned long long live; const unsigned long long *v = emu_wave_gather((unsigned long long)(unsigned)x, &live);
+    return (int)(unsigned)v[lane];
+}
 // data-parallel-primitive moves used by the wave scans (sx_device.hpp): row_shr:n (0x110 + n), row_bcast:15 (0x142),
 // row_bcast:31 (0x143); old where the row / bank mask disables the lane; 0 (bound_ctrl) or old where there is no source
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
