@@ -237,6 +237,13 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
         uint64_t key;
         if (CS > 0 && p >= (uint32_t)WS) { // (everywhere but at the very start of the text)
             key = key_and_window_dna<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1), (CS > 0 ? BS : 2)>(img, (uint32_t)((uint64_t)(p - (uint32_t)WS) - origin), kc, kbits);
+        } else if (CS > 0) {
+            // the first few positions of the text, in the static forms: symbol by symbol from memory.  (With the general
+            // form below compiled in here, the compiler evaluated its 64 uniform tests once per workgroup and parked them
+            // in a register's lanes -- 130 instructions up front for a path that a handful of suffixes of the whole text take.)
+            key = 0;
+            for (uint32_t s = 0; s < kc.C; ++s) key = key * kc.base + (uint64_t)T[(uint64_t)p + s];
+            if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
         } else {
             if (kc.C <= 32) { // uniform
                 uint64_t q[4];
