@@ -27,19 +27,26 @@ namespace sx {
 
 // Tile shape (tools/sortbench.sh, 3e8 pairs, 40 key bits, ms for the whole sort): 256 threads x 16
 // keys 15.4; 512 x 8 15.3; 512 x 12 14.4; 512 x 16 13.5; 512 x 20 18.3; 1024 x 16 14.8.  What counts
-// is the run a digit leaves the tile with: 8192 keys over 256 digits = 256-byte key runs.
+// is the run a digit leaves the tile with: 8192 keys over 256 digits = 256-byte key runs.  Round 2, with
+// the per-wave counters aliased into the key image (66 KB of LDS, two workgroups a CU either way): the same
+// 8192-key tile as 1024 threads x 8 keys needs 60 VGPRs instead of 100, so 32 waves a CU instead of 16, and
+// the scatter of the 1 GiB DNA build takes 5.26 ms instead of 5.51 (same box, twice each; tools/r02_run26.sh).
 #ifndef SX_RADIX_ITEMS
-#define SX_RADIX_ITEMS 16
+#define SX_RADIX_ITEMS 8
 #endif
 constexpr int kRadixItems = SX_RADIX_ITEMS;
 #ifndef SX_RADIX_MINWAVES
 #define SX_RADIX_MINWAVES 1
 #endif
 #ifndef SX_RADIX_THREADS
-#define SX_RADIX_THREADS 512
+#define SX_RADIX_THREADS 1024
 #endif
 constexpr int kRT = SX_RADIX_THREADS, kRW = kRT / kWave;
 constexpr int kRadixTile = kRT * kRadixItems;
+// The histogram kernels walk the same tiles with their own shape: 16 keys (or digits) a thread suits their wide loads.
+constexpr int kHT = 512, kHI = kRadixTile / kHT;
+// the per-wave counters live in the key image when they would not leave room for two workgroups a CU otherwise
+template <int DB> struct radix_alias { static constexpr bool value = DB > 8 || kRW > 8; };
 
 // Digit width of a pass: 8 bits (256 digits: the default), 9 or 10.  Wider digits mean fewer passes over the
 // pairs (40 key bits: 4 passes of 10 instead of 5 of 8) and shorter runs per (tile, digit): 8192 pairs over 1024
@@ -53,18 +60,18 @@ template <int DB> struct radix_dig_type { typedef uint16_t type; };
 template <> struct radix_dig_type<8> { typedef uint8_t type; };
 
 template <int DB>
-__global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
+__global__ __launch_bounds__(kHT) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
                                                             int shift, uint32_t mask,
                                                             uint32_t *__restrict__ hist, uint32_t ntiles)
 {
     constexpr int ND = 1 << DB;
     __shared__ uint32_t h[ND];
-    for (int i = (int)threadIdx.x; i < ND; i += kRT) h[i] = 0;
+    for (int i = (int)threadIdx.x; i < ND; i += kHT) h[i] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile;
 #pragma unroll
-    for (int k = 0; k < kRadixItems; ++k) {
-        const uint64_t i = base + (uint64_t)k * kRT + threadIdx.x;
+    for (int k = 0; k < kHI; ++k) {
+        const uint64_t i = base + (uint64_t)k * kHT + threadIdx.x;
         const uint32_t d = i < n ? (uint32_t)(keys[i] >> shift) & mask : 0u;
         // (a wave of equal digits adds once: see radix_hist_digits_kernel)
         const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
@@ -75,13 +82,13 @@ __global__ __launch_bounds__(kRT) void radix_hist_kernel(const uint64_t *__restr
         }
     }
     __syncthreads();
-    for (int i = (int)threadIdx.x; i < ND; i += kRT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
+    for (int i = (int)threadIdx.x; i < ND; i += kHT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
 }
 
 // The same from the digits the previous pass's scatter wrote next to its output (one byte per key for 8-bit
 // digits, two for wider ones, in the order of that output): an eighth / a quarter of the key array's traffic.
 template <int DB>
-__global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const typename radix_dig_type<DB>::type *__restrict__ dig,
+__global__ __launch_bounds__(kHT) void radix_hist_digits_kernel(const typename radix_dig_type<DB>::type *__restrict__ dig,
                                                                 uint64_t n, uint32_t *__restrict__ hist)
 {
     constexpr int ND = 1 << DB;
@@ -89,46 +96,51 @@ __global__ __launch_bounds__(kRT) void radix_hist_digits_kernel(const typename r
     // of a word-like text share one), and lanes adding to one LDS word are served one after the other
     constexpr int kCopies = DB == 8 ? 4 : 1;
     __shared__ uint32_t hh[kCopies][ND];
-    for (int i = (int)threadIdx.x; i < kCopies * ND; i += kRT) (&hh[0][0])[i] = 0;
+    for (int i = (int)threadIdx.x; i < kCopies * ND; i += kHT) (&hh[0][0])[i] = 0;
     __syncthreads();
     uint32_t *h = hh[threadIdx.x & (kCopies - 1)];
-    const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)threadIdx.x * kRadixItems;
-    static_assert(kRadixItems == 16, "16 digits per thread: one or two 16-byte loads");
-    const bool full = base + 16 <= n;
+    const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)threadIdx.x * kHI;
+    static_assert(kHI == 16 || kHI == 8, "16 or 8 digits per thread: wide loads");
+    const bool full = base + kHI <= n;
     if (DB == 8) {
         uint32_t w[4] = {0, 0, 0, 0};
         if (full) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);
-            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+            if (kHI == 16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(dig + base);
+                w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+            } else {
+                const uint2 v = *reinterpret_cast<const uint2 *>(dig + base);
+                w[0] = v.x, w[1] = v.y, w[2] = v.x, w[3] = v.y; // (the second half repeats the first: tested, not counted)
+            }
         }
         // Sorted or repetitive input (the keys of a tie-refinement round, a periodic text) has long runs of one
-        // digit, and 64 lanes adding to one LDS word are served one after the other: a wave whose 1024 digits are
-        // all the same adds once, a thread whose 16 digits are adds once (250 us a pass for 10^8 equal keys before).
+        // digit, and 64 lanes adding to one LDS word are served one after the other: a wave whose digits are
+        // all the same adds once, a thread whose digits are adds once (250 us a pass for 10^8 equal keys before).
         // (The wave-wide tests are reached by every lane: no collective under a branch.)
         const uint32_t first = w[0] & 0xFFu, rep = first * 0x01010101u;
         const bool mono = full && w[0] == rep && w[1] == rep && w[2] == rep && w[3] == rep;
         const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
         const bool wave_mono = __all((mono && first == lead) ? 1 : 0);
         if (wave_mono) {
-            if (lane_id() == 0) atomicAdd(&h[first], 16u * kWave);
+            if (lane_id() == 0) atomicAdd(&h[first], (uint32_t)kHI * kWave);
         } else if (mono) {
-            atomicAdd(&h[first], 16u);
+            atomicAdd(&h[first], (uint32_t)kHI);
         } else if (full) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+            for (int k = 0; k < kHI; ++k) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
         } else {
-            for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
+            for (uint64_t i = base; i < n && i < base + kHI; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
         }
-    } else if (full) {
+    } else if (full && kHI == 16) {
         const uint4 v0 = *reinterpret_cast<const uint4 *>(dig + base), v1 = *reinterpret_cast<const uint4 *>(dig + base + 8);
         const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int k = 0; k < 16; ++k) atomicAdd(&h[(w[k >> 1] >> (16 * (k & 1))) & (uint32_t)(ND - 1)], 1u);
     } else {
-        for (uint64_t i = base; i < n && i < base + 16; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
+        for (uint64_t i = base; i < n && i < base + kHI; ++i) atomicAdd(&h[(uint32_t)dig[i] & (uint32_t)(ND - 1)], 1u);
     }
     __syncthreads();
-    for (int i = (int)threadIdx.x; i < ND; i += kRT) {
+    for (int i = (int)threadIdx.x; i < ND; i += kHT) {
         uint32_t sum = 0;
 #pragma unroll
         for (int cpy = 0; cpy < kCopies; ++cpy) sum += hh[cpy][i];
@@ -316,7 +328,7 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
     const uint32_t cnt = FULL || left >= (uint64_t)kRadixTile ? (uint32_t)kRadixTile : (uint32_t)left;
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) lpos[k] = (lpos[k] & 0xFFFFu) + wcount[w * ND + (lpos[k] >> 16)];
-    if (DB > 8) __syncthreads(); // the counters share the key image: every slot is known before the first key lands
+    if (radix_alias<DB>::value) __syncthreads(); // the counters share the key image: every slot is known before the first key lands
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
@@ -363,11 +375,11 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     constexpr int ND = 1 << DB;
     __shared__ uint64_t skey[kRadixTile]; // the tile in digit order: keys first, then reused for the values
     // per-wave digit counters, then the first slot of each (wave, digit)
-    __shared__ uint32_t wcount_own[DB == 8 ? kRW * ND : 1];
+    __shared__ uint32_t wcount_own[radix_alias<DB>::value ? 1 : kRW * ND];
     __shared__ uint32_t goff[ND];         // global offset of the digit minus its first slot inside the tile
     __shared__ uint32_t scan_lds[kRW];
     static_assert((size_t)kRW * ND * sizeof(uint32_t) <= sizeof(uint64_t) * kRadixTile, "the counters fit the key image");
-    uint32_t *wcount = DB == 8 ? wcount_own : reinterpret_cast<uint32_t *>(skey);
+    uint32_t *wcount = radix_alias<DB>::value ? reinterpret_cast<uint32_t *>(skey) : wcount_own;
 
     const int t = (int)threadIdx.x;
     // Workgroups are dealt round robin to the 8 XCDs, each with its own L2.  Tiles that follow each other write
@@ -434,10 +446,10 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
         const bool has_next = next_shift < end_bit;
         const int next_bits = has_next ? (end_bit - next_shift < DB ? end_bit - next_shift : DB) : 0;
         if (shift == begin_bit && !first_digits_ready)
-            sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel<DB>, dim3(ntiles), dim3(kRT), (const uint64_t *)kin, n, shift,
+            sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel<DB>, dim3(ntiles), dim3(kHT), (const uint64_t *)kin, n, shift,
                       mask, hist, ntiles);
         else
-            sx_launch(ctx, SX_KC_RADIX_HIST, n * dig_bytes, radix_hist_digits_kernel<DB>, dim3(ntiles), dim3(kRT), (const dig_t *)dig, n, hist);
+            sx_launch(ctx, SX_KC_RADIX_HIST, n * dig_bytes, radix_hist_digits_kernel<DB>, dim3(ntiles), dim3(kHT), (const dig_t *)dig, n, hist);
         if (nchunks == 1) {
             sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 12, radix_offsets_small_kernel<ND>, dim3(1), dim3(ND), hist, ntiles);
         } else {
