@@ -17,6 +17,14 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ uint64_t lanemask_le() { return (2ull << lane_id()) - 1ull; }
+// OR over the wave's lanes (every lane gets it; all lanes must call)
+__device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
 
 struct OpAdd {
     __device__ __forceinline__ static uint32_t identity() { return 0u; }

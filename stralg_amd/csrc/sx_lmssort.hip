@@ -473,23 +473,53 @@ struct InActHead {
     const uint8_t *ahead;
     __device__ __forceinline__ uint32_t operator()(uint64_t t) const { return ahead[t] ? (uint32_t)t + 1u : 0u; }
 };
-struct OutActKey {
+// ... and, at its head's slot, the group's size (written by the group's last member)
+struct OutGroupIds {
+    const uint8_t *ahead;
+    uint64_t A;
+    uint32_t *agid, *gsize;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const
+    {
+        const uint32_t g = (excl > v ? excl : v) - 1u;
+        agid[t] = g;
+        if (t + 1 == A || ahead[t + 1]) gsize[g] = (uint32_t)(t + 1) - g;
+    }
+};
+// the sub-list's groups numbered 0, 1, ... (few long groups: the sort by group then takes one pass, not one per byte of a list index)
+struct InSubHead {
+    const uint32_t *sub_t, *sub_gid;
+    __device__ __forceinline__ uint32_t operator()(uint64_t j) const { return sub_t[j] == sub_gid[j] ? 1u : 0u; }
+};
+struct OutGroupNumber {
+    uint32_t *number;
+    __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const { number[j] = excl + v - 1u; }
+};
+// the members of groups with more than `limit` members, compacted (list order: groups stay whole and in order), with the
+// next C symbols of each as its key
+struct InLargeGroup {
+    const uint32_t *agid, *gsize;
+    uint32_t limit;
+    __device__ __forceinline__ uint32_t operator()(uint64_t t) const { return gsize[agid[t]] > limit ? 1u : 0u; }
+};
+struct OutLargeMember {
     const uint8_t *T;
-    const uint32_t *ap;
+    const uint32_t *ap, *agid;
     uint64_t n, skip;
     pkey_cfg kc;
-    uint32_t *agid;
+    uint32_t *sub_t, *sub_gid;
     uint64_t *key_keep, *key_sort;
     uint32_t *order;
     __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const
     {
-        agid[t] = (excl > v ? excl : v) - 1u;
+        if (!v) return;
+        sub_t[excl] = (uint32_t)t;
+        sub_gid[excl] = agid[t];
         const uint64_t q = (uint64_t)ap[t] + skip;
         // q > n cannot happen inside a tie (a key holding the sentinel is unique); stay in bounds anyway
         const uint64_t k = q <= n ? prefix_key(T, q, kc) : 0ull;
-        key_keep[t] = k;
-        key_sort[t] = k;
-        order[t] = (uint32_t)t;
+        key_keep[excl] = k;
+        key_sort[excl] = k;
+        order[excl] = excl;
     }
 };
 
@@ -501,29 +531,32 @@ __global__ __launch_bounds__(kBlock) void gid_keys_kernel(const uint32_t *__rest
     if (t < A) keys[t] = agid[order[t]];
 }
 
-// after ordering by (group, next key): write the refined order back, find the new boundaries
+// after ordering the sub-list by (group, next key): write the refined order back, find the new boundaries.  Slot j of the
+// sub-list is slot sub_t[j] of the active list; a group's members occupy the same slots before and after.
 __global__ __launch_bounds__(kBlock) void refine_write_kernel(const uint32_t *__restrict__ order,
+                                                              const uint32_t *__restrict__ sub_t,
                                                               const uint32_t *__restrict__ ap,
                                                               const uint32_t *__restrict__ apos,
-                                                              const uint32_t *__restrict__ agid,
-                                                              const uint64_t *__restrict__ key_keep, uint64_t A,
+                                                              const uint32_t *__restrict__ sub_gid,
+                                                              const uint64_t *__restrict__ key_keep, uint64_t A3,
                                                               uint32_t *__restrict__ vals_sorted,
                                                               uint32_t *__restrict__ ap_new,
                                                               uint8_t *__restrict__ head_new,
                                                               uint32_t *__restrict__ seedw,
                                                               const uint8_t *__restrict__ T, wnd_cfg wcfg)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= A) return;
-    const uint32_t o = order[t];
-    const uint32_t p = ap[o];
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= A3) return;
+    const uint32_t o = order[j];
+    const uint32_t p = ap[sub_t[o]];
+    const uint32_t t = sub_t[j];
     vals_sorted[apos[t]] = p; // slot t of the active list keeps its place in the sorted order
     if (seedw) seedw[apos[t]] = p ? wnd_fill<uint32_t>(T, p, wcfg) : 0u; // its window moves with it
     ap_new[t] = p;
     bool head = true;
-    if (t > 0) {
-        const uint32_t o1 = order[t - 1];
-        head = agid[o1] != agid[o] || key_keep[o1] != key_keep[o];
+    if (j > 0) {
+        const uint32_t o1 = order[j - 1];
+        head = sub_gid[o1] != sub_gid[o] || key_keep[o1] != key_keep[o];
     }
     head_new[t] = head ? 1 : 0;
 }
@@ -585,6 +618,149 @@ __global__ __launch_bounds__(kBlock) void refine_small_groups_kernel(
             ap_new[t + i] = p[i];
             head_new[t + i] = (i == 0 || k[i] != k[i > 0 ? i - 1 : 0]) ? 1 : 0;
         }
+    }
+}
+
+// Groups of kSmallGroup + 1 .. kMidGroup members (a family of diverged repeats leaves tens of millions of suffixes in
+// groups of some hundred to some thousand: through the radix passes every one of them crossed HBM 12 times a round).
+// A workgroup takes the groups whose head lies in its span of the active list -- such a group ends inside the
+// workgroup's reach -- computes the members' next keys, orders them by (group, key) in LDS and writes the round's
+// result for them.  The order comes from a bitonic network over the members (padded to a power of two): a 63-bit key
+// and the group's number would take nine stable 8-bit passes of ballot ranking, ~1200 issue cycles per pass and 64
+// members; the network's 55 .. 78 compare-exchange steps cost a fifth of that for the some hundred members a
+// workgroup typically owns.  (Members with equal keys stay tied whatever their order.)
+constexpr int kRmThreads = 512, kRmWaves = kRmThreads / kWave, kRmItems = 8;
+constexpr int kRmCap = kRmThreads * kRmItems; // 4096 list slots in reach (48 KiB of LDS, three workgroups a CU)
+#ifndef SX_RM_SPAN
+#define SX_RM_SPAN 2048
+#endif
+constexpr int kRmSpan = SX_RM_SPAN;           // a workgroup owns the groups whose head lies in its span
+constexpr int kMidGroup = kRmCap - kRmSpan;   // 2048: a group this long that starts in the span ends within the reach
+constexpr int kRmGroups = 256;                // owned groups have more than kSmallGroup members: fewer than 2048 / 9
+static_assert(kRmSpan / (kSmallGroup + 1) < kRmGroups && (kRmCap & (kRmCap - 1)) == 0, "group numbers; the network's size");
+// (group, key, slot) of one member before that of another
+__device__ __forceinline__ bool rm_before(uint64_t ka, uint32_t va, uint64_t kb, uint32_t vb)
+{
+    const uint32_t ga = va >> 16, gb = vb >> 16;
+    return ga != gb ? ga < gb : (ka != kb ? ka < kb : va < vb);
+}
+__global__ __launch_bounds__(kRmThreads, 4) void refine_mid_groups_kernel(
+    const uint8_t *__restrict__ T, uint64_t n, const uint32_t *__restrict__ ap, const uint32_t *__restrict__ apos,
+    const uint32_t *__restrict__ agid, const uint32_t *__restrict__ gsize, uint64_t A, uint64_t skip, pkey_cfg kc,
+    uint32_t *__restrict__ vals_sorted, uint32_t *__restrict__ ap_new, uint8_t *__restrict__ head_new,
+    uint32_t *__restrict__ seedw, wnd_cfg wcfg)
+{
+    __shared__ uint64_t K[kRmCap]; // next keys of the owned members, dense, in list order
+    __shared__ uint32_t V[kRmCap]; // local list slot the member came from | its group's number << 16
+    __shared__ uint32_t gfirst[kRmGroups], gstart[kRmGroups]; // a group's first dense index / its head's local list slot
+    __shared__ uint32_t s_act[kRmWaves], s_head[kRmWaves], s_diff;
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t g0 = (uint64_t)blockIdx.x * kRmSpan;
+    const uint32_t avail = A - g0 < (uint64_t)kRmCap ? (uint32_t)(A - g0) : (uint32_t)kRmCap;
+    const uint32_t i0 = (uint32_t)w * (kWave * kRmItems) + (uint32_t)lane; // slots i0 + 64 k: a wave's slots are consecutive
+    // ---- which slots in reach are members of owned groups; their dense index and group number -----------------------
+    uint32_t act_mask = 0, head_mask = 0, run_act = 0, run_head = 0;
+    uint32_t dg[kRmItems]; // dense index within the wave | heads up to here within the wave << 16
+    {
+        // (every load of a step up front: a branch around the second one would make the gathers wait for each other)
+        uint32_t a[kRmItems], sz[kRmItems];
+#pragma unroll
+        for (int k = 0; k < kRmItems; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * kWave;
+            a[k] = i < avail ? agid[g0 + i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < kRmItems; ++k) {
+            const bool own = a[k] >= g0 && a[k] - g0 < (uint64_t)kRmSpan; // (a head's index is at most its member's: below A)
+            sz[k] = gsize[own ? a[k] : g0];
+            if (!own) a[k] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < kRmItems; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * kWave;
+            const bool act = a[k] != 0xFFFFFFFFu && sz[k] > (uint32_t)kSmallGroup && sz[k] <= (uint32_t)kMidGroup;
+            const bool hd = act && a[k] == g0 + i;
+            const uint64_t ba = __ballot(act ? 1 : 0), bh = __ballot(hd ? 1 : 0);
+            dg[k] = (run_act + (uint32_t)__popcll(ba & lanemask_lt())) | ((run_head + (uint32_t)__popcll(bh & lanemask_le())) << 16);
+            if (act) act_mask |= 1u << k;
+            if (hd) head_mask |= 1u << k;
+            run_act += (uint32_t)__popcll(ba);
+            run_head += (uint32_t)__popcll(bh);
+        }
+    }
+    if (lane == 0) s_act[w] = run_act, s_head[w] = run_head;
+    if (t == 0) s_diff = 0;
+    __syncthreads();
+    uint32_t base_act = 0, base_head = 0, n_act = 0;
+#pragma unroll
+    for (int ww = 0; ww < kRmWaves; ++ww) {
+        if (ww < w) base_act += s_act[ww], base_head += s_head[ww];
+        n_act += s_act[ww];
+    }
+    if (n_act == 0) return; // (uniform)
+#pragma unroll
+    for (int k = 0; k < kRmItems; ++k) {
+        if ((act_mask >> k) & 1u) {
+            const uint32_t i = i0 + (uint32_t)k * kWave;
+            const uint32_t d = base_act + (dg[k] & 0xFFFFu), g = base_head + (dg[k] >> 16) - 1u;
+            V[d] = i | (g << 16);
+            if ((head_mask >> k) & 1u) gfirst[g] = d, gstart[g] = i;
+        }
+    }
+    // the network's size: the power of two that holds the members (two members a thread at least)
+    uint32_t P = 2 * kRmThreads;
+    while (P < n_act) P <<= 1;
+    for (uint32_t d = n_act + (uint32_t)t; d < P; d += kRmThreads) K[d] = ~0ull, V[d] = 0xFFFFFFFFu; // padding sorts last
+    __syncthreads();
+    // ---- next keys of the members, dense: as many steps as hold them (most workgroups own some hundred) -------------
+    const uint32_t per = (n_act + (uint32_t)kRmThreads - 1u) / (uint32_t)kRmThreads;
+    for (uint32_t k0 = 0; k0 < per; k0 += 4) { // uniform
+        uint32_t pp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t d = (uint32_t)t + (k0 + (uint32_t)j) * kRmThreads;
+            pp[j] = d < n_act ? ap[g0 + (V[d] & 0xFFFFu)] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t d = (uint32_t)t + (k0 + (uint32_t)j) * kRmThreads;
+            const uint64_t q = (uint64_t)pp[j] + skip;
+            // q > n cannot happen inside a tie (a key holding the sentinel is unique); stay in bounds anyway
+            if (d < n_act) K[d] = q <= n ? prefix_key(T, q, kc) : 0ull;
+        }
+    }
+    __syncthreads();
+    {
+        bool differs = false; // from its group's head (no member does: every group stays as it is)
+        for (uint32_t d = (uint32_t)t; d < n_act; d += kRmThreads) differs = differs || K[d] != K[gfirst[V[d] >> 16]];
+        if (__any(differs ? 1 : 0) && lane == 0) s_diff = 1;
+    }
+    __syncthreads();
+    // ---- bitonic network over (group, key, slot) -----------------------------------------------------------------
+    if (s_diff) { // (uniform)
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t c = (uint32_t)t; c < P / 2; c += kRmThreads) {
+                    const uint32_t i = ((c & ~(j - 1u)) << 1) | (c & (j - 1u)), l = i | j;
+                    const uint64_t ki = K[i], kl = K[l];
+                    const uint32_t vi = V[i], vl = V[l];
+                    const bool up = (i & k) == 0u; // this block of k ascends
+                    if (rm_before(kl, vl, ki, vi) == up) K[i] = kl, V[i] = vl, K[l] = ki, V[l] = vi;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- out: dense slot d is member d - gfirst[g] of group g -----------------------------------------------------
+    for (uint32_t d = (uint32_t)t; d < n_act; d += kRmThreads) {
+        const uint64_t key = K[d];
+        const uint32_t v = V[d], g = v >> 16, r = d - gfirst[g];
+        const uint64_t tt = g0 + gstart[g] + r;
+        const uint32_t p = ap[g0 + (v & 0xFFFFu)], slot = apos[tt];
+        vals_sorted[slot] = p;
+        if (seedw) seedw[slot] = p ? wnd_fill<uint32_t>(T, p, wcfg) : 0u;
+        ap_new[tt] = p;
+        head_new[tt] = (r == 0 || K[d - 1] != key) ? 1 : 0;
     }
 }
 
@@ -692,7 +868,7 @@ size_t sx_lms_prefix_bytes(uint64_t m)
     b += 2 * (m * 8 + a);   // keys
     b += 3 * (m * 4 + a);   // values, seed windows
     b += 3 * (cap * 8 + a); // refinement keys: kept copy + sort ping-pong
-    b += 8 * (cap * 4 + a); // apos x2, ap x2, ap_new, agid, order x2
+    b += 11 * (cap * 4 + a); // apos x2, ap x2, ap_new, agid, order x2, group sizes, the sub-list of long groups x2
     b += 3 * (cap + a);     // heads
     b += 2 * ((m / 8192 + 2) * 4 + a); // tie counts and offsets per tile of the sorted keys
     b += 3 * (size_t)(m / 4096 + 2) * 4 + a; // the same, and the owned range's start, per workgroup of the local sort
@@ -750,6 +926,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t *apos = am.take<uint32_t>(cap), *apos2 = am.take<uint32_t>(cap);
     uint32_t *ap = am.take<uint32_t>(cap), *ap2 = am.take<uint32_t>(cap), *ap_new = am.take<uint32_t>(cap);
     uint32_t *agid = am.take<uint32_t>(cap), *ord_a = am.take<uint32_t>(cap), *ord_b = am.take<uint32_t>(cap);
+    uint32_t *gsize = am.take<uint32_t>(cap), *sub_t = am.take<uint32_t>(cap), *sub_gid = am.take<uint32_t>(cap);
     uint8_t *head = am.take<uint8_t>(cap), *head2 = am.take<uint8_t>(cap), *head_new = am.take<uint8_t>(cap);
     uint32_t *seedw = am.take<uint32_t>(m);
     uint32_t *d_scalar = am.take<uint32_t>(16);
@@ -758,7 +935,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     const uint32_t ls_tiles = sx_local_sort_tiles(m);
     uint32_t *tile_lsrt = am.take<uint32_t>(3 * (size_t)ls_tiles); // start, tied members, offset of every local-sort workgroup
     if (!tile_cnt || !tile_pos || !seedw || !ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
-        !agid || !ord_a || !ord_b || !head || !head2 || !head_new || !d_scalar)
+        !agid || !ord_a || !ord_b || !gsize || !sub_t || !sub_gid || !head || !head2 || !head_new || !d_scalar)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
     const dim3 block(kBlock);
 
@@ -942,25 +1119,47 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         A = A2;
         return 0;
     };
-    // one refinement step by the next Cmax symbols through two radix sorts of (group, next key): any group size
-    auto refine_by_sorting = [&](uint64_t skip) -> int {
-        const uint32_t gbits = (uint32_t)(sx_bitlen(A) > 0 ? sx_bitlen(A) : 1);
-        // group ids and the next C symbols of every tied suffix
-        SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head},
-                                   OutActKey{ti.T, ap, ti.n, skip, pkey_make(base, Cmax), agid, key_keep, rk_a, ord_a},
-                                   nullptr, SX_KC_DOUBLING, (uint64_t)A * 32)));
+    // One refinement step by the next Cmax symbols for the groups of more than kSmallGroup members (the smaller ones
+    // are settled by their head's thread): group sizes, then groups of up to kMidGroup members inside a workgroup's
+    // LDS, the members of longer ones compacted and ordered by two radix sorts of (group, next key).
+    // SX_FLAG_SORT_MODE 1 (plain passes only): every group of more than kSmallGroup members takes the radix sorts.
+    const bool lds_tier = ctx->sort_mode != 1;
+    auto refine_larger_groups = [&](uint64_t skip) -> int {
+        const pkey_cfg kc_r = pkey_make(base, Cmax);
+        SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head}, OutGroupIds{head, (uint64_t)A, agid, gsize}, nullptr,
+                                   SX_KC_DOUBLING, (uint64_t)A * 9)));
+        if (lds_tier) {
+            ctx->stats.refine_tiers |= 1u;
+            sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_mid_groups_kernel, dim3(sx_div_up(A, kRmSpan)),
+                      dim3(kRmThreads), ti.T, ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid,
+                      (const uint32_t *)gsize, (uint64_t)A, skip, kc_r, vs, ap_new, head_new,
+                      embed ? seedw : nullptr, full_wcfg);
+        }
+        SX_TRY((device_compact(ctx, A, InLargeGroup{agid, gsize, (uint32_t)(lds_tier ? kMidGroup : kSmallGroup)},
+                               OutLargeMember{ti.T, ap, agid, ti.n, skip, kc_r, sub_t, sub_gid, key_keep, rk_a, ord_a}, d_scalar,
+                               SX_KC_DOUBLING, (uint64_t)A * 12)));
+        uint32_t A3 = 0;
+        SX_TRY(sx_readback(ctx, d_scalar, 1, &A3));
+        if (A3 == 0) return 0;
+        ctx->stats.refine_tiers |= 2u;
+        uint32_t *sub_num = gsize; // (the sizes are not needed any more)
+        SX_TRY((device_scan<OpAdd>(ctx, A3, InSubHead{sub_t, sub_gid}, OutGroupNumber{sub_num}, d_scalar + 3, SX_KC_DOUBLING,
+                                   (uint64_t)A3 * 12)));
+        uint32_t n_long = 0;
+        SX_TRY(sx_readback(ctx, d_scalar + 3, 1, &n_long));
+        const uint32_t gbits = n_long > 1 ? (uint32_t)sx_bitlen(n_long - 1) : 1u;
         // order by (group, next key), LSD: stable sort by next key, then stable sort by group
         int f = 0;
-        SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A, 0, kbits_r, &f));
+        SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A3, 0, kbits_r, &f));
         uint32_t *ord1 = f ? ord_b : ord_a, *ord1_other = f ? ord_a : ord_b;
         uint64_t *k1 = f ? rk_a : rk_b, *k1_other = f ? rk_b : rk_a; // k1: free to overwrite
-        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 16, gid_keys_kernel, dim3(sx_div_up(A, kBlock)), block,
-                  (const uint32_t *)ord1, (const uint32_t *)agid, (uint64_t)A, k1);
-        SX_TRY(sx_sort_pairs(ctx, k1, ord1, k1_other, ord1_other, A, 0, (int)gbits, &f));
+        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A3 * 16, gid_keys_kernel, dim3(sx_div_up(A3, kBlock)), block,
+                  (const uint32_t *)ord1, (const uint32_t *)sub_num, (uint64_t)A3, k1);
+        SX_TRY(sx_sort_pairs(ctx, k1, ord1, k1_other, ord1_other, A3, 0, (int)gbits, &f));
         const uint32_t *order = f ? ord1_other : ord1;
-        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 40, refine_write_kernel, dim3(sx_div_up(A, kBlock)), block, order,
-                  (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)agid, (const uint64_t *)key_keep,
-                  (uint64_t)A, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
+        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A3 * 44, refine_write_kernel, dim3(sx_div_up(A3, kBlock)), block, order,
+                  (const uint32_t *)sub_t, (const uint32_t *)ap, (const uint32_t *)apos, (const uint32_t *)sub_num,
+                  (const uint64_t *)key_keep, (uint64_t)A3, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
         return 0;
     };
     for (int round = 1; A > 0; ++round) {
@@ -983,7 +1182,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             if (counters[1]) return 0; // a repeat beyond the comparison cap: general path
             SX_TRY(keep_tied());
             if (A == 0) break;
-            SX_TRY(refine_by_sorting(skip)); // what is left sits in groups of more than eight
+            SX_TRY(refine_larger_groups(skip)); // what is left sits in groups of more than eight: every member is rewritten
             SX_TRY(keep_tied());
             continue;
         }
@@ -992,7 +1191,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                   ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip,
                   pkey_make(base, Cmax), vs, ap_new, head_new, embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
         SX_TRY(sx_readback(ctx, d_scalar + 1, 1, counters));
-        if (counters[0]) SX_TRY(refine_by_sorting(skip)); // larger groups exist: redo the round for everyone by sorting
+        if (counters[0]) SX_TRY(refine_larger_groups(skip)); // larger groups exist: they are refined in LDS or by sorting
         SX_TRY(keep_tied());
     }
     *out = vs;

@@ -17,3 +17,20 @@ def synth(n, sigma, seed, start=0):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
         return (np.uint64(1) + (z >> np.uint64(33)) % np.uint64(sigma - 1)).astype(np.uint8)
+
+
+def repeat_families(n, seed, families):
+    """uint8 array of n symbols in [1, 5): uniform noise with, for every (copies, length, divergence) of `families`,
+    that many copies of one random element at non-overlapping places, each symbol of a copy replaced by a random one
+    with the given probability.  The suffixes at one offset of an element's copies share long prefixes: after the
+    prefix-key sort they sit in groups of up to `copies` members (what a family of interspersed repeats does to a genome)."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(1, 5, size=n, dtype=np.uint8)
+    for copies, length, divergence in families:
+        element = rng.integers(1, 5, size=length, dtype=np.uint8)
+        for pos in rng.choice(n // length - 1, size=copies, replace=False) * length:
+            copy = element.copy()
+            changed = rng.random(length) < divergence
+            copy[changed] = rng.integers(1, 5, size=int(changed.sum()), dtype=np.uint8)
+            x[pos:pos + length] = copy
+    return x

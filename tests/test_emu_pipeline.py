@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from stralg_amd.synth import synth
+from stralg_amd.synth import synth, repeat_families
 
 
 def _sa(ctx, x, sigma):
@@ -138,6 +138,30 @@ def test_long_repeats_finish_by_comparison(emu_ctx):
         assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all(), (copies, L)
         st = emu_ctx.last_stats()
         assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, (copies, L, st)
+
+
+def test_repeat_families_refine_in_lds_and_by_sorting(emu_ctx):
+    """families of diverged repeats leave groups of hundreds and thousands of tied suffixes: groups of 9 .. 2048 members
+    are refined inside a workgroup's LDS (refine_mid_groups_kernel), the members of longer ones by radix sorts of the
+    compacted sub-list; with SX_FLAG_SORT_MODE 1 every group of more than 8 takes the radix sorts"""
+    x = repeat_families(500000, 3, ((2600, 36, 0.002), (100, 120, 0.03), (30, 300, 0.0)))
+    ref = oracle.sa_is(x, 5)
+    assert (_sa(emu_ctx, x, 5) == ref).all()
+    st = emu_ctx.last_stats()
+    assert st["lms_path"] == 1 and st["refine_tiers"] == 3, st
+    # groups of up to some hundred members only: nothing is left for the radix sorts
+    y = repeat_families(200000, 4, ((200, 120, 0.03), (40, 300, 0.0)))
+    ref_y = oracle.sa_is(y, 5)
+    assert (_sa(emu_ctx, y, 5) == ref_y).all()
+    st = emu_ctx.last_stats()
+    assert st["lms_path"] == 1 and st["refine_tiers"] == 1, st
+    emu_ctx.set_sort_mode(1)
+    try:
+        assert (_sa(emu_ctx, y, 5) == ref_y).all()
+        st = emu_ctx.last_stats()
+        assert st["lms_path"] == 1 and st["refine_tiers"] == 2, st
+    finally:
+        emu_ctx.set_sort_mode(0)
 
 
 def test_very_long_run(emu_ctx):

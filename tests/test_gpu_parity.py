@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from oracle import pyoracle
-from stralg_amd.synth import synth
+from stralg_amd.synth import synth, repeat_families
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -969,6 +969,22 @@ def test_long_repeats_finish_by_comparison(gpu_ctx):
     assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all()
     st = gpu_ctx.last_stats()
     assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, st
+
+
+def test_repeat_families_refine_in_lds_and_by_sorting(gpu_ctx):
+    """families of diverged repeats in 16 Mi symbols: groups of 9 .. 2048 tied suffixes are refined inside a
+    workgroup's LDS, longer ones by radix sorts of their members only; the plain-passes mode (every group of more than
+    8 through the radix sorts) gives the same suffix array; both match the oracle"""
+    x = repeat_families(1 << 24, 11, ((30000, 60, 0.01), (5000, 200, 0.05), (2000, 300, 0.08), (300, 1000, 0.02)))
+    ref = oracle.sa_is(x, 5)
+    try:
+        for mode, tiers in ((0, 3), (1, 2)):
+            gpu_ctx.set_sort_mode(mode)
+            assert (gpu_ctx.sa_build(x, 5) == ref).all(), mode
+            st = gpu_ctx.last_stats()
+            assert st["lms_path"] == 1 and st["refine_tiers"] == tiers, (mode, st)
+    finally:
+        gpu_ctx.set_sort_mode(0)
 
 
 def test_differential_fuzz():

@@ -15,7 +15,7 @@ for k in range(cases):
     n = int(rng.choice([1, 2, 3, 17, 255, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 65537, 100003, 300007,
                         1048577, 2500001, 2500001, 9000001]))
     n = max(1, n + int(rng.integers(-3, 4)))
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 7))
     if sigma == 2:
         x = np.ones(n, dtype=np.uint8)
     else:
@@ -33,6 +33,17 @@ for k in range(cases):
     elif kind == 3:               # periodic
         p = int(rng.integers(1, 9))
         x = np.resize(x[:p], n)
+    elif kind == 6 and n > 4096:  # families of diverged repeats: groups of tens to thousands of tied suffixes
+        for _ in range(int(rng.integers(1, 4))):
+            L = int(rng.integers(8, 200))
+            copies = int(rng.integers(10, max(11, min(12000, n // (3 * L)))))
+            el = x[:L].copy()
+            div = float(rng.choice([0.0, 0.002, 0.02, 0.08]))
+            for pos in rng.choice(n // L - 1, size=copies, replace=False) * L:
+                c = el.copy()
+                mm = rng.random(L) < div
+                c[mm] = rng.integers(1, sigma, size=int(mm.sum()), dtype=np.uint8) if sigma > 2 else 1
+                x[pos:pos + L] = c
     elif kind == 4 and sigma > 3: # skewed
         x = np.where(rng.random(n) < 0.9, 1, x).astype(np.uint8)
     flag = int(rng.integers(0, 4))
@@ -47,7 +58,8 @@ for k in range(cases):
     sa = np.zeros(n + 1, np.uint32)
     got = ctx.sa_build(x, sigma)
     st = ctx.last_stats()
-    paths[(st["lms_path"], st["sort_local"])] = paths.get((st["lms_path"], st["sort_local"]), 0) + 1
+    pk = (st["lms_path"], st["sort_local"], st["refine_tiers"])
+    paths[pk] = paths.get(pk, 0) + 1
     assert (got == want).all(), ("SA", k, sigma, n, kind, flag)
     if sigma <= 128 and n < 70000:
         want_c, want_o = oracle.c_table(x, sigma), oracle.o_table(x, want, sigma).ravel()
