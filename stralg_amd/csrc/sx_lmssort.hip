@@ -767,71 +767,138 @@ __global__ __launch_bounds__(kRmThreads, 4) void refine_mid_groups_kernel(
 // Groups that survive two rounds of key refinement are true repeats, and the next 17 symbols rarely end them
 // (a 50 kb duplication would need 3000 rounds).  Small groups are therefore finished in one step by comparing
 // the suffixes themselves from the symbols already known equal on, 16 bytes at a time; the suffixes of a text
-// are distinct (the sentinel), so this settles every member.  Cost is the sum of the common prefixes; a
-// comparison that runs beyond kCompareCap symbols gives up and the build takes the general path.
+// are distinct (the sentinel), so this settles every member.  Cost is the sum of the common prefixes.  The
+// head's thread gives a comparison kSoloCompare symbols; a group with a longer one is taken over by the whole
+// wave, every lane comparing 16 bytes of a 1024-byte stretch (a thread alone walks a 50 000-symbol duplication
+// in 3000 dependent steps, 0.4 ms during which the rest of the chip has long finished).  A comparison that runs
+// beyond kCompareCap symbols gives up and the build takes the general path.
 constexpr uint64_t kCompareCap = 1ull << 22;
-__device__ __forceinline__ bool suffix_less_from(const uint8_t *__restrict__ T, uint32_t a, uint32_t b, uint64_t off,
-                                                 uint32_t *__restrict__ hard)
+constexpr uint64_t kSoloCompare = 512;
+__device__ __forceinline__ bool first_difference_less(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1)
 {
-    for (uint64_t l = off;; l += 16) {
-        if (l - off > kCompareCap) {
-            atomicAdd(hard, 1u);
-            return false;
-        }
+    // the first differing byte decides (little endian: lowest byte first)
+    const uint64_t x = a0 != b0 ? a0 ^ b0 : a1 ^ b1, ua = a0 != b0 ? a0 : a1, ub = a0 != b0 ? b0 : b1;
+    const int sh = (__ffsll((unsigned long long)x) - 1) & ~7;
+    return ((ua >> sh) & 0xFFull) < ((ub >> sh) & 0xFFull);
+}
+// by one thread; sets `too_long` (and returns anything) when the suffixes agree on kSoloCompare symbols from `off`
+__device__ __forceinline__ bool suffix_less_from(const uint8_t *__restrict__ T, uint32_t a, uint32_t b, uint64_t off, bool &too_long)
+{
+    for (uint64_t l = off; l - off < kSoloCompare; l += 16) {
         uint64_t a0, a1, b0, b1;
         load_bytes16(T, (uint64_t)a + l, a0, a1);
         load_bytes16(T, (uint64_t)b + l, b0, b1);
-        if (a0 != b0 || a1 != b1) { // the first differing byte decides (little endian: lowest byte first)
-            const uint64_t x = a0 != b0 ? a0 ^ b0 : a1 ^ b1, ua = a0 != b0 ? a0 : a1, ub = a0 != b0 ? b0 : b1;
-            const int sh = (__ffsll((unsigned long long)x) - 1) & ~7;
-            return ((ua >> sh) & 0xFFull) < ((ub >> sh) & 0xFFull);
+        if (a0 != b0 || a1 != b1) return first_difference_less(a0, a1, b0, b1);
+    }
+    too_long = true;
+    return false;
+}
+// by the whole wave (a, b, off uniform; every lane must call).  The text is readable up to 16 bytes past the
+// sentinel at n; the first difference lies at or before the earlier of the two sentinels.
+__device__ __forceinline__ bool wave_suffix_less_from(const uint8_t *__restrict__ T, uint64_t n, uint32_t a, uint32_t b,
+                                                      uint64_t off, uint32_t *__restrict__ hard)
+{
+    const uint64_t mine = (uint64_t)lane_id() * 16;
+    for (uint64_t l = off;; l += (uint64_t)kWave * 16) {
+        const uint64_t pa = (uint64_t)a + l + mine, pb = (uint64_t)b + l + mine;
+        const bool in = pa <= n && pb <= n;
+        uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        if (in) {
+            load_bytes16(T, pa, a0, a1);
+            load_bytes16(T, pb, b0, b1);
+        }
+        const uint64_t bal = __ballot((in && (a0 != b0 || a1 != b1)) ? 1 : 0);
+        if (bal) { // uniform
+            const int first = __ffsll((unsigned long long)bal) - 1;
+            return first_difference_less(__shfl(a0, first, kWave), __shfl(a1, first, kWave), __shfl(b0, first, kWave),
+                                         __shfl(b1, first, kWave));
+        }
+        if (l - off > kCompareCap || !__any(in ? 1 : 0)) { // uniform
+            if (lane_id() == 0) atomicAdd(hard, 1u);
+            return false;
         }
     }
 }
 
+#define SX_SORT8(LESS)                                                                                                 \
+    SX_CSWAP(0, 1, LESS) SX_CSWAP(2, 3, LESS) SX_CSWAP(4, 5, LESS) SX_CSWAP(6, 7, LESS)                                \
+    SX_CSWAP(0, 2, LESS) SX_CSWAP(1, 3, LESS) SX_CSWAP(4, 6, LESS) SX_CSWAP(5, 7, LESS)                                \
+    SX_CSWAP(1, 2, LESS) SX_CSWAP(5, 6, LESS)                                                                          \
+    if (size > 4) {                                                                                                    \
+        SX_CSWAP(0, 4, LESS) SX_CSWAP(1, 5, LESS) SX_CSWAP(2, 6, LESS) SX_CSWAP(3, 7, LESS)                            \
+        SX_CSWAP(2, 4, LESS) SX_CSWAP(3, 5, LESS)                                                                      \
+        SX_CSWAP(1, 2, LESS) SX_CSWAP(3, 4, LESS) SX_CSWAP(5, 6, LESS)                                                 \
+    }
+#define SX_CSWAP(a, b, LESS)                                                                                           \
+    if (p[b] != kPad && (p[a] == kPad || LESS(p[b], p[a]))) {                                                          \
+        const uint32_t tp = p[a];                                                                                      \
+        p[a] = p[b], p[b] = tp;                                                                                        \
+    }
 __global__ __launch_bounds__(kBlock) void refine_by_comparison_kernel(
-    const uint8_t *__restrict__ T, const uint32_t *__restrict__ ap, const uint32_t *__restrict__ apos,
+    const uint8_t *__restrict__ T, uint64_t n, const uint32_t *__restrict__ ap, const uint32_t *__restrict__ apos,
     const uint8_t *__restrict__ head, uint64_t A, uint64_t skip, uint32_t *__restrict__ vals_sorted,
     uint32_t *__restrict__ ap_new, uint8_t *__restrict__ head_new, uint32_t *__restrict__ seedw, wnd_cfg wcfg,
     uint32_t *__restrict__ counters /* [0] groups beyond kSmallGroup (left as they are), [1] comparisons given up */)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= A || !head[t]) return;
-    int size = 1;
-    while (size <= kSmallGroup && t + size < A && !head[t + size]) ++size;
-    if (size > kSmallGroup) { // ap_new / head_new already hold this group unchanged (copied before the launch)
-        atomicAdd(&counters[0], 1u);
-        return;
-    }
     constexpr uint32_t kPad = 0xFFFFFFFFu;
-    uint32_t p[kSmallGroup];
-#pragma unroll
-    for (int i = 0; i < kSmallGroup; ++i) p[i] = i < size ? ap[t + i] : kPad;
-#define SX_CSWAP(a, b)                                                                                                 \
-    if (p[b] != kPad && (p[a] == kPad || suffix_less_from(T, p[b], p[a], skip, &counters[1]))) {                        \
-        const uint32_t tp = p[a];                                                                                      \
-        p[a] = p[b], p[b] = tp;                                                                                        \
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    int gsz = 0; // size of the group this thread is the head of
+    if (t < A && head[t]) {
+        gsz = 1;
+        while (gsz <= kSmallGroup && t + gsz < A && !head[t + gsz]) ++gsz;
     }
-    SX_CSWAP(0, 1) SX_CSWAP(2, 3) SX_CSWAP(4, 5) SX_CSWAP(6, 7)
-    SX_CSWAP(0, 2) SX_CSWAP(1, 3) SX_CSWAP(4, 6) SX_CSWAP(5, 7)
-    SX_CSWAP(1, 2) SX_CSWAP(5, 6)
-    if (size > 4) {
-        SX_CSWAP(0, 4) SX_CSWAP(1, 5) SX_CSWAP(2, 6) SX_CSWAP(3, 7)
-        SX_CSWAP(2, 4) SX_CSWAP(3, 5)
-        SX_CSWAP(1, 2) SX_CSWAP(3, 4) SX_CSWAP(5, 6)
-    }
-#undef SX_CSWAP
+    bool too_long = false;
+    if (gsz > kSmallGroup) { // ap_new / head_new already hold this group unchanged (copied before the launch)
+        atomicAdd(&counters[0], 1u);
+    } else if (gsz > 0) {
+        const int size = gsz;
+        uint32_t p[kSmallGroup];
 #pragma unroll
-    for (int i = 0; i < kSmallGroup; ++i) {
+        for (int i = 0; i < kSmallGroup; ++i) p[i] = i < size ? ap[t + i] : kPad;
+#define SX_LESS_SOLO(x, y) suffix_less_from(T, x, y, skip, too_long)
+        SX_SORT8(SX_LESS_SOLO)
+#undef SX_LESS_SOLO
+        if (!too_long) {
+#pragma unroll
+            for (int i = 0; i < kSmallGroup; ++i) {
+                if (i < size) {
+                    const uint32_t slot = apos[t + i];
+                    vals_sorted[slot] = p[i];
+                    if (seedw) seedw[slot] = p[i] ? wnd_fill<uint32_t>(T, p[i], wcfg) : 0u;
+                    ap_new[t + i] = p[i];
+                    head_new[t + i] = 1; // every member is told apart
+                }
+            }
+        }
+    }
+    // groups with a long comparison, one after the other, by the whole wave
+    uint64_t todo = __ballot(too_long ? 1 : 0);
+    while (todo) { // uniform
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint64_t tg = __shfl(t, src, kWave);
+        const int size = __shfl(gsz, src, kWave);
+        uint32_t p[kSmallGroup];
+#pragma unroll
+        for (int i = 0; i < kSmallGroup; ++i) p[i] = i < size ? ap[tg + i] : kPad; // (uniform addresses)
+#define SX_LESS_WAVE(x, y) wave_suffix_less_from(T, n, x, y, skip, &counters[1])
+        SX_SORT8(SX_LESS_WAVE)
+#undef SX_LESS_WAVE
+        const int i = lane_id();
         if (i < size) {
-            const uint32_t slot = apos[t + i];
-            vals_sorted[slot] = p[i];
-            if (seedw) seedw[slot] = p[i] ? wnd_fill<uint32_t>(T, p[i], wcfg) : 0u;
-            ap_new[t + i] = p[i];
-            head_new[t + i] = 1; // every member is told apart
+            uint32_t mine = p[0];
+#pragma unroll
+            for (int k = 1; k < kSmallGroup; ++k) mine = i == k ? p[k] : mine;
+            const uint32_t slot = apos[tg + i];
+            vals_sorted[slot] = mine;
+            if (seedw) seedw[slot] = mine ? wnd_fill<uint32_t>(T, mine, wcfg) : 0u;
+            ap_new[tg + i] = mine;
+            head_new[tg + i] = 1;
         }
     }
 }
+#undef SX_CSWAP
+#undef SX_SORT8
 
 struct InStillTied {
     const uint8_t *head;
@@ -1176,7 +1243,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             SX_CHECK(hipMemcpyAsync(ap_new, ap, (size_t)A * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
             SX_CHECK(hipMemcpyAsync(head_new, head, (size_t)A, hipMemcpyDeviceToDevice, ctx->stream));
             sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_by_comparison_kernel, dim3(sx_div_up(A, kBlock)), block, ti.T,
-                      (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip, vs, ap_new, head_new,
+                      ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip, vs, ap_new, head_new,
                       embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
             SX_TRY(sx_readback(ctx, d_scalar + 1, 2, counters));
             if (counters[1]) return 0; // a repeat beyond the comparison cap: general path

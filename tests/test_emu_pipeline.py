@@ -138,6 +138,12 @@ def test_long_repeats_finish_by_comparison(emu_ctx):
         assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all(), (copies, L)
         st = emu_ctx.last_stats()
         assert st["lms_path"] == 1 and st["doubling_rounds"] >= 3, (copies, L, st)
+    # long comparisons are taken over by the whole wave (1024 bytes a step); one of them here runs into the sentinel
+    x = base.copy()
+    x[-3000:] = x[700:3700]
+    x[60000:62500] = x[700:3200]
+    assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all()
+    assert emu_ctx.last_stats()["lms_path"] == 1
 
 
 def test_repeat_families_refine_in_lds_and_by_sorting(emu_ctx):

@@ -987,6 +987,22 @@ def test_repeat_families_refine_in_lds_and_by_sorting(gpu_ctx):
         gpu_ctx.set_sort_mode(0)
 
 
+def test_duplication_beyond_the_comparison_cap(gpu_ctx):
+    """a 4.5 Mi-symbol exact duplication in 64 Mi symbols of DNA: the pair comparisons (taken over by whole waves, 1024
+    bytes a step) give up beyond 4 Mi symbols and the build falls back to the general path; a 1 Mi-symbol one is
+    settled by them and the build stays on the prefix-key path"""
+    n = 1 << 26
+    x = synth(n, 5, 123)
+    y = x.copy()
+    y[40_000_000:40_000_000 + (1 << 20)] = y[1000:1000 + (1 << 20)]
+    assert (gpu_ctx.sa_build(y, 5) == oracle.sa_is(y, 5)).all()
+    assert gpu_ctx.last_stats()["lms_path"] == 1
+    L = 4_700_000
+    x[40_000_000:40_000_000 + L] = x[1000:1000 + L]
+    assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all()
+    assert gpu_ctx.last_stats()["lms_path"] == 2
+
+
 def test_differential_fuzz():
     """tools/fuzz_gpu.py: 250 random (size, alphabet, structure, path flag) combinations against the oracle --
     suffix array, C and O tables from (text, sa) and from the fused build.  (This is the harness that found the
