@@ -45,7 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--sigma", type=int, default=5, help="alphabet_size of the uniform workloads")
     ap.add_argument("--workload", default=None,
                     help="dna (default at --gpus 1) | fasta (default at --gpus > 1) | bytes | uniform | genome_like | "
-                         "n_runs | text_like | periodic")
+                         "n_runs | text_like | pangenome | periodic")
     ap.add_argument("--no-tables", action="store_true", help="suffix array only")
     ap.add_argument("--no-direct-sort", action="store_true",
                     help="wide alphabets: LMS sort + induced-sort passes even where the direct sort of all suffixes applies")

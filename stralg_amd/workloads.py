@@ -10,12 +10,15 @@ texts as stralg's constructors take them: symbols in [1, alphabet_size), no 0.
   n_runs       DNA with four runs of N (the gaps of a reference assembly): 2.8 %, 1.7 %, 0.28 % and
                0.005 % of the text
   text_like    Zipf-distributed words of a 20 000-word vocabulary separated by blanks (28 symbols)
+  pangenome    16 haplotypes of one random genome of n / 16 symbols, one after the other, every symbol of a copy
+               replaced with probability 0.001 (what a collection of assemblies of one species looks like to an index:
+               every suffix shares some thousand symbols with 15 others)
   periodic     a Fibonacci string over two symbols: every LMS substring repeats, the worst case for
                anything that tells suffixes apart by prefixes (what equal_LMS has to name,
                stralg/sa_is.c:265-292)
 """
 
-WORKLOADS = ("dna", "bytes", "genome_like", "n_runs", "text_like", "periodic")
+WORKLOADS = ("dna", "bytes", "genome_like", "n_runs", "text_like", "pangenome", "periodic")
 
 
 def _gen(dev, seed):
@@ -109,6 +112,22 @@ def text_like(n, seed, dev):
     return x, 28
 
 
+def pangenome(ctx, n, seed, dev, copies=16, divergence=0.001):
+    import torch
+    g = _gen(dev, seed)
+    base_len = max(1, n // copies)
+    base = torch.empty(base_len, dtype=torch.uint8, device=dev)
+    ctx.synth_dev(base, base_len, 5, seed)
+    x = torch.empty(n, dtype=torch.uint8, device=dev)
+    for s in range(0, n, base_len):
+        e = min(n, s + base_len)
+        part = base[:e - s].clone()
+        changed = torch.rand(e - s, device=dev, generator=g) < divergence
+        other = torch.randint(1, 5, (e - s,), device=dev, generator=g).to(torch.uint8)
+        x[s:e] = torch.where(changed, other, part)
+    return x, 5
+
+
 def periodic(n, dev):
     import torch
     a = torch.tensor([2], dtype=torch.uint8, device=dev)
@@ -132,6 +151,8 @@ def make_text(ctx, workload, n, sigma, seed, dev):
         return n_runs(ctx, n, seed, dev)
     if workload == "text_like":
         return text_like(n, seed, dev)
+    if workload == "pangenome":
+        return pangenome(ctx, n, seed, dev)
     if workload == "periodic":
         return periodic(n, dev)
     raise ValueError(f"unknown workload {workload!r}")
