@@ -79,7 +79,9 @@ typedef struct sx_build_stats {
     uint32_t sort_local;     /* bit 0: the prefix-key sort finished in LDS (hybrid: HBM passes on the top 24 key bits only);
                                 bit 1: some workgroup of it met crowded bins and took stable passes */
     uint32_t refine_tiers;   /* tie refinement of the prefix-key sort: bit 0: some round ordered groups of 9 .. 2048 members in
-                                LDS; bit 1: some round sent the members of longer groups through radix sorts */
+                                LDS; bit 1: some round sent the members of longer groups through radix sorts; prefix doubling of the
+                                general path: bit 2: some round ordered small groups by one wave each, bit 3: some round sent
+                                members through radix sorts */
     double ms_total;         /* wall time of the last build on the device stream */
 } sx_build_stats;
 

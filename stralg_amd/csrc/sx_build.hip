@@ -61,9 +61,10 @@ static size_t reduce_bytes(uint64_t M, uint64_t m)
     b += 2 * (M * 4 + a); // vals
     b += 3 * (M * 4 + a); // R, rank, sa_r
     b += 2 * (M * 4 + a); // active positions
-    b += M * 4 + a;       // gid
+    b += 2 * (M * 4 + a); // gid, sub-list slots
     b += 2 * (M + a);     // heads
     b += m * 4 + a;       // sorted lms
+    b += 4096 * 4 + a;    // partial head counts
     b += 4096;
     return b;
 }
@@ -221,12 +222,15 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         rb.pos_a = am.take<uint32_t>(M);
         rb.pos_b = am.take<uint32_t>(M);
         rb.gid = am.take<uint32_t>(M);
+        rb.sub_t = am.take<uint32_t>(M);
         rb.head_a = am.take<uint8_t>(M);
         rb.head_b = am.take<uint8_t>(M);
         uint32_t *slms = am.take<uint32_t>(ti.m);
         rb.d_scalar = am.take<uint32_t>(16);
+        rb.head_bins = am.take<uint32_t>(4096);
+        if (!rb.head_bins) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: reduce buffers");
         if (!pos || !is_lms || !rb.ka || !rb.kb || !rb.va || !rb.vb || !rb.R || !rb.rank || !rb.sa_r || !rb.pos_a ||
-            !rb.pos_b || !rb.gid || !rb.head_a || !rb.head_b || !slms || !rb.d_scalar)
+            !rb.pos_b || !rb.gid || !rb.sub_t || !rb.head_a || !rb.head_b || !slms || !rb.d_scalar)
             return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: reduce buffers");
 
         SX_TRY(sx_sample_write(ctx, ti, pos, is_lms));

@@ -18,6 +18,16 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ uint64_t lanemask_le() { return (2ull << lane_id()) - 1ull; }
+// maximum over the wave's lanes (every lane gets it; all lanes must call)
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_xor(v, d, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
 // OR over the wave's lanes (every lane gets it; all lanes must call)
 __device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v)
 {

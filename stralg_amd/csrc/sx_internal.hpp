@@ -54,8 +54,10 @@ struct sx_reduce_bufs {
     uint32_t *sa_r;         // suffix array of the reduced string, M
     uint32_t *pos_a, *pos_b; // active positions, M each
     uint32_t *gid;          // M
+    uint32_t *sub_t;        // M: list slots of the members a doubling round orders by radix sorts
     uint8_t *head_a, *head_b; // M each
     uint32_t *d_scalar;     // >= 4 u32
+    uint32_t *head_bins;    // 1024 u32: partial counts of the groups a doubling round leaves
 };
 // names from the sorted piece keys; n_names out.  keys/vals sorted in (ks, vs).
 int sx_name_pieces(sx_ctx *ctx, const uint64_t *ks, const uint32_t *vs, uint64_t M, sx_reduce_bufs &rb,

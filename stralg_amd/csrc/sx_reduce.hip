@@ -8,6 +8,7 @@
 // radix sort instead: rank pairs (rank[i], rank[i+h]) are sorted, groups are
 // refined, h doubles; only suffixes in groups of more than one stay active.
 // The suffix array is unique, so the result equals the reference's.
+#include <vector>
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
@@ -48,16 +49,29 @@ __global__ __launch_bounds__(kBlock) void pack_names_kernel(const uint32_t *__re
     vals[i] = (uint32_t)i;
 }
 
+// (every kernel that sets head flags also counts them: the host chooses the next round's form by the mean group size.
+// One add per wave, spread over kHeadBins words: five million adds to one word took half a second.)
+constexpr uint32_t kHeadBins = 1024; // (one read-back of a page)
+__device__ __forceinline__ void count_heads(bool is_head, uint32_t *__restrict__ n_heads)
+{
+    const uint64_t b = __ballot(is_head ? 1 : 0);
+    if (b && lane_id() == __ffsll((unsigned long long)b) - 1)
+        atomicAdd(&n_heads[(blockIdx.x * (uint32_t)kWavesPerBlock + (uint32_t)wave_id()) & (kHeadBins - 1u)], (uint32_t)__popcll(b));
+}
 __global__ __launch_bounds__(kBlock) void init_groups_kernel(const uint64_t *__restrict__ ks,
                                                              const uint32_t *__restrict__ vs, uint64_t M,
                                                              uint32_t *__restrict__ sa_r, uint32_t *__restrict__ pos,
-                                                             uint8_t *__restrict__ head)
+                                                             uint8_t *__restrict__ head, uint32_t *__restrict__ n_heads)
 {
     const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= M) return;
-    sa_r[j] = vs[j];
-    pos[j] = (uint32_t)j;
-    head[j] = (j == 0 || ks[j] != ks[j - 1]) ? 1 : 0;
+    bool hd = false;
+    if (j < M) {
+        sa_r[j] = vs[j];
+        pos[j] = (uint32_t)j;
+        hd = j == 0 || ks[j] != ks[j - 1];
+        head[j] = hd ? 1 : 0;
+    }
+    count_heads(hd, n_heads);
 }
 
 // group id = SA position of the group's first member, carried by a max-scan
@@ -108,12 +122,132 @@ struct OutKeep {
 __global__ __launch_bounds__(kBlock) void regroup_kernel(const uint64_t *__restrict__ k2s,
                                                          const uint32_t *__restrict__ sas,
                                                          const uint32_t *__restrict__ pos2, uint64_t A,
-                                                         uint32_t *__restrict__ sa_r, uint8_t *__restrict__ head2)
+                                                         uint32_t *__restrict__ sa_r, uint8_t *__restrict__ head2,
+                                                         uint32_t *__restrict__ n_heads)
 {
     const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= A) return;
-    head2[t] = (t == 0 || k2s[t] != k2s[t - 1]) ? 1 : 0;
-    sa_r[pos2[t]] = sas[t];
+    bool hd = false;
+    if (t < A) {
+        hd = t == 0 || k2s[t] != k2s[t - 1];
+        head2[t] = hd ? 1 : 0;
+        sa_r[pos2[t]] = sas[t];
+    }
+    count_heads(hd, n_heads);
+}
+
+// Small groups in one wave.  The active list is in suffix order, so a round only has to order every group's members
+// by the rank h symbols ahead: the group part of the (group, rank) key is sorted already, and re-sorting all of it
+// through eight radix passes is what a collection of near-identical sequences pays round after round (every suffix
+// in a group of as many members as there are copies).  A wave takes a window of 64 consecutive list slots, windows
+// start every kWaveStride slots; it owns the groups whose first member lies in the window's first kWaveStride slots
+// and that end inside the window -- every group of up to 64 - kWaveStride + 1 members is owned by exactly one wave,
+// longer ones by at most one.  A member's place is its group's first slot + the members with a smaller rank + the
+// members with the same rank to its left, counted by reading the window's 64 (group, rank) pairs lane by lane.
+// Members of groups no wave owns stay unmarked in done[] and take the radix sorts.
+constexpr int kWaveStride = 48;
+constexpr uint64_t kWaveTierMeanGroup = 24; // the waves take a round when its groups hold at most this many members on average
+struct InNotDone {
+    const uint8_t *done;
+    __device__ __forceinline__ uint32_t operator()(uint64_t t) const { return done[t] ? 0u : 1u; }
+};
+struct OutNotDone {
+    const uint64_t *key2;
+    const uint32_t *val2;
+    uint64_t *ksub;
+    uint32_t *vsub, *sub_t;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const
+    {
+        if (!v) return;
+        ksub[excl] = key2[t];
+        vsub[excl] = val2[t];
+        sub_t[excl] = (uint32_t)t;
+    }
+};
+__global__ __launch_bounds__(kBlock) void doubling_wave_groups_kernel(const uint64_t *__restrict__ key2,
+                                                                      const uint32_t *__restrict__ val2,
+                                                                      const uint32_t *__restrict__ pos2, uint64_t A,
+                                                                      uint32_t rb, uint32_t *__restrict__ v_out,
+                                                                      uint8_t *__restrict__ head2,
+                                                                      uint32_t *__restrict__ sa_r,
+                                                                      uint8_t *__restrict__ done,
+                                                                      uint32_t *__restrict__ n_heads)
+{
+    const uint64_t base = ((uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)wave_id()) * kWaveStride;
+    if (base >= A) return; // (the whole wave)
+    const int l = lane_id();
+    const uint64_t t = base + (uint64_t)l;
+    const bool valid = t < A;
+    const uint64_t key = valid ? key2[t] : ~0ull;
+    const uint32_t val = valid ? val2[t] : 0u, ps = valid ? pos2[t] : 0u;
+    constexpr uint32_t kNoGroup = 0xFFFFFFFFu; // (group ids are list positions: below 2^32 - 1)
+    const uint32_t g = valid ? (uint32_t)(key >> rb) : kNoGroup;
+    const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull));
+    // the slot before the window and the one after it, for the groups that cross its ends
+    const uint32_t g_before = base > 0 ? (uint32_t)(key2[base - 1] >> rb) : kNoGroup;
+    const uint32_t g_after = base + kWave < A ? (uint32_t)(key2[base + kWave] >> rb) : kNoGroup;
+    uint32_t g_left = __shfl_up(g, 1, kWave);
+    if (l == 0) g_left = g_before;
+    // a slot opens a group when its group differs from its left neighbour's; the slot after the last one closes the list
+    const uint64_t heads = __ballot((valid && g != g_left) || t == A ? 1 : 0);
+    const uint64_t upto = heads & lanemask_le();
+    const int first = upto ? 63 - __clzll((unsigned long long)upto) : -1; // lane of the group's first member
+    const uint64_t later = heads & ~lanemask_le();
+    const bool open_end = later == 0ull && g == g_after; // the group goes on behind the window
+    const bool owned = valid && first >= 0 && first < kWaveStride && !open_end;
+    // members of the group to the left and to the right, one lane further every step, as far as the longest owned
+    // group reaches (a collection of 16 copies: 15 steps; a long group: the whole window, lane by lane)
+    const int my_end = later ? __ffsll((unsigned long long)later) - 1 : kWave; // lane after the group's last member
+    uint32_t reach = owned ? (uint32_t)(my_end - first) : 0u;
+    reach = wave_reduce_max(reach);
+    uint32_t less = 0, same_left = 0;
+    if (reach <= 24u) { // uniform
+        for (uint32_t o = 1; o < reach; ++o) {
+            const uint32_t gu = __shfl_up(g, o, kWave), ru = __shfl_up(r, o, kWave);
+            const uint32_t gd = __shfl_down(g, o, kWave), rd = __shfl_down(r, o, kWave);
+            const bool mate_u = (uint32_t)l >= o && gu == g, mate_d = (uint32_t)l + o < (uint32_t)kWave && gd == g;
+            less += (mate_u && ru < r) ? 1u : 0u;
+            same_left += (mate_u && ru == r) ? 1u : 0u;
+            less += (mate_d && rd < r) ? 1u : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < kWave; ++d) {
+            const uint32_t gd = (uint32_t)__builtin_amdgcn_readlane((int)g, d), rd = (uint32_t)__builtin_amdgcn_readlane((int)r, d);
+            const bool mate = gd == g;
+            less += (mate && rd < r) ? 1u : 0u;
+            same_left += (mate && rd == r && d < l) ? 1u : 0u;
+        }
+    }
+    const int at = first + (int)(less + same_left); // lane whose slot the member moves to
+    const uint32_t p_at = __shfl(ps, at < 0 ? 0 : at, kWave);
+    if (owned) {
+        const uint64_t slot = base + (uint64_t)at;
+        v_out[slot] = val;
+        head2[slot] = same_left == 0 ? 1 : 0; // first of its run of equal ranks (the group's first member included)
+        sa_r[p_at] = val;
+        done[slot] = 1;
+    }
+    count_heads(owned && same_left == 0, n_heads);
+}
+
+// the members ordered by the radix sorts go back to their slots: sorted slot j of the sub-list is list slot sub_t[j]
+__global__ __launch_bounds__(kBlock) void regroup_sub_kernel(const uint64_t *__restrict__ k2s,
+                                                             const uint32_t *__restrict__ sas,
+                                                             const uint32_t *__restrict__ sub_t,
+                                                             const uint32_t *__restrict__ pos2, uint64_t A3,
+                                                             uint32_t *__restrict__ v_out, uint32_t *__restrict__ sa_r,
+                                                             uint8_t *__restrict__ head2, uint32_t *__restrict__ n_heads)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool hd = false;
+    if (j < A3) {
+        const uint32_t t = sub_t[j], s = sas[j];
+        hd = j == 0 || k2s[j] != k2s[j - 1];
+        head2[t] = hd ? 1 : 0;
+        v_out[t] = s;
+        sa_r[pos2[t]] = s;
+    }
+    count_heads(hd, n_heads);
 }
 
 // ---- sorted LMS suffixes -----------------------------------------------------------
@@ -172,8 +306,11 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
 
     uint32_t *pos = rb.pos_a, *pos2 = rb.pos_b;
     uint8_t *head = rb.head_a, *head2 = rb.head_b;
+    uint32_t *n_heads = rb.head_bins; // groups of the list a round leaves (singletons included), in kHeadBins partial counts
+    std::vector<uint32_t> h_bins(kHeadBins);
+    SX_CHECK(hipMemsetAsync(n_heads, 0, kHeadBins * sizeof(uint32_t), ctx->stream));
     sx_launch(ctx, SX_KC_DOUBLING, M * (12 + 9), init_groups_kernel, dim3(sx_div_up(M, kBlock)), block,
-              (const uint64_t *)ks, (const uint32_t *)vs, M, rb.sa_r, pos, head);
+              (const uint64_t *)ks, (const uint32_t *)vs, M, rb.sa_r, pos, head, n_heads);
     uint32_t *sa = vs; // active suffixes in sorted order
     uint64_t A = M;
     uint64_t h = q;
@@ -190,19 +327,58 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
         if (A2 == 0) return 0;
         if (h >= M) return sx_fail_msg(ctx, SX_E_INTERNAL, "doubling: span exceeds the string with active groups");
         ctx->stats.doubling_rounds++;
-        // e. sort the active suffixes inside their groups by the rank h symbols ahead
-        uint64_t *k_in = kfree, *k_other = ks;
-        uint32_t *v_in = vfree, *v_other = vs;
-        SX_TRY(sx_sort_pairs(ctx, k_in, v_in, k_other, v_other, A2, 0, (int)(2 * rbits), &in_b));
-        ks = in_b ? k_other : k_in;
-        kfree = in_b ? k_in : k_other;
-        vs = in_b ? v_other : v_in;
-        vfree = in_b ? v_in : v_other;
-        // f. new group boundaries, write the refined order back
-        sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A2 * (8 + 4 + 4 + 4 + 1), regroup_kernel,
-                  dim3(sx_div_up(A2, kBlock)), block, (const uint64_t *)ks, (const uint32_t *)vs,
-                  (const uint32_t *)pos2, (uint64_t)A2, rb.sa_r, head2);
-        sa = vs;
+        // every dropped element was a group of its own: the kept list holds the other groups
+        SX_TRY(sx_readback(ctx, n_heads, kHeadBins, h_bins.data()));
+        uint64_t heads = 0;
+        for (uint32_t i = 0; i < kHeadBins; ++i) heads += h_bins[i];
+        const uint64_t dropped = A - A2, groups = heads > dropped ? heads - dropped : 1;
+        // Small groups (a collection of near-identical sequences: as many members as copies) are ordered by one wave
+        // each; the others, and all of them when the groups are long on average, by radix sorts of (group, rank).
+        // (SX_FLAG_SORT_MODE 1: plain passes only.)
+        const bool wave_tier = ctx->sort_mode != 1 && (uint64_t)A2 <= groups * kWaveTierMeanGroup;
+        SX_CHECK(hipMemsetAsync(n_heads, 0, kHeadBins * sizeof(uint32_t), ctx->stream));
+        if (wave_tier) {
+            // e. (the old arrays are free now: sa receives the new order, the old head flags serve as done[])
+            ctx->stats.refine_tiers |= 4u;
+            uint8_t *done = head;
+            SX_CHECK(hipMemsetAsync(done, 0, A2, ctx->stream));
+            const uint64_t waves = sx_div_up(A2, kWaveStride);
+            sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A2 * (8 + 4 + 4 + 4 + 4 + 2), doubling_wave_groups_kernel,
+                      dim3(sx_div_up(waves, kWavesPerBlock)), block, (const uint64_t *)kfree, (const uint32_t *)vfree,
+                      (const uint32_t *)pos2, (uint64_t)A2, rbits, sa, head2, rb.sa_r, done, n_heads);
+            // the members of groups no wave owned: radix sorts of the compacted sub-list, then back to their slots
+            uint64_t *k_in = ks;     // (the sorted keys are not needed once the groups are marked)
+            uint32_t *v_in = rb.gid; // (free after the compaction above)
+            SX_TRY((device_compact(ctx, A2, InNotDone{done}, OutNotDone{kfree, vfree, k_in, v_in, rb.sub_t},
+                                   rb.d_scalar + 1, SX_KC_DOUBLING, (uint64_t)A2 * 2)));
+            uint32_t A3 = 0;
+            SX_TRY(sx_readback(ctx, rb.d_scalar + 1, 1, &A3));
+            if (A3) {
+                ctx->stats.refine_tiers |= 8u;
+                uint64_t *k_other = kfree; // (copied into the sub-list: free)
+                uint32_t *v_other = pos;   // (the old slots: free after the compaction above)
+                SX_TRY(sx_sort_pairs(ctx, k_in, v_in, k_other, v_other, A3, 0, (int)(2 * rbits), &in_b));
+                sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A3 * (8 + 4 + 4 + 4 + 4 + 1), regroup_sub_kernel,
+                          dim3(sx_div_up(A3, kBlock)), block, (const uint64_t *)(in_b ? k_other : k_in),
+                          (const uint32_t *)(in_b ? v_other : v_in), (const uint32_t *)rb.sub_t, (const uint32_t *)pos2,
+                          (uint64_t)A3, sa, rb.sa_r, head2, n_heads);
+            }
+        } else {
+            // e. sort the active suffixes inside their groups by the rank h symbols ahead
+            ctx->stats.refine_tiers |= 8u;
+            uint64_t *k_in = kfree, *k_other = ks;
+            uint32_t *v_in = vfree, *v_other = vs;
+            SX_TRY(sx_sort_pairs(ctx, k_in, v_in, k_other, v_other, A2, 0, (int)(2 * rbits), &in_b));
+            ks = in_b ? k_other : k_in;
+            kfree = in_b ? k_in : k_other;
+            vs = in_b ? v_other : v_in;
+            vfree = in_b ? v_in : v_other;
+            // f. new group boundaries, write the refined order back
+            sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A2 * (8 + 4 + 4 + 4 + 1), regroup_kernel,
+                      dim3(sx_div_up(A2, kBlock)), block, (const uint64_t *)ks, (const uint32_t *)vs,
+                      (const uint32_t *)pos2, (uint64_t)A2, rb.sa_r, head2, n_heads);
+            sa = vs;
+        }
         A = A2;
         h *= 2;
         uint32_t *tp = pos; pos = pos2; pos2 = tp;

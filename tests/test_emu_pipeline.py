@@ -58,6 +58,44 @@ def test_both_lms_paths(emu_ctx):
     assert (1, True) in seen and any(p == 2 for p, _ in seen)
 
 
+def test_near_identical_copies_double_by_waves(emu_ctx):
+    """a collection of near-identical sequences (8 copies of one random text, 0.3 % of the symbols replaced): every LMS
+    suffix is tied with seven others for hundreds of symbols, the general path's prefix-doubling rounds order the
+    small groups by one wave each (doubling_wave_groups_kernel); groups that cross a wave's window or hold more than
+    64 members, and every group with SX_FLAG_SORT_MODE 1, take the radix sorts"""
+    rng = np.random.default_rng(17)
+    one = rng.integers(1, 5, size=8000, dtype=np.uint8)
+    parts = []
+    for _ in range(8):
+        c = one.copy()
+        hit = rng.random(c.size) < 0.003
+        c[hit] = rng.integers(1, 5, size=int(hit.sum()), dtype=np.uint8)
+        parts.append(c)
+    x = np.concatenate(parts)
+    want = oracle.sa_is(x, 5)
+    assert (_sa(emu_ctx, x, 5) == want).all()
+    st = emu_ctx.last_stats()
+    assert st["lms_path"] == 2 and st["refine_tiers"] & 4 and st["doubling_rounds"] >= 5, st
+    emu_ctx.set_sort_mode(1)
+    try:
+        assert (_sa(emu_ctx, x, 5) == want).all()
+        st = emu_ctx.last_stats()
+        assert st["lms_path"] == 2 and st["refine_tiers"] & 12 == 8, st
+    finally:
+        emu_ctx.set_sort_mode(0)
+    # 100 copies of a short piece on top: their groups are longer than a wave's window and take the radix sorts in the same
+    # rounds in which the waves order the groups of 8
+    y = np.concatenate([x] + [one[:200]] * 100)
+    assert (_sa(emu_ctx, y, 5) == oracle.sa_is(y, 5)).all()
+    st = emu_ctx.last_stats()
+    assert st["lms_path"] == 2 and st["refine_tiers"] & 12 == 12, st
+    # 100 copies of a text and nothing else: long groups on average, the rounds go straight to the radix sorts
+    z = np.concatenate([one[:500]] * 100 + [one[:300]])
+    assert (_sa(emu_ctx, z, 5) == oracle.sa_is(z, 5)).all()
+    st = emu_ctx.last_stats()
+    assert st["lms_path"] == 2 and st["refine_tiers"] & 8, st
+
+
 def test_static_key_shapes(emu_ctx):
     """the key kernel's static forms for DNA-like texts (prefix lengths of 64 Mi ... 4 Gi symbol inputs), forced
     on small texts: keys and embedded windows by dot products"""

@@ -1003,6 +1003,30 @@ def test_duplication_beyond_the_comparison_cap(gpu_ctx):
     assert gpu_ctx.last_stats()["lms_path"] == 2
 
 
+def test_near_identical_copies_double_by_waves(gpu_ctx):
+    """16 copies of one random 1 Mi-symbol text with 0.1 % of the symbols replaced (what a collection of assemblies of one
+    species looks like): the general path's doubling rounds order the groups of 16 by one wave each; the plain-passes
+    mode orders them by radix sorts; both match the oracle"""
+    rng = np.random.default_rng(23)
+    one = rng.integers(1, 5, size=1 << 20, dtype=np.uint8)
+    parts = []
+    for _ in range(16):
+        c = one.copy()
+        hit = rng.random(c.size) < 0.001
+        c[hit] = rng.integers(1, 5, size=int(hit.sum()), dtype=np.uint8)
+        parts.append(c)
+    x = np.concatenate(parts)
+    want = oracle.sa_is(x, 5)
+    try:
+        for mode, bits in ((0, 4), (1, 8)):
+            gpu_ctx.set_sort_mode(mode)
+            assert (gpu_ctx.sa_build(x, 5) == want).all(), mode
+            st = gpu_ctx.last_stats()
+            assert st["lms_path"] == 2 and st["refine_tiers"] & bits, (mode, st)
+    finally:
+        gpu_ctx.set_sort_mode(0)
+
+
 def test_differential_fuzz():
     """tools/fuzz_gpu.py: 250 random (size, alphabet, structure, path flag) combinations against the oracle --
     suffix array, C and O tables from (text, sa) and from the fused build.  (This is the harness that found the
