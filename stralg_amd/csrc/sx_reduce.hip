@@ -314,6 +314,7 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
     uint32_t *sa = vs; // active suffixes in sorted order
     uint64_t A = M;
     uint64_t h = q;
+    bool waves_pay = true; // until a round leaves more than a quarter of its members to the radix sorts all the same
     for (int round = 0; round < 64; ++round) {
         // a. group ids and ranks of the active suffixes
         SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidRank{sa, rb.gid, rb.rank}, nullptr,
@@ -335,7 +336,7 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
         // Small groups (a collection of near-identical sequences: as many members as copies) are ordered by one wave
         // each; the others, and all of them when the groups are long on average, by radix sorts of (group, rank).
         // (SX_FLAG_SORT_MODE 1: plain passes only.)
-        const bool wave_tier = ctx->sort_mode != 1 && (uint64_t)A2 <= groups * kWaveTierMeanGroup;
+        const bool wave_tier = ctx->sort_mode != 1 && waves_pay && (uint64_t)A2 <= groups * kWaveTierMeanGroup;
         SX_CHECK(hipMemsetAsync(n_heads, 0, kHeadBins * sizeof(uint32_t), ctx->stream));
         if (wave_tier) {
             // e. (the old arrays are free now: sa receives the new order, the old head flags serve as done[])
@@ -353,6 +354,7 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
                                    rb.d_scalar + 1, SX_KC_DOUBLING, (uint64_t)A2 * 2)));
             uint32_t A3 = 0;
             SX_TRY(sx_readback(ctx, rb.d_scalar + 1, 1, &A3));
+            if ((uint64_t)A3 * 4 > (uint64_t)A2) waves_pay = false; // (a few long groups hold much of the list: words of a vocabulary)
             if (A3) {
                 ctx->stats.refine_tiers |= 8u;
                 uint64_t *k_other = kfree; // (copied into the sub-list: free)
