@@ -281,11 +281,19 @@ __global__ __launch_bounds__(kBlock) void otable_wide_kernel(const uint8_t *__re
         __syncthreads();
         if (cp == 0 && sym < sigma) atomicAdd(&gtot[rg][sym], 1u); // (one wave per row group does the counting)
         __syncthreads();
-        for (uint32_t a = cp; a < sigma; a += CP) {
-            uint32_t base = pre[a];
-            for (uint32_t g = 0; g < rg; ++g) base += gtot[g][a];
+        // counts -> the count every row group starts from (one thread per column): a column step then reads one word
+        if ((uint32_t)t < sigma) {
+            uint32_t run = pre[t];
+            for (uint32_t g = 0; g < RG; ++g) {
+                const uint32_t c = gtot[g][t];
+                gtot[g][t] = run;
+                run += c;
+            }
+        }
+        __syncthreads();
+        for (uint32_t a = cp; a < sigma; a += CP) { // (four columns a step with their reads and ballots interleaved: no faster)
             const uint64_t m = __ballot(sym == a ? 1 : 0);
-            rows[(rg * kWave + (uint32_t)lane) * stride + a] = base + (uint32_t)__popcll(m & lanemask_lt());
+            rows[(rg * kWave + (uint32_t)lane) * stride + a] = gtot[rg][a] + (uint32_t)__popcll(m & lanemask_lt());
         }
         __syncthreads();
         const uint64_t rows_left = N + 1 - tile0;
