@@ -19,6 +19,11 @@
 
 // workgroups of the wide O-table kernel, each looping over its tiles (sigma 21 at 1 GiB, 4.2 M tiles of 256 rows: 20.5 ms
 // with a workgroup per tile, 17.6 with 65 536 workgroups, 18.1 with 16 384, 18.8 with 4096)
+// ... and of the kernel for small alphabets (1 GiB of DNA, 1 M tiles of 1024 rows: 4.19 ms with a workgroup per tile,
+// 3.92 with 262 144 workgroups, 3.87 with 65 536, 3.96 with 16 384)
+#ifndef SX_SMALL_GRID
+#define SX_SMALL_GRID 65536u
+#endif
 #ifndef SX_WIDE_GRID
 #define SX_WIDE_GRID 65536u
 #endif
@@ -171,13 +176,14 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     constexpr int kRows = small_cfg<SIG>::rows, kTile = small_cfg<SIG>::tile;
     __shared__ __attribute__((aligned(16))) uint32_t rows[kTile * SIG];
     const int t = (int)threadIdx.x;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // SX_SMALL_GRID
+    const uint64_t tile0 = (uint64_t)tile * kTile;
     const uint64_t r0 = tile0 + (uint64_t)t * kRows;
     // the tile's starting counts: asked for first, needed only after the block scan
     uint32_t pre[SIG];
 #pragma unroll
     for (int a = 0; a < SIG; ++a)
-        pre[a] = (uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + blockIdx.x] - tilepre[(uint64_t)a * ntiles] : 0u;
+        pre[a] = (uint32_t)a < sigma ? tilepre[(uint64_t)a * ntiles + tile] - tilepre[(uint64_t)a * ntiles] : 0u;
     uint32_t sym[kRows];
     // per-thread symbol counts as 16-bit fields of two u64 (symbols 0-3, 4-7): a tile holds at most
     // 1024 symbols, so one 64-bit block scan replaces four 32-bit ones
@@ -251,6 +257,8 @@ __global__ __launch_bounds__(kBlock) void otable_small_kernel(const uint8_t *__r
     const uint32_t nrows = rows_left < (uint64_t)kTile ? (uint32_t)rows_left : (uint32_t)kTile;
     const uint32_t nwords = nrows * sigma;
     store_rows(rows, o_out + tile0 * sigma, nwords);
+    __syncthreads(); // rows[] is reused by the next tile
+    }
 }
 
 // O rows for 8 < sigma <= 128.  A tile is RG groups of 64 rows (RG = 4, 2, 1 for sigma <= 32, 64, 128: about
@@ -374,7 +382,7 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
         // small alphabets: the kernel whose row length is sigma itself assembles a thread's rows in registers and
         // hands them to LDS 16 bytes at a time (sigma = 6 through the 8-column form: 7.3 instead of 5.3 ms at 1 GiB)
 #define SX_OTABLE_SMALL(SIG)                                                                                           \
-    sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<SIG>, dim3(ntiles), dim3(kBlock), bwt, N, sigma,       \
+    sx_launch(ctx, SX_KC_OTABLE, out_bytes, otable_small_kernel<SIG>, dim3(ntiles < SX_SMALL_GRID ? ntiles : SX_SMALL_GRID), dim3(kBlock), bwt, N, sigma,       \
               (const uint32_t *)tilehist, ntiles, d_o)
         if (small) {
             switch (sigma) {
