@@ -92,8 +92,8 @@ __global__ __launch_bounds__(kBlock) void bwt_count_wave_kernel(const uint8_t *_
                                                                 uint32_t ntiles)
 {
     const int lane = lane_id();
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave_id();
-    if (tile >= ntiles) return; // whole waves
+    // (whole waves; a wave walks over its tiles: 65 536 workgroups instead of one per four tiles)
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave_id(); tile < ntiles; tile += gridDim.x * kWavesPerBlock) {
     const uint64_t r0 = (uint64_t)tile * 1024u + (uint64_t)lane * 16u;
     uint32_t S[4] = {0, 0, 0, 0};
     uint32_t inside = 0xFFFFu; // rows below N
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kBlock) void bwt_count_wave_kernel(const uint8_t *_
     odd = wave_total_packed(odd);
     if ((uint32_t)lane < sigma && lane < 8)
         tilehist[(uint64_t)lane * ntiles + tile] = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
+    }
 }
 
 // The tile counts [sigma][ntiles] are scanned as one flat array (device_scan); the prefix of
@@ -358,7 +359,8 @@ static int bwt_tables_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_
 
     static_assert(small_cfg<5>::tile == 1024 && small_cfg<8>::tile == 1024, "bwt_count_wave: a wave per 1024-row tile");
     if (d_bwt_in && small)
-        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_wave_kernel, dim3(sx_div_up(ntiles, kWavesPerBlock)), dim3(kBlock), d_bwt_in,
+        sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_wave_kernel,
+                  dim3(sx_div_up(ntiles, kWavesPerBlock) < SX_SMALL_GRID ? sx_div_up(ntiles, kWavesPerBlock) : SX_SMALL_GRID), dim3(kBlock), d_bwt_in,
                   N, sigma, tilehist, ntiles);
     else if (d_bwt_in)
         sx_launch(ctx, SX_KC_BWT_GATHER, N, bwt_count_kernel, dim3(loop_grid), dim3(kBlock), d_bwt_in, N, tile_rows, sigma,
