@@ -77,7 +77,7 @@ typedef struct sx_build_stats {
     uint32_t sort_passes;    /* radix passes, all sorts */
     uint32_t lms_path;       /* 1: prefix-key LMS sort resolved everything, 2: general path, 3: direct sort of all suffixes */
     uint32_t sort_local;     /* bit 0: the prefix-key sort finished in LDS (hybrid: HBM passes on the top 24 key bits only);
-                                bit 1: some workgroup of it met crowded bins and took stable passes */
+                                bit 1: some workgroup of it met crowded bins and took stable passes; bit 2: HBM passes on the top 32 bits (four) */
     uint32_t refine_tiers;   /* tie refinement of the prefix-key sort: bit 0: some round ordered groups of 9 .. 2048 members in
                                 LDS; bit 1: some round sent the members of longer groups through radix sorts; prefix doubling of the
                                 general path: bit 2: some round ordered small groups by one wave each, bit 3: some round sent
@@ -102,8 +102,8 @@ enum {
     SX_FLAG_PREFIX_SYMBOLS = 4,     /* first attempt of the prefix-key sort takes this many symbols (0: by the text's size) */
     SX_FLAG_RADIX_DIGIT_BITS = 5,   /* digit width of the LSD radix passes: 8 (default), 9 or 10 */
     SX_FLAG_SORT_MODE = 6           /* prefix-key sort: 0 choose, 1 LSD passes only (tie refinement too: no group is ordered in
-                                       LDS), 2 hybrid (HBM passes on the top bits + sub-buckets ordered in LDS) whenever the
-                                       key shape allows it, whatever the size */
+                                       LDS), 2 hybrid (HBM passes on the top 24 key bits + sub-buckets ordered in LDS) whenever the
+                                       key shape allows it, whatever the size, 3 the same with the top 32 bits */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

@@ -223,7 +223,8 @@ class Context:
         self._check(self.lib.sx_ctx_set_flag(self.h, 5, int(bits)), "sx_ctx_set_flag")
 
     def set_sort_mode(self, mode):
-        """SX_FLAG_SORT_MODE: 0 choose, 1 LSD passes only, 2 hybrid sort wherever the key shape allows it."""
+        """SX_FLAG_SORT_MODE: 0 choose, 1 LSD passes only, 2 hybrid sort wherever the key shape allows it (HBM passes on
+        the top 24 key bits), 3 the same with the top 32 bits."""
         self._check(self.lib.sx_ctx_set_flag(self.h, 6, int(mode)), "sx_ctx_set_flag")
 
     def trim(self):

@@ -226,7 +226,7 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         return 0;
     }
     if (flag == SX_FLAG_SORT_MODE) {
-        if (value < 0 || value > 2) return SX_E_ARG;
+        if (value < 0 || value > 3) return SX_E_ARG;
         ctx->sort_mode = value;
         return 0;
     }

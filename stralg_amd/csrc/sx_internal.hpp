@@ -75,15 +75,16 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                           const void **seed_windows, int *resolved, bool all_suffixes = false);
 
 // ---- sx_localsort.hip: the hybrid sort's last step (sub-buckets of equal top key bits ordered in LDS)
-constexpr int kSxHybridTopBits = 24; // key bits that go through HBM passes (three 8-bit passes)
-bool sx_local_sort_applies(uint64_t m, int kbits);
+// key bits that go through HBM passes: 24 (three 8-bit passes) or, when those leave sub-buckets too long for a workgroup
+// (texts of 2 Gi symbols and more, skewed symbol frequencies), 32 (four)
+bool sx_local_sort_applies(uint64_t m, int kbits, int top_bits);
 uint32_t sx_local_sort_tiles(uint64_t m);
-// (kin, vin): m pairs ordered by key bits [kbits - 24, kbits).  Writes the positions in key order to vout, the keys'
+// (kin, vin): m pairs ordered by key bits [kbits - top_bits, kbits).  Writes the positions in key order to vout, the keys'
 // payload bits (from kbits on) to seedw (optional), the members of groups of equal keys to (apos, ap, ahead)
 // (at most cap), their number to d_total_and_fail[0]; d_total_and_fail[1] <- bit 0 when a sub-bucket did not fit a
 // workgroup (the outputs are then unusable), bit 1 when some workgroup used stable passes (statistics).  tile_*: one u32 per workgroup (sx_local_sort_tiles); stage: m x 8
 // bytes, stage_head: m bytes of scratch.
-int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, uint32_t *vout,
+int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t *vout,
                   uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
                   uint32_t *d_total_and_fail);

@@ -1045,12 +1045,17 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         // ordered in LDS.  It needs sub-buckets that fit a workgroup: a prefix of 24 / log2(base) symbols must not be too
         // frequent.  Judged here from the text's most frequent symbol (a run of it is the most frequent prefix of a text
         // without repeats); repeats show when the kernel finds a sub-bucket that does not fit, and LSD passes finish the job.
-        bool hybrid = ctx->sort_mode != 1 && sort_db == 8 && sx_local_sort_applies(m, kbits) && tile_lsrt != nullptr;
-        if (hybrid && ctx->sort_mode == 0) {
-            // Sub-buckets the top bits leave: the low L = kbits - 24 bits span base^(L / log2 base) key values, so the
+        int top_bits = 0; // of the hybrid sort; 0: plain passes over all key bits
+        if (ctx->sort_mode != 1 && sort_db == 8 && tile_lsrt != nullptr) {
+            // Sub-buckets the top bits leave: the low L = kbits - top bits span base^(L / log2 base) key values, so the
             // top bits tell apart prefixes of C - L / log2(base) symbols (A C G T in base 5, 17 symbols, L = 16: 10.1) -- and
             // a text has about (effective alphabet)^(that many) of those, the effective alphabet being 1 / sum p^2 (4,
             // not 5: a fifth of the key space per symbol is never used).  Also: the copies of the most frequent one.
+            // Three passes (24 bits).  Four passes (32 bits) leave short sub-buckets in texts of 2 Gi symbols and more and
+            // with skewed frequencies too (2 GiB of uniform DNA: 40.3 against 43.2 ms for six plain passes), but are only
+            // taken when asked for (SX_FLAG_SORT_MODE 3): texts that long are genomes, their repeat families overflow a
+            // workgroup whatever the symbol counts promise, and a failed attempt costs more than a good one saves
+            // (the genome-like 1 GiB text: 58 instead of 44 ms).
             double pmax = 0.0, sum_p2 = 0.0;
             const double n_sym = (double)ti.N - 1.0;
             for (int c = 1; c < 256 && n_sym > 0; ++c) {
@@ -1058,13 +1063,21 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 if (pc > pmax) pmax = pc;
                 sum_p2 += pc * pc;
             }
-            const double syms = (double)C - (double)(kbits - kSxHybridTopBits) / log2((double)base);
             const double eff = sum_p2 > 0.0 ? 1.0 / sum_p2 : 1.0;
-            const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
-            const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
-            if (m < (1u << 22) || mean_bucket > 300.0 || top_bucket > 400.0) hybrid = false; // (a workgroup holds a sub-bucket of up to 1024)
+            for (int cand = 24; cand <= 32 && top_bits == 0; cand += 8) {
+                if (!sx_local_sort_applies(m, kbits, cand)) continue;
+                if (ctx->sort_mode >= 2) { // forced (tests): 2 three passes, 3 four
+                    if ((ctx->sort_mode == 2) == (cand == 24)) top_bits = cand;
+                    continue;
+                }
+                const double syms = (double)C - (double)(kbits - cand) / log2((double)base);
+                const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
+                const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
+                if (cand == 24 && m >= (1u << 22) && mean_bucket <= 300.0 && top_bucket <= 400.0) top_bits = cand; // (a workgroup holds a sub-bucket of up to 1024)
+            }
         }
-        const uint32_t dig_shift = hybrid ? (uint32_t)(kbits - kSxHybridTopBits) : 0u;
+        const bool hybrid = top_bits != 0;
+        const uint32_t dig_shift = hybrid ? (uint32_t)(kbits - top_bits) : 0u;
         const uint32_t dig_mask = kbits - (int)dig_shift >= 8 ? 0xFFu : (1u << (kbits - (int)dig_shift)) - 1u;
         if (all_suffixes && C <= 12) {
             const pkey_cfg kc = pkey_make(base, C);
@@ -1111,11 +1124,11 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         bool listed = false; // the members of groups of equal keys are in (apos, ap, head), A of them
         if (hybrid) {
             // three stable passes on the top 24 bits, then the sub-buckets in LDS: positions, windows and ties in one go
-            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - kSxHybridTopBits, kbits, &in_b, all_suffixes, true, 8));
+            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - top_bits, kbits, &in_b, all_suffixes, true, 8));
             const uint64_t *kin = in_b ? kb : ka;
             const uint32_t *vin = in_b ? vb : va;
             uint32_t *vo = in_b ? va : vb;
-            SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
+            SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, top_bits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
                                  tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar));
             uint32_t res[2] = {0, 0};
             SX_TRY(sx_readback(ctx, d_scalar, 2, res));
@@ -1124,7 +1137,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 vs = vo;
                 ks = nullptr; // (the sorted keys are not written by this path; nothing below reads them)
                 listed = true;
-                ctx->stats.sort_local = 1u | (res[1] & 2u); // (bit 1: some workgroup ordered its pairs by stable passes)
+                ctx->stats.sort_local = 1u | (res[1] & 2u) | (top_bits == 32 ? 4u : 0u); // (bit 1: some workgroup ordered its pairs by stable passes)
             } else {
                 // a sub-bucket too long for a workgroup (a repeated prefix): plain LSD passes over all key bits from here
                 uint64_t *k0 = in_b ? kb : ka, *k1 = in_b ? ka : kb;

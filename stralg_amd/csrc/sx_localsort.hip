@@ -420,20 +420,20 @@ using namespace sx;
 
 uint32_t sx_local_sort_tiles(uint64_t m) { return sx_div_up(m, kLsSpan); }
 
-bool sx_local_sort_applies(uint64_t m, int kbits)
+bool sx_local_sort_applies(uint64_t m, int kbits, int top_bits)
 {
-    // the top kSxHybridTopBits go through HBM passes, the low L = kbits - 24 bits (with up to 13 bits of sub-bucket rank)
+    // the top `top_bits` go through HBM passes, the low L = kbits - top_bits bits (with up to 13 bits of sub-bucket rank)
     // must fit the 32-bit sort field of an LDS item, the payload the other 32
-    return m >= 1 && kbits >= 32 && kbits - kSxHybridTopBits <= 19;
+    return m >= 1 && kbits >= 32 && kbits - top_bits >= 1 && kbits - top_bits <= 19;
 }
 
-int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, uint32_t *vout,
+int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t *vout,
                   uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
                   uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used */)
 {
     const uint32_t tiles = sx_local_sort_tiles(m);
-    const uint32_t L = (uint32_t)(kbits - kSxHybridTopBits);
+    const uint32_t L = (uint32_t)(kbits - top_bits);
     SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, sizeof(uint32_t), ctx->stream));
     sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
               (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1);

@@ -197,7 +197,7 @@ def test_hybrid_prefix_sort(gpu_ctx):
             want = oracle.sa_is(x, sigma)
             bw_want = oracle.bwt(x, want)
             for C in ((14, 16, 17, 18) if sigma == 5 else (13, 16)):
-                for mode in (1, 2):
+                for mode in (1, 2, 3):  # plain passes; HBM passes on the top 24 / 32 key bits, then sub-buckets in LDS
                     gpu_ctx.set_prefix_symbols(C)
                     gpu_ctx.set_sort_mode(mode)
                     xd = torch.from_numpy(x).cuda()
@@ -205,7 +205,7 @@ def test_hybrid_prefix_sort(gpu_ctx):
                     bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
                     gpu_ctx.sa_bwt_build_dev(xd, n, sigma, sa, bw)
                     st = gpu_ctx.last_stats()
-                    assert (st["sort_local"] & 1) == (1 if mode == 2 else 0) and st["key_slots"] == C, (sigma, n, C, mode, st)
+                    assert (st["sort_local"] & 5) == (0, 1, 5)[mode - 1] and st["key_slots"] == C, (sigma, n, C, mode, st)
                     assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n, C, mode)
                     assert (bw.cpu().numpy() == bw_want).all(), (sigma, n, C, mode)
         # 40 copies of a 60-symbol piece: equal keys crowd a bin of the counting pass, that workgroup takes stable passes

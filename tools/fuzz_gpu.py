@@ -48,7 +48,7 @@ for k in range(cases):
         x = np.where(rng.random(n) < 0.9, 1, x).astype(np.uint8)
     flag = int(rng.integers(0, 4))
     ctx.set_chain_max_entries(int(rng.choice([-1, -1, 0, 2048, 8192, 65536, 524288, 4194304])))  # which induce rounds are chained
-    ctx.set_sort_mode(int(rng.choice([0, 1, 2, 2])))  # LSD passes / top bits in HBM passes + sub-buckets in LDS (where the key shape allows)
+    ctx.set_sort_mode(int(rng.choice([0, 1, 2, 2, 3])))  # LSD passes / top bits in HBM passes + sub-buckets in LDS (where the key shape allows)
     ctx.set_radix_digit_bits(int(rng.choice([0, 0, 0, 9, 10])))
     ctx.force_general_path(flag == 1)
     ctx.set_no_direct_sort(flag == 2)

@@ -6,12 +6,16 @@ import stralg_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 32) - 2
 sigma = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ctx = stralg_amd.Context(0)
+if len(sys.argv) > 3:
+    ctx.set_sort_mode(int(sys.argv[3]))  # (3: four HBM passes on the top 32 key bits, then sub-buckets in LDS)
 text = torch.empty(n, dtype=torch.uint8, device="cuda")
 ctx.synth_dev(text, n, sigma, 7)
 sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
-torch.cuda.synchronize(); t0 = time.perf_counter()
-ctx.sa_build_dev(text, n, sigma, sa)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
+for call in range(2):  # (the first call allocates the workspace)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctx.sa_build_dev(text, n, sigma, sa)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"call {call}: {dt*1e3:.1f} ms", flush=True)
 print(f"n = {n}: {dt*1e3:.1f} ms = {n/dt/1e6:.0f} Msuffixes/s, stats {ctx.last_stats()}", flush=True)
 ctx.trim()
 N = n + 1
