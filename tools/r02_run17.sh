@@ -5,7 +5,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT=gpurun_out/r02z
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc=$?" >> $OUT/bench_default.err
+T0=$SECONDS; timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc=$? wall=$((SECONDS-T0)) s" >> $OUT/bench_default.err
 BENCH_ARGS="--steps 2 --warmup 1 --no-cpu --no-e2e --no-verify" timeout 600 bash tools/profile.sh > $OUT/profile.log 2>&1
 cp gpurun_out/prof/summary.txt $OUT/profile_summary.txt
 find gpurun_out/prof/trace -name "*kernel_stats.csv" -newer $OUT/bench_default.json -exec cp {} $OUT/kernel_stats.csv \;
