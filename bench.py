@@ -305,6 +305,12 @@ def run_rank(args):
     # one more untimed step, with events around every launch: the per-class table and the dominant class
     table = profiled_step()
     dom = max(table, key=lambda k: table[k]["ms"])
+    # The induce scatter's class is four kernels (one per pass and source region), the radix scatter's one: when the two
+    # are within 5 % of each other the roofline is taken on the one that is a single row of the rocprofv3 summary
+    # (radix_scatter_kernel is the kernel with the largest total there: 20 ms of 98 against 5.6 for the largest
+    # induce variant); the other class's figures are in "kernels" either way.
+    if dom == "induce_scatter" and table.get("radix_scatter", {}).get("ms", 0.0) >= 0.95 * table[dom]["ms"]:
+        dom = "radix_scatter"
     # Timed region: events only around the dominant kernel's launches (the roofline figure is measured live, on
     # the library's own stream); two event records around each of a step's ~300 launches would cost ~5 % of it.
     ctx.profile_reset()
