@@ -1027,6 +1027,24 @@ def test_near_identical_copies_double_by_waves(gpu_ctx):
         gpu_ctx.set_sort_mode(0)
 
 
+def test_tied_groups_at_the_tier_boundaries(gpu_ctx):
+    """exact copies of one piece, as many as the refinement tiers' limits (8 | 9 .. 2048 | 2049 ..): groups of exactly that
+    many tied suffixes, alone and together, match the oracle"""
+    rng = np.random.default_rng(31)
+    n = 1 << 22
+    for counts in ((8,), (9,), (2047,), (2048,), (2049,), (4096,), (8, 9, 2048, 2049, 64, 3)):
+        x = rng.integers(1, 5, size=n, dtype=np.uint8)
+        at = 1000
+        for g in counts:
+            piece = rng.integers(1, 5, size=70, dtype=np.uint8)
+            for _ in range(g):
+                x[at:at + 70] = piece
+                at += 70 + int(rng.integers(1, 30))
+        assert at < n
+        assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all(), counts
+        assert gpu_ctx.last_stats()["lms_path"] == 1, counts
+
+
 def test_differential_fuzz():
     """tools/fuzz_gpu.py: 250 random (size, alphabet, structure, path flag) combinations against the oracle --
     suffix array, C and O tables from (text, sa) and from the fused build.  (This is the harness that found the
