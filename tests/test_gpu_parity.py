@@ -1045,6 +1045,20 @@ def test_tied_groups_at_the_tier_boundaries(gpu_ctx):
         assert gpu_ctx.last_stats()["lms_path"] == 1, counts
 
 
+def test_copies_at_the_wave_window_boundaries(gpu_ctx):
+    """exact copies of a text, as many as the limits of the doubling rounds' wave tier (a window of 64 list slots, owned
+    groups begin in its first 48: every group of up to 17 has an owner), alone and mixed with longer groups that only
+    sometimes fit a window: the general path matches the oracle"""
+    rng = np.random.default_rng(37)
+    one = rng.integers(1, 5, size=40000, dtype=np.uint8)
+    short = rng.integers(1, 5, size=900, dtype=np.uint8)
+    for copies, extra in ((2, 0), (16, 0), (17, 0), (18, 0), (3, 17), (3, 18), (3, 40), (3, 48), (3, 64), (3, 65), (24, 0), (25, 0)):
+        x = np.concatenate([one] * copies + [short] * extra + [one[:777]])
+        assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all(), (copies, extra)
+        st = gpu_ctx.last_stats()
+        assert st["lms_path"] == 2, (copies, extra, st)
+
+
 def test_differential_fuzz():
     """tools/fuzz_gpu.py: 250 random (size, alphabet, structure, path flag) combinations against the oracle --
     suffix array, C and O tables from (text, sa) and from the fused build.  (This is the harness that found the
