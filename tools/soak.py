@@ -13,7 +13,7 @@ def digest(t):
     return int((x * idx).sum()), int(x.sum())
 from stralg_amd import workloads
 cases = [("dna", 30, 5, False), ("dna", 28, 5, False), ("bytes", 28, 256, False), ("uniform", 27, 21, False), ("dna", 24, 5, False),
-         ("genome_like", 28, 5, False), ("n_runs", 28, 6, False), ("uniform", 26, 12, True), ("bytes", 26, 256, True), ("text_like", 26, 28, False)]
+         ("genome_like", 28, 5, False), ("n_runs", 28, 6, False), ("uniform", 26, 12, True), ("bytes", 26, 256, True), ("text_like", 26, 28, False), ("pangenome", 27, 5, False)]
 for gen, log2n, sigma, no_direct in cases:
     n = 1 << log2n
     ctx.set_no_direct_sort(no_direct)
