@@ -58,6 +58,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last step's results")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
     ap.add_argument("--e2e-log2n", default="28,30", help="sizes of the host-buffer measurements")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other BASELINE.json configurations measured after the timed region (default run only)")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each of the other configurations")
+    ap.add_argument("--no-egress", action="store_true",
+                    help="FASTA records: skip the egress leg (the record's index leaving the GPU on every rank at once)")
     return ap.parse_args(argv)
 
 
@@ -207,6 +212,162 @@ def end_to_end(ctx, sizes, seed):
     return out
 
 
+# ---- the other BASELINE.json configurations, after the timed region ---------------------------------------------------
+
+LMS_PATHS = {0: "none", 1: "prefix-key LMS sort + induced-sort passes", 2: "general path (pieces, names, reduced string) + "
+             "induced-sort passes", 3: "direct prefix sort of all suffixes"}
+
+
+def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_direct=False, cuda=True):
+    """`steps` timed steps of the hot path on one more text (generated on the device), one warm-up that doubles as the
+    per-class profile, results verified on the device afterwards.  Outside bench.py's timed region."""
+    import torch
+    from stralg_amd import farm, verify, workloads
+    text, sigma = workloads.make_text(ctx, gen, n, sigma_arg, seed, dev)
+    if cuda:
+        torch.cuda.synchronize()
+    N = n + 1
+    tables = tables and sigma <= 128
+    sa = torch.empty(N, dtype=torch.int32, device=dev)
+    c_tab = torch.zeros(sigma, dtype=torch.int32, device=dev) if tables else None
+    o_tab = torch.empty((N + 1) * sigma, dtype=torch.int32, device=dev) if tables else None
+    bwt = torch.empty(N, dtype=torch.uint8, device=dev) if tables else None
+
+    def step():
+        if tables:
+            ctx.sa_bwt_build_dev(text, n, sigma, sa, bwt)
+            ctx.bwt_tables_from_bwt_dev(bwt, N, sigma, c_tab, o_tab)
+        else:
+            ctx.sa_build_dev(text, n, sigma, sa)
+
+    ctx.set_no_direct_sort(no_direct)
+    try:
+        ctx.profile_reset()
+        ctx.profile_only(None)
+        ctx.profile_enable(True)
+        step()
+        if cuda:
+            torch.cuda.synchronize()
+        ctx.profile_enable(False)
+        table = ctx.profile_read()
+        elapsed = farm.timed(step, steps, 0, cuda=cuda)
+        stats = ctx.last_stats()
+    finally:
+        ctx.set_no_direct_sort(False)
+    dom = max(table, key=lambda k: table[k]["ms"])
+    d = table[dom]
+    alg_total = sum(v["alg_bytes"] for v in table.values())
+    ms = elapsed / steps * 1e3
+    out = {"n": n, "alphabet_size": sigma, "tables": tables, "steps": steps, "ms_per_step": round(ms, 3),
+           "Msuffixes_per_s": round(N / (ms * 1e-3) / 1e6, 1),
+           "lms_path": stats.get("lms_path"), "algorithm": LMS_PATHS.get(stats.get("lms_path"), "?"),
+           "induce_rounds": stats.get("induce_rounds"),
+           "dominant_class": dom, "dominant_ms_per_step": round(d["ms"], 3),
+           "roofline_frac": round(d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d["ms"] > 0 else 0.0,
+           "whole_step_frac_of_peak": round(alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    ctx.trim()
+    try:
+        verify.verify_build_on_device(text, n, sigma, sa, bwt, c_tab if tables else None, o_tab)
+        out["verified"] = True
+    except AssertionError as e:
+        out["verified"] = False
+        out["error"] = str(e)
+    del text, sa, bwt, c_tab, o_tab
+    if cuda:
+        torch.cuda.empty_cache()
+    return out
+
+
+def other_configs(ctx, dev, steps, cuda=True, log2n=30):
+    """BASELINE.json configs[1] and [3] and one hard text, so that the driver's line carries them too:
+    256 MiB DNA; 1 GiB of random bytes by the default path (direct prefix sort) and through the LMS sort + induced-sort
+    passes (the "wide-alphabet LDS-histogram path" configs[3] names); a genome-like 1 GiB text."""
+    out = {}
+
+    def size(n):
+        return f"{n >> 30}GiB" if n >= 1 << 30 else (f"{n >> 20}MiB" if n >= 1 << 20 else f"{n}B")
+
+    big, quarter = 1 << log2n, 1 << (log2n - 2)
+    for name, gen, n, sig, tables, no_direct in (
+            (f"dna_{size(quarter)}", "dna", quarter, 5, True, False),
+            (f"bytes_{size(big)}", "bytes", big, 256, False, False),
+            (f"bytes_{size(big)}_induced", "bytes", big, 256, False, True),
+            (f"genome_like_{size(big)}", "genome_like", big, 5, True, False)):
+        try:
+            out[name] = measure_config(ctx, dev, gen, n, sig, 42, steps, tables, no_direct, cuda)
+        except Exception as e:  # noqa: BLE001 -- an extra must not take the headline line down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+# ---- FASTA records: the index leaves the GPU (what limits configs[4]: PCIe, host memory, NUMA) -----------------------
+
+def egress_leg(ctx, local_rank, text, n, sigma, world, red_dev, cuda=True):
+    """Every rank at once, between barriers: the record's whole index (suffix array, C, O: 24 bytes per base) leaves
+    the GPU -- (1) stralg_amd_write_complete_bwt_info_stream into /dev/null (stralg/serialise.c:7-18's file, streamed
+    through two pinned buffers: no host copy of the tables), (2) memory permitting, sx_build_tables into malloc'd host
+    arrays as build_complete_table's caller owns them (stralg/bwt.c:134-161).  Both start from the record on the host
+    (H2D included)."""
+    import ctypes as C
+    import numpy as np
+    import psutil
+    import torch
+    from stralg_amd import farm
+    lib = ctx.lib
+    N = n + 1
+    index_bytes = 4 * N + 4 * sigma + 4 * sigma * (N + 1)
+    lut = torch.tensor(list(b"\0ACGTN"), dtype=torch.uint8)
+    letters = lut[text.cpu().long().clamp(max=5)].numpy().tobytes()  # (bytes' own terminator ends the string)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    lib.stralg_amd_write_complete_bwt_info_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
+    lib.stralg_amd_write_complete_bwt_info_stream.restype = C.c_int
+    lib.stralg_amd_set_device.argtypes = [C.c_int]
+    lib.stralg_amd_set_device(local_rank)
+    out = {"index_bytes_per_record": index_bytes}
+    f = libc.fopen(b"/dev/null", b"wb")
+
+    def stream():
+        if lib.stralg_amd_write_complete_bwt_info_stream(f, letters, False) != 0:
+            raise RuntimeError("stralg_amd_write_complete_bwt_info_stream failed")
+
+    stream()  # (the first call pays the thread context's hipMalloc and the pinned buffers)
+    t_own = farm.timed(stream, 1, 0, cuda=cuda)
+    libc.fclose(f)
+    t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
+    out.update(stream_ms_per_record=round(t_max * 1e3, 1),
+               egress_inclusive_Msuffixes_per_s=round(units / t_max / 1e6, 3),
+               d2h_GBps_per_rank=round(index_bytes / t_own / 1e9, 2),
+               d2h_GBps_all_ranks=round(index_bytes * world / t_max / 1e9, 2))
+    lib.stralg_amd_release()
+    # (2) into malloc'd host arrays, when every rank's 24 bytes per base fit the host
+    need = (index_bytes + n) * world
+    fits, _ = farm.reduce_scalars(0.0 if psutil.virtual_memory().available > need * 1.3 else 1.0, 0, device=red_dev)
+    if fits == 0.0:
+        x = text.cpu().numpy()
+        sa = np.empty(N, dtype=np.uint32)
+        c = np.zeros(sigma, dtype=np.uint32)
+        o = np.empty((N + 1) * sigma, dtype=np.uint32)
+
+        def host_tables():
+            ctx._check(lib.sx_build_tables(ctx.h, x.ctypes.data, n, sigma, sa.ctypes.data, c.ctypes.data, o.ctypes.data),
+                       "sx_build_tables")
+
+        host_tables()  # (first touch of the result arrays, the staging slab)
+        t_own = farm.timed(host_tables, 1, 0, cuda=cuda)
+        t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
+        out.update(host_tables_ms_per_record=round(t_max * 1e3, 1),
+                   host_tables_Msuffixes_per_s=round(units / t_max / 1e6, 3),
+                   host_tables_GBps_per_rank=round((index_bytes + n) / t_own / 1e9, 2))
+    else:
+        out["host_tables"] = f"skipped: {need >> 30} GiB of host memory needed for {world} ranks"
+    out["egress_note"] = ("all ranks at once between barriers, starting from the record on the host: remap, H2D, build, then "
+                   "SA + C + O (24 B per base) over PCIe; stream = the reference's index file into /dev/null")
+    return out
+
+
 # ---- one rank ----------------------------------------------------------------------------------------------
 
 def run_rank(args):
@@ -304,13 +465,7 @@ def run_rank(args):
         step()
     # one more untimed step, with events around every launch: the per-class table and the dominant class
     table = profiled_step()
-    dom = max(table, key=lambda k: table[k]["ms"])
-    # The induce scatter's class is four kernels (one per pass and source region), the radix scatter's one: when the two
-    # are within 5 % of each other the roofline is taken on the one that is a single row of the rocprofv3 summary
-    # (radix_scatter_kernel is the kernel with the largest total there: 20 ms of 98 against 5.6 for the largest
-    # induce variant); the other class's figures are in "kernels" either way.
-    if dom == "induce_scatter" and table.get("radix_scatter", {}).get("ms", 0.0) >= 0.95 * table[dom]["ms"]:
-        dom = "radix_scatter"
+    dom = max(table, key=lambda k: table[k]["ms"])  # the class with the largest summed time, whichever it is
     # Timed region: events only around the dominant kernel's launches (the roofline figure is measured live, on
     # the library's own stream); two event records around each of a step's ~300 launches would cost ~5 % of it.
     ctx.profile_reset()
@@ -366,6 +521,15 @@ def run_rank(args):
         t0 = time.perf_counter()
         job.upload()
         fasta["h2d_GBps_per_rank"] = round(job.file_len / (time.perf_counter() - t0) / 1e9, 2)
+        fasta["numa_node_per_rank"] = farm.gather_ints(numa_node if numa_node is not None else -1)
+        if not args.no_egress:
+            job_n, job_sigma = job.n, job.sigma
+            job = None  # the index is rebuilt from the host's copy of the record: free the device-resident one
+            ctx.trim()
+            if cuda:
+                torch.cuda.empty_cache()
+            eg = egress_leg(ctx, local_rank, text, job_n, job_sigma, world, red_dev, cuda)
+            fasta.update(eg)
 
     if rank == 0:
         value = total_units / elapsed / 1e6
@@ -375,7 +539,9 @@ def run_rank(args):
         size_label = (f"{n >> 30} GiB" if n >= (1 << 30) and n % (1 << 30) == 0 else
                       (f"{n >> 20} MiB" if n >= (1 << 20) and n % (1 << 20) == 0 else f"{n} B"))
         alpha_label = {"dna": "DNA", "fasta": "DNA, FASTA records", "bytes": "sigma=256"}.get(workload, workload if workload != "uniform" else f"sigma={sigma}")
-        what = "SA-IS + BWT C/O tables" if tables else "SA-IS"
+        # name the algorithm that ran: lms_path 3 is the direct prefix sort of all suffixes (sx_build.hip), not SA-IS
+        algo = "direct prefix sort" if stats.get("lms_path") == 3 else "SA-IS"
+        what = f"{algo} + BWT C/O tables" if tables else algo
         if workload == "fasta":
             wl = (f"one FASTA record of 2^{args.log2n} bases per GPU (bwt_readmapper.c:54-62): image in HBM -> pack -> remap -> "
                   f"sa_is_construction + init_bwt_table (C, O)" if args.n == 0 else f"one FASTA record of {n} bases per GPU")
@@ -438,6 +604,17 @@ def run_rank(args):
             if cuda:
                 torch.cuda.empty_cache()
             out["end_to_end"] = end_to_end(ctx, [int(v) for v in args.e2e_log2n.split(",") if v], 42)
+        if (world == 1 and not args.no_other_configs and workload == "dna" and args.n == 0 and not args.no_tables
+                and (args.log2n == 30 or emu)):
+            try:
+                del text, sa, bwt, c_tab, o_tab
+            except NameError:
+                pass
+            job = None
+            ctx.trim()
+            if cuda:
+                torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(ctx, dev, max(1, args.other_steps), cuda, args.log2n)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cpu_sample, sigma, f"the first {cpu_n} symbols of the record rank 0 built")
         print(json.dumps(out), flush=True)

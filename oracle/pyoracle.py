@@ -207,7 +207,9 @@ def synth(n, sigma, seed):
 
 
 # ---------------------------------------------------------------------------
-# The unmodified reference (build container only; never present on the GPU box)
+# The unmodified reference, oracle/_ref/libstralg_ref.so: built in the build container from /root/reference by
+# oracle/Makefile; the built library (never the sources) travels to the GPU box with the snapshot, where only
+# bench.py's cpu_baseline leg and the tests load it.  The product never does.
 # ---------------------------------------------------------------------------
 
 class _RefSA(C.Structure):

@@ -984,8 +984,19 @@ int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, b
                 }
             jobs[d] = (struct farm_job){strings, out, order + first, at - first, include_reverse, devices[d]};
         }
-        for (int d = 0; d < n_devices; ++d) pthread_create(&threads[d], NULL, farm_worker, &jobs[d]);
-        for (int d = 0; d < n_devices; ++d) pthread_join(threads[d], NULL);
+        /* a lane whose thread cannot be created (EAGAIN under a thread limit) is run by the caller after the
+         * others have been started: every record is built either way, and only created threads are joined */
+        bool *created = calloc((size_t)n_devices, sizeof *created);
+        if (!created) {
+            rc = -2;
+        } else {
+            for (int d = 0; d < n_devices; ++d) created[d] = pthread_create(&threads[d], NULL, farm_worker, &jobs[d]) == 0;
+            for (int d = 0; d < n_devices; ++d)
+                if (!created[d]) (void)farm_worker(&jobs[d]);
+            for (int d = 0; d < n_devices; ++d)
+                if (created[d]) pthread_join(threads[d], NULL);
+            free(created);
+        }
     }
     free(threads), free(jobs), free(lengths), free(lane), free(order);
     return rc;

@@ -1073,7 +1073,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 const double syms = (double)C - (double)(kbits - cand) / log2((double)base);
                 const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
                 const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
-                if (cand == 24 && m >= (1u << 22) && mean_bucket <= 300.0 && top_bucket <= 400.0) top_bits = cand; // (a workgroup holds a sub-bucket of up to 1024)
+                if (cand == 24 && m >= (1u << 22) && mean_bucket <= 300.0 && top_bucket <= 400.0) top_bits = cand; // (a workgroup owns the sub-buckets that start in its span and end within its reach: one that starts
+                                                                                                       //  at the span's last pair may hold kLsCap - kLsSpan = 1024 pairs, one that starts earlier more)
             }
         }
         const bool hybrid = top_bits != 0;

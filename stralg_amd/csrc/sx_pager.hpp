@@ -79,8 +79,13 @@ struct sx_host_pager {
         }
         int nt = thread_count();
         if ((size_t)nt > chunks.size()) nt = (int)chunks.size();
-        for (int t = 0; t < nt; ++t)
-            workers.emplace_back([this] {
+        // Thread creation may fail (EAGAIN under a thread limit; a farm has a pager per GPU): an exception must not leave
+        // through the C ABI.  The chunks are a shared queue, so the workers that did start touch all of them; with no
+        // worker at all every chunk is marked ready and the copies fault the pages in themselves -- download() never
+        // waits for a chunk nobody will complete.
+        try {
+            for (int t = 0; t < nt; ++t)
+                workers.emplace_back([this] {
                 for (;;) {
                     const size_t i = next.fetch_add(1, std::memory_order_relaxed);
                     if (i >= chunks.size()) return;
@@ -92,6 +97,10 @@ struct sx_host_pager {
                     ready[i].store(1, std::memory_order_release);
                 }
             });
+        } catch (...) {
+            if (workers.empty())
+                for (size_t i = 0; i < chunks.size(); ++i) ready[i].store(1, std::memory_order_release);
+        }
     }
 
     void wait(size_t i) const

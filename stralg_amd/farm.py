@@ -56,6 +56,16 @@ def reduce_scalars(elapsed, units, device=None):
     return float(t.item()), int(round(u.item()))
 
 
+def gather_ints(value):
+    """[value of rank 0, value of rank 1, ...] (bookkeeping only)"""
+    dist = _dist()
+    if dist is None:
+        return [int(value)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, int(value))
+    return [int(v) for v in out]
+
+
 def timed(step, steps, warmup, cuda=True):
     """warmup untimed steps, then exactly `steps` timed ones between fences."""
     for _ in range(warmup):

@@ -144,6 +144,103 @@ def check_serialisation(lib, cases, tmp_path):
             assert open(d, "rb").read() == want, (name, rev, "read + write")
 
 
+def genome_cases():
+    """tests/golden/golden_genomes.npz: the production caller's genomes (tools/readmappers/data/genomes/hg38-*.fa).
+    file name -> dict(file, err, packed, records, recs=[dict(name, sym, sigma, c, sa_sha256, sa_rows, ...)])"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_genomes.npz"))
+    cases = {}
+    for key in z.files:
+        parts = key.split("/")
+        c = cases.setdefault(parts[0], {"recs": {}})
+        if len(parts) == 2:
+            c[parts[1]] = z[key]
+        else:
+            c["recs"].setdefault(parts[1], {})[parts[2]] = z[key]
+    out = {}
+    for fname, c in cases.items():
+        recs = []
+        for k in sorted(c["recs"], key=lambda r: int(r[3:])):
+            r = dict(c["recs"][k])
+            r["name"] = r["name"].tobytes()
+            r["sigma"] = int(r["sigma"][0])
+            for f in list(r):
+                if f.endswith("_sha256"):
+                    r[f] = r[f].tobytes().hex()
+                elif f.endswith("_len"):
+                    r[f] = int(r[f][0])
+            recs.append(r)
+        out[fname] = dict(file=c["file"].tobytes(), err=int(c["err"][0]), packed=c["packed"].tobytes(),
+                          records=int(c["records"][0]), recs=recs)
+    return out
+
+
+def check_against_sha(arr, rec, field, what):
+    """an array against its fixture: SHA-256 of the little-endian uint32 bytes, and every 997th row for a useful message"""
+    import hashlib
+    a = np.ascontiguousarray(arr, dtype=np.uint32)
+    assert (a[::997] == rec[field + "_rows"]).all(), (what, field, "sampled rows differ")
+    assert hashlib.sha256(a.tobytes()).hexdigest() == rec[field + "_sha256"], (what, field)
+
+
+def check_genomes(lib, cases, tmp_path, names=None):
+    """load_fasta_records -> stralg_amd_fasta_tables_batch (include_reverse, two lanes on device 0) ->
+    write_complete_bwt_info on the genome files, everything against the reference's results"""
+    import ctypes as C
+    import hashlib
+
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.c_void_p), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.c_void_p),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.c_void_p)]
+
+    lib.load_fasta_records.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    lib.load_fasta_records.restype = C.c_void_p
+    lib.free_fasta_records.argtypes = [C.c_void_p]
+    lib.number_of_fasta_records.argtypes = [C.c_void_p]
+    lib.number_of_fasta_records.restype = C.c_uint32
+    lib.stralg_amd_fasta_tables_batch.argtypes = [C.c_void_p, C.c_bool, C.POINTER(C.c_int), C.c_int, C.POINTER(C.POINTER(BT))]
+    lib.stralg_amd_fasta_tables_batch.restype = C.c_int
+    lib.write_complete_bwt_info_fname.argtypes = [C.c_char_p, C.POINTER(BT)]
+    lib.write_complete_bwt_info_fname.restype = None
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    for fname, g in cases.items():
+        if names is not None and fname not in names:
+            continue
+        path = tmp_path / fname
+        path.write_bytes(g["file"])
+        err = C.c_int(-1)
+        h = lib.load_fasta_records(str(path).encode(), C.byref(err))
+        assert h and err.value == 0 and lib.number_of_fasta_records(h) == g["records"]
+        out = (C.POINTER(BT) * g["records"])()
+        devs = (C.c_int * 2)(0, 0)
+        assert lib.stralg_amd_fasta_tables_batch(h, True, devs, 2, out) == g["records"]
+        for t, want in zip(out, g["recs"]):
+            N, sigma = t.contents.sa.contents.length, want["sigma"]
+            assert N == want["sym"].size + 1
+            assert (np.ctypeslib.as_array(t.contents.sa.contents.string, shape=(N - 1,)) == want["sym"]).all()
+            check_against_sha(np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)), want, "sa", fname)
+            assert (np.ctypeslib.as_array(t.contents.c_table, shape=(sigma,)) == want["c"]).all()
+            check_against_sha(np.ctypeslib.as_array(t.contents.o_table, shape=(N + 1, sigma)), want, "o", fname)
+            check_against_sha(np.ctypeslib.as_array(t.contents.ro_table, shape=(N + 1, sigma)), want, "ro", fname)
+            idx = tmp_path / (fname + ".bwt")
+            lib.write_complete_bwt_info_fname(str(idx).encode(), t)
+            blob = idx.read_bytes()
+            assert len(blob) == want["serial_with_reverse_len"]
+            assert hashlib.sha256(blob).hexdigest() == want["serial_with_reverse_sha256"], fname
+            lib.completely_free_bwt_table(t)
+        lib.free_fasta_records(h)
+
+
+@pytest.fixture(scope="session")
+def golden_genomes():
+    return genome_cases()
+
+
 @pytest.fixture(scope="session")
 def golden_fasta():
     return fasta_cases()

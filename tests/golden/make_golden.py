@@ -10,6 +10,9 @@ Cases:
      match_test.c:682-696, serialise_test.c:15, test-data/*.txt, bioinf ref.fa)
   * seeded random strings, sigma in {2,3,5,21,128,256}, n up to 64 Ki
   * structured strings (runs, periodic, Fibonacci, monotone)
+Also written: golden_next.npz (inverse, LCP, exact-search intervals), golden_fasta.npz (FASTA loader, index files)
+and golden_genomes.npz (the production caller's genomes tools/readmappers/data/genomes/hg38-1000.fa / hg38-10000.fa:
+file, packed image, and per record C, the SHA-256 and sampled rows of SA, O, RO, and the SHA-256 of the reference's index file).
 For every case: remapped symbols, alphabet_size, SA (sa_is_construction; checked
 equal to sa_is_mem / skew / qsort inside this script), and for sigma <= 128 and
 n <= 4096 the C, O and RO tables of build_complete_table.
@@ -167,6 +170,41 @@ def main():
         fa["serial/" + name.replace("/", "-") + "/forward_only"] = np.frombuffer(ref.serialise(raw, False), dtype=np.uint8)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_fasta.npz"), **fa)
     print(f"{len(fasta_inputs)} FASTA cases -> golden_fasta.npz")
+
+    # ---- the production caller's own inputs (tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62 is run by the
+    # reference's evaluation scripts on tools/readmappers/data/genomes/hg38-*.fa): the data files, what
+    # load_fasta_records makes of them, and per record everything build_complete_table + write_complete_bwt_info hand over
+    import hashlib
+    gen = {}
+    GENOMES = "/root/reference/tools/readmappers/data/genomes"
+    for fname in ("hg38-1000.fa", "hg38-10000.fa"):
+        data = open(os.path.join(GENOMES, fname), "rb").read()
+        err, recs = ref.fasta(data)
+        assert err == 0 and len(recs) == 1
+        gen[fname + "/file"] = np.frombuffer(data, dtype=np.uint8)
+        gen[fname + "/err"] = np.array([err], dtype=np.int32)
+        gen[fname + "/packed"] = np.frombuffer(b"".join(n + b"\0" + q + b"\0" for n, q in recs[::-1]), dtype=np.uint8)
+        gen[fname + "/records"] = np.array([len(recs)], dtype=np.uint32)
+        for k, (name, seq) in enumerate(recs):  # iteration order
+            t = ref.build_complete_table(seq, True)
+            sym, sigma = ref.remap_string(np.frombuffer(seq, dtype=np.uint8))
+            assert sigma == t["sigma"] and (ref.sa_is(sym, sigma) == t["sa"]).all()
+            key = f"{fname}/rec{k}"
+            gen[key + "/name"] = np.frombuffer(name, dtype=np.uint8)
+            gen[key + "/sym"] = sym
+            gen[key + "/sigma"] = np.array([sigma], np.uint32)
+            gen[key + "/c"] = t["c"]
+            # 50 000 and 500 000 bases: the arrays as SHA-256 of their little-endian bytes, plus every 997th row in full
+            for field in ("sa", "o", "ro"):
+                a = np.ascontiguousarray(t[field], dtype=np.uint32)
+                gen[f"{key}/{field}_sha256"] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8)
+                gen[f"{key}/{field}_rows"] = a[::997].copy()
+            for rev, tag in ((True, "with_reverse"), (False, "forward_only")):
+                blob = ref.serialise(seq, rev)
+                gen[f"{key}/serial_{tag}_sha256"] = np.frombuffer(hashlib.sha256(blob).digest(), dtype=np.uint8)
+                gen[f"{key}/serial_{tag}_len"] = np.array([len(blob)], dtype=np.uint64)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_genomes.npz"), **gen)
+    print(f"{len(gen)} arrays -> golden_genomes.npz")
 
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz")
     np.savez_compressed(out, **cases)

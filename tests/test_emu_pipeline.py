@@ -396,6 +396,14 @@ def test_serialisation_bytes(emu_ctx, tmp_path):
     check_serialisation(emu_ctx.lib, serial_cases(), tmp_path)
 
 
+def test_production_genome_through_the_farm(emu_ctx, golden_genomes, tmp_path):
+    """the read-mapper's loop on its own 50 000-base genome (tools/readmappers/data/genomes/hg38-1000.fa) over the
+    CPU execution harness: load_fasta_records -> stralg_amd_fasta_tables_batch -> write_complete_bwt_info, against
+    the unmodified reference's arrays and index file"""
+    from conftest import check_genomes
+    check_genomes(emu_ctx.lib, golden_genomes, tmp_path, names=("hg38-1000.fa",))
+
+
 def test_primitives(emu_ctx):
     rng = np.random.default_rng(1)
     n = 5000

@@ -110,6 +110,34 @@ def test_bench_launches_its_own_ranks_on_fasta_records(emu_ctx):
     fr = doc["fasta_record"]
     assert fr["kernel_only_Msuffixes_per_s"] > 0 and fr["ingest_inclusive_Msuffixes_per_s"] > 0
     assert doc["build_stats"]["n"] == 5003
+    # the egress leg: every rank's index leaves its device at once (streamed index file, then malloc'd host tables)
+    assert fr["numa_node_per_rank"] == [-1, -1] or len(fr["numa_node_per_rank"]) == 2
+    assert fr["index_bytes_per_record"] == 4 * 5004 + 4 * 5 + 4 * 5 * 5005
+    for key in ("stream_ms_per_record", "egress_inclusive_Msuffixes_per_s", "d2h_GBps_per_rank", "d2h_GBps_all_ranks",
+                "host_tables_ms_per_record", "host_tables_Msuffixes_per_s"):
+        assert key in fr and fr[key] >= 0, key
+    assert fr["stream_ms_per_record"] > 0 and fr["egress_inclusive_Msuffixes_per_s"] > 0
+
+
+def test_bench_default_run_carries_the_other_configs(emu_ctx):
+    """the default (one GPU, DNA) line also measures BASELINE.json's other single-GPU configurations after the timed
+    region, each verified, and names the algorithm that ran (here at 2^12 symbols over the CPU execution harness)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["STRALG_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2n", "12", "--steps", "1", "--warmup", "0",
+                          "--no-e2e", "--no-cpu", "--other-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert doc["verified"] is True and doc["metric"].startswith("Msuffixes/s (SA-IS + BWT C/O tables")
+    oc = doc["other_configs"]
+    assert set(oc) == {"dna_1024B", "bytes_4096B", "bytes_4096B_induced", "genome_like_4096B"}
+    for name, c in oc.items():
+        assert c.get("verified") is True, (name, c)
+        assert c["ms_per_step"] > 0 and "roofline_frac" in c and "lms_path" in c
+    assert oc["bytes_4096B"]["lms_path"] == 3 and "direct prefix sort" in oc["bytes_4096B"]["algorithm"]
+    assert oc["bytes_4096B_induced"]["lms_path"] in (1, 2) and oc["bytes_4096B_induced"]["induce_rounds"] > 100
 
 
 def test_bench_reports_a_failed_verification(emu_ctx, tmp_path):

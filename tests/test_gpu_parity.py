@@ -682,16 +682,17 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
         gpu_ctx.sa_build_dev(text, n, sigma, sa)
         assert gpu_ctx.last_stats()["lms_path"] == 3  # random bytes take the direct sort of all suffixes
         verify.verify_sa_on_device(text, sa, n)
-        if log2n <= 28:
-            # ... and the induced-sort passes on the same input give the same array
-            sa2 = torch.empty_like(sa)
-            gpu_ctx.set_no_direct_sort(True)
-            try:
-                gpu_ctx.sa_build_dev(text, n, sigma, sa2)
-                assert gpu_ctx.last_stats()["lms_path"] in (1, 2)
-            finally:
-                gpu_ctx.set_no_direct_sort(False)
-            assert bool((sa2 == sa).all())
+        # ... and the LMS sort + induced-sort passes on the same input (BASELINE.json configs[3]'s "wide-alphabet
+        # LDS-histogram path", at its full size too) give the same array
+        sa2 = torch.empty_like(sa)
+        gpu_ctx.set_no_direct_sort(True)
+        try:
+            gpu_ctx.sa_build_dev(text, n, sigma, sa2)
+            st = gpu_ctx.last_stats()
+            assert st["lms_path"] in (1, 2) and st["induce_rounds"] > 500
+        finally:
+            gpu_ctx.set_no_direct_sort(False)
+        assert bool((sa2 == sa).all())
         return
     # the fused calls bench.py times: suffix array + BWT from the induced-sort passes, then C and O from that BWT
     c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
@@ -786,6 +787,15 @@ def test_fasta_reference_named_c_api(gpu_ctx, golden_fasta, tmp_path):
     assert not lib.load_fasta_records(str(bad).encode(), None)
 
 
+def test_production_genomes_through_the_farm(gpu_ctx, golden_genomes, tmp_path):
+    """the read-mapper's preprocessing loop (bwt_readmapper.c:54-62) on its own genomes
+    (tools/readmappers/data/genomes/hg38-1000.fa, hg38-10000.fa): load_fasta_records ->
+    stralg_amd_fasta_tables_batch (include_reverse) -> write_complete_bwt_info, every array and the index file
+    against what the unmodified reference produced (tests/golden/golden_genomes.npz)"""
+    from conftest import check_genomes
+    check_genomes(gpu_ctx.lib, golden_genomes, tmp_path)
+
+
 def test_fasta_to_tables_on_device(gpu_ctx):
     """a FASTA image that never leaves the GPU: pack, per record remap + suffix array + BWT + C/O, each checked
     against the oracle working from the file on the host"""
@@ -824,6 +834,36 @@ def test_fasta_to_tables_on_device(gpu_ctx):
         assert (sa.cpu().numpy().view(np.uint32) == sa_want).all(), r
         assert (c.cpu().numpy().view(np.uint32) == oracle.c_table(sym_want, sigma)).all()
         assert (o.cpu().numpy().view(np.uint32) == oracle.o_table(sym_want, sa_want, sigma).ravel()).all()
+
+
+def test_fasta_record_at_full_size(gpu_ctx):
+    """BASELINE.json configs[4]'s unit of work at its size: one FASTA record of 2^30 bases (60-column lines, as
+    bench.py --gpus N gives every rank) from the file image in HBM through sx_fasta_pack_dev -> sx_remap_dev ->
+    sx_sa_bwt_build_dev -> sx_bwt_tables_from_bwt_dev (bwt_readmapper.c:54-62), then the size-independent proofs:
+    pack + remap reproduce the record; the suffix array is the sorted permutation; bwt = text[sa - 1]; C and every
+    O row"""
+    import torch
+    from stralg_amd import farm, verify, workloads
+    n = 1 << 30
+    dev = torch.device("cuda", 0)
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    gpu_ctx.synth_dev(text, n, 5, 77)
+    image = workloads.fasta_image(text, "record0 a 1 GiB chromosome")
+    assert image.numel() == len(b">record0 a 1 GiB chromosome\n") + n + (n + 59) // 60
+    job = farm.FastaRecordJob(gpu_ctx, image.cpu(), dev, tables=True)
+    del image
+    job.upload()
+    assert job.build() == n + 1
+    assert job.n == n and job.sigma == 5
+    assert bool((job.d_text[:n] == text).all()) and int(job.d_text[n]) == 0
+    st = gpu_ctx.last_stats()
+    assert st["lms_path"] == 1 and st["n"] == n
+    del text
+    job.d_file = job.d_packed = None
+    torch.cuda.empty_cache()
+    gpu_ctx.trim()
+    done = verify.verify_build_on_device(job.d_text, n, 5, job.sa, job.bwt, job.c, job.o)
+    assert len(done) == 3
 
 
 def test_fasta_large_image(gpu_ctx):

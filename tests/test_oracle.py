@@ -76,6 +76,27 @@ def test_fasta_packing_golden(golden_fasta):
     assert golden_fasta["ref/ref.fa"]["records"] == 5 and golden_fasta["ref/malformed.fa"]["err"] == 2  # fasta_test.c:53,76
 
 
+def test_production_genomes_golden(golden_genomes):
+    """the read-mapper's own genomes (tools/readmappers/data/genomes/hg38-1000.fa, hg38-10000.fa; 50 000 and 500 000
+    bases): the oracle's FASTA packing, remap, suffix array and C / O / RO tables against what the unmodified
+    reference's load_fasta_records + build_complete_table produced"""
+    from conftest import check_against_sha
+    from oracle import pyoracle
+    for fname, g in golden_genomes.items():
+        bad, packed, recs = pyoracle.fasta_pack(g["file"])
+        assert not bad and g["err"] == 0 and packed == g["packed"] and len(recs) == g["records"] == 1, fname
+        for (name, seq), want in zip(recs[::-1], g["recs"]):  # iteration order = reverse file order
+            assert name == want["name"], fname
+            sym, sigma, _ = oracle.remap(seq)
+            assert sigma == want["sigma"] == 5 and (sym == want["sym"]).all(), fname
+            sa = oracle.sa_is(sym, sigma)
+            check_against_sha(sa, want, "sa", fname)
+            assert (oracle.c_table(sym, sigma) == want["c"]).all(), fname
+            check_against_sha(oracle.o_table(sym, sa, sigma), want, "o", fname)
+            rsym = sym[::-1].copy()
+            check_against_sha(oracle.o_table(rsym, oracle.sa_is(rsym, sigma), sigma), want, "ro", fname)
+
+
 def test_naive_agrees():
     rng = np.random.default_rng(5)
     for sigma in (2, 4, 17):
