@@ -2,6 +2,7 @@
  * TEST INFRASTRUCTURE ONLY (see that header). */
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
+#include <mutex>
 
 // Minimal x86-64 context switch (callee-saved registers + stack pointer); glibc's
 // swapcontext makes a signal-mask system call per switch, far too slow here.
@@ -97,6 +98,10 @@ const unsigned long long *emu_wave_gather(unsigned long long v, unsigned long lo
 
 void emu_launch(void (*tramp)(void *), void *args, dim3 grid, dim3 block)
 {
+    // one kernel at a time: the scheduler's state, threadIdx & co. and the kernels' __shared__ arrays (plain statics
+    // here) are process-wide, and the host layer may launch from several threads (one context each)
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> lock(launch_mu);
     int nt = (int)(block.x * block.y * block.z);
     if (nt <= 0 || nt > kMaxThreads) { fprintf(stderr, "emu: bad block size %d\n", nt); abort(); }
     if ((unsigned long long)grid.x * grid.y * grid.z == 0) { fprintf(stderr, "emu: empty grid\n"); abort(); }

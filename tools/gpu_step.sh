@@ -1,0 +1,36 @@
+#!/bin/bash
+# One GPU-box session: the named steps, in order, each logging under gpurun_out/<tag>/ (tools/gpu_step.sh TAG step...).
+#   tests[:K_EXPR]   pytest -m gpu (optionally -k K_EXPR)
+#   bench[:ARGS]     python bench.py ARGS > bench[_<n>].json
+#   bench2           two ranks sharing the one GPU (gloo carries the scalars): the N > 1 path of bench.py
+#   prof             rocprofv3 --kernel-trace --stats of bench.py (summary via tools/profile_summary.py)
+set -o pipefail
+tag=$1; shift
+out=gpurun_out/$tag
+mkdir -p "$out"
+k=0
+for step in "$@"; do
+  k=$((k+1))
+  name=${step%%:*}; arg=""
+  [[ "$step" == *:* ]] && arg=${step#*:}
+  echo "== $step" | tee -a "$out/steps.log"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -x -q -k "$arg" > "$out/tests_$k.log" 2>&1
+      else timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$out/tests_$k.log" 2>&1; fi
+      rc=$?; tail -5 "$out/tests_$k.log";;
+    bench)
+      timeout -k 10 900 python bench.py $arg > "$out/bench_$k.json" 2> "$out/bench_$k.err"
+      rc=$?; tail -c 600 "$out/bench_$k.err"; head -c 400 "$out/bench_$k.json"; echo;;
+    bench2)
+      STRALG_BENCH_BACKEND=gloo STRALG_BENCH_SHARE_GPU=1 timeout -k 10 900 python bench.py --gpus 2 $arg > "$out/bench2_$k.json" 2> "$out/bench2_$k.err"
+      rc=$?; tail -c 600 "$out/bench2_$k.err"; head -c 300 "$out/bench2_$k.json"; echo;;
+    py)
+      timeout -k 10 900 python $arg > "$out/py_$k.log" 2>&1
+      rc=$?; tail -20 "$out/py_$k.log";;
+    *) echo "unknown step $name"; rc=64;;
+  esac
+  echo "   rc=$rc" | tee -a "$out/steps.log"
+  [ $rc -ne 0 ] && exit $rc
+done
+exit 0
