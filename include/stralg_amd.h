@@ -101,9 +101,13 @@ enum {
     SX_FLAG_NO_DIRECT_SORT = 3,     /* wide alphabets: never sort all suffixes by prefix directly, always LMS sort + induction */
     SX_FLAG_PREFIX_SYMBOLS = 4,     /* first attempt of the prefix-key sort takes this many symbols (0: by the text's size) */
     SX_FLAG_RADIX_DIGIT_BITS = 5,   /* digit width of the LSD radix passes: 8 (default), 9 or 10 */
-    SX_FLAG_SORT_MODE = 6           /* prefix-key sort: 0 choose, 1 LSD passes only (tie refinement too: no group is ordered in
+    SX_FLAG_SORT_MODE = 6,          /* prefix-key sort: 0 choose, 1 LSD passes only (tie refinement too: no group is ordered in
                                        LDS), 2 hybrid (HBM passes on the top 24 key bits + sub-buckets ordered in LDS) whenever the
                                        key shape allows it, whatever the size, 3 the same with the top 32 bits */
+    SX_FLAG_INDUCE_BATCH_OFF = 7,   /* induced-sort passes over at most 8 buckets: 1 = every self round of a bucket is a launch of
+                                       its own (no eight-rounds-at-a-time form) */
+    SX_FLAG_INDUCE_BATCH_MIN = 8    /* ranges longer than this many entries take the eight-rounds-at-a-time form (negative: the
+                                       default, what the one-workgroup tail kernel holds; tests set 0) */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

@@ -227,6 +227,14 @@ class Context:
         the top 24 key bits), 3 the same with the top 32 bits."""
         self._check(self.lib.sx_ctx_set_flag(self.h, 6, int(mode)), "sx_ctx_set_flag")
 
+    def set_induce_batch(self, on=True):
+        """SX_FLAG_INDUCE_BATCH_OFF: the self rounds of a bucket eight at a time (default) or a launch each"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 7, 0 if on else 1), "sx_ctx_set_flag")
+
+    def set_induce_batch_min(self, entries):
+        """SX_FLAG_INDUCE_BATCH_MIN: ranges longer than this take the eight-rounds-at-a-time form (negative: default)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 8, int(entries)), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

@@ -16,11 +16,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---- per-thread device context --------------------------------------------- */
 
 static __thread sx_ctx *tls_ctx = NULL;
-static __thread sx_ctx *tls_ctx2 = NULL; /* build_complete_table's reverse direction, built beside the forward one */
 static __thread int tls_device = -1;
 
 static void die(const char *what, int rc, const sx_ctx *ctx)
@@ -120,23 +120,12 @@ static sx_ctx *thread_ctx(void)
     return tls_ctx;
 }
 
-/* the calling thread's second context on the same device (created on first use) */
-static sx_ctx *thread_ctx2(void)
-{
-    if (tls_ctx2) return tls_ctx2;
-    (void)thread_ctx(); /* settles tls_device */
-    int rc = sx_ctx_create(tls_device, &tls_ctx2);
-    if (rc != 0) die("sx_ctx_create (second context)", rc, NULL);
-    return tls_ctx2;
-}
-
 int stralg_amd_set_device(int device)
 {
     if (device < 0 || device >= sx_device_count()) return -1;
-    if (tls_device != device) {
-        if (tls_ctx) sx_ctx_destroy(tls_ctx);
-        if (tls_ctx2) sx_ctx_destroy(tls_ctx2);
-        tls_ctx = tls_ctx2 = NULL;
+    if (tls_ctx && tls_device != device) {
+        sx_ctx_destroy(tls_ctx);
+        tls_ctx = NULL;
     }
     tls_device = device;
     return 0;
@@ -145,8 +134,7 @@ int stralg_amd_set_device(int device)
 void stralg_amd_release(void)
 {
     if (tls_ctx) sx_ctx_destroy(tls_ctx);
-    if (tls_ctx2) sx_ctx_destroy(tls_ctx2);
-    tls_ctx = tls_ctx2 = NULL;
+    tls_ctx = NULL;
 }
 
 /* ---- suffix arrays (stralg/suffix_array_internal.c:7-19, suffix_array.c:12-24) ---- */
@@ -444,61 +432,23 @@ static struct remap_table *remap_record(const uint8_t *string, size_t n, uint8_t
     return table;
 }
 
-/* build_complete_table's helpers: work that depends on nothing the forward build produces runs beside it --
- * the row-pointer tables (8 bytes per row: 8 GiB for a 1 GiB record, addresses only) and the whole reverse
- * direction (reversal, H2D, build and download through a second context with its own stream: its upload and kernels
- * hide behind the forward download, PCIe being full duplex, and the two downloads share the link). */
-struct rows_job {
-    uint32_t *table;
-    size_t rows;
-    uint32_t sigma;
-    uint32_t **idx;
-};
-
-static void *rows_worker(void *p)
+static double now_ms(void)
 {
-    struct rows_job *j = p;
-    j->idx = row_pointers(j->table, j->rows, j->sigma);
-    return NULL;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
 
-struct reverse_job {
-    sx_ctx *ctx;
-    const uint8_t *remapped;
-    size_t n;
-    uint32_t sigma;
-    uint32_t *ro_table;
-    int rc;
-};
-
-static void *reverse_worker(void *p)
-{
-    struct reverse_job *j = p;
-    /* the reverse suffix array and the reversed copy are temporary (bwt.c:147-158) */
-    uint8_t *rev = malloc(j->n + 1);
-    uint32_t *c_tmp = calloc(j->sigma, sizeof *c_tmp);
-    if (!rev || !c_tmp) {
-        j->rc = -2;
-    } else {
-        struct lut_job lj = {j->remapped, rev, NULL, j->n, true};
-        parallel_ranges(j->n, lut_slice, &lj);
-        rev[j->n] = 0;
-        j->rc = sx_build_tables(j->ctx, rev, j->n, j->sigma, NULL, c_tmp, j->ro_table);
-    }
-    free(c_tmp);
-    free(rev);
-    return NULL;
-}
-
-/* records shorter than this build their reverse table after the forward one, through the one context */
-static size_t concurrent_reverse_min(void)
-{
-    const char *env = getenv("STRALG_AMD_PARALLEL_MIN");
-    return env && atol(env) >= 1 ? (size_t)atol(env) : (size_t)4 << 20;
-}
-
+/* (Round 3 measured two ways of hiding host work behind the downloads of a 1 GiB record, both on the GPU box: the
+ * row-pointer tables filled by helper threads while sx_build_tables runs -- the download slowed down by what the fill
+ * took, 660 against 515 ms, the sum unchanged at 765 - 800 ms -- and the whole reverse direction through a second
+ * context beside the forward one -- 1480 - 1530 ms either way.  The host side is bound by first-touch page faults and
+ * the memory bandwidth of the GPU's NUMA node (zeroing + DMA + pointer fill: 64 GiB of writes a record), not by idle
+ * time, so the phases stay one after the other.  $STRALG_AMD_TIMING=1 prints them.) */
 struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse)
 {
+    const bool timing = getenv("STRALG_AMD_TIMING") != NULL;
+    const double t0 = timing ? now_ms() : 0.0;
     const size_t n = strlen((const char *)string);
     uint8_t *remapped = malloc(n + 1);
     struct remap_table *remap_table = remap_record(string, n, remapped);
@@ -526,39 +476,32 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
     table->sa = sa;
     table->c_table = calloc(sigma, sizeof *table->c_table);
     table->o_table = big_alloc(o_words * sizeof *table->o_table);
-    table->ro_table = include_reverse ? big_alloc(o_words * sizeof *table->ro_table) : NULL;
-    table->ro_indices = NULL;
-
-    /* beside the forward build: both row-pointer tables and, for records worth a second context, the reverse direction */
-    const bool beside = n >= concurrent_reverse_min();
-    struct rows_job rows_f = {table->o_table, N + 1, sigma, NULL}, rows_r = {table->ro_table, N + 1, sigma, NULL};
-    struct reverse_job rev_job = {NULL, remapped, n, sigma, table->ro_table, 0};
-    pthread_t th_rows_f, th_rows_r, th_rev;
-    bool on_rows_f = false, on_rows_r = false, on_rev = false;
-    if (beside) {
-        on_rows_f = pthread_create(&th_rows_f, NULL, rows_worker, &rows_f) == 0;
-        if (include_reverse) {
-            rev_job.ctx = thread_ctx2();
-            on_rev = pthread_create(&th_rev, NULL, reverse_worker, &rev_job) == 0;
-            on_rows_r = pthread_create(&th_rows_r, NULL, rows_worker, &rows_r) == 0;
-        }
-    }
+    const double t1 = timing ? now_ms() : 0.0;
     int rc = sx_build_tables(ctx, remapped, n, sigma, sa->array, table->c_table, table->o_table);
     if (rc != 0) die("build_complete_table", rc, ctx);
-    if (on_rows_f) pthread_join(th_rows_f, NULL);
-    else (void)rows_worker(&rows_f);
-    table->o_indices = rows_f.idx;
+    const double t2 = timing ? now_ms() : 0.0;
+    table->o_indices = row_pointers(table->o_table, N + 1, sigma);
+    if (timing)
+        fprintf(stderr, "stralg_amd timing: n=%zu strlen + remap + allocation %.1f ms, sx_build_tables %.1f ms, row pointers "
+                        "%.1f ms\n", n, t1 - t0, t2 - t1, now_ms() - t2);
+
+    table->ro_table = NULL;
+    table->ro_indices = NULL;
     if (include_reverse) {
-        if (on_rev) {
-            pthread_join(th_rev, NULL);
-        } else { /* short record, or no thread to be had: after the forward direction, through the same context */
-            rev_job.ctx = ctx;
-            (void)reverse_worker(&rev_job);
-        }
-        if (rev_job.rc != 0) die("build_complete_table (reverse)", rev_job.rc, rev_job.ctx);
-        if (on_rows_r) pthread_join(th_rows_r, NULL);
-        else (void)rows_worker(&rows_r);
-        table->ro_indices = rows_r.idx;
+        /* the reverse suffix array and the reversed copy are temporary (bwt.c:147-158) */
+        const double t3 = timing ? now_ms() : 0.0;
+        uint8_t *rev = malloc(n + 1);
+        struct lut_job lj = {remapped, rev, NULL, n, true};
+        parallel_ranges(n, lut_slice, &lj);
+        rev[n] = 0;
+        uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
+        table->ro_table = big_alloc(o_words * sizeof *table->ro_table);
+        rc = sx_build_tables(ctx, rev, n, sigma, NULL, c_tmp, table->ro_table);
+        if (rc != 0) die("build_complete_table (reverse)", rc, ctx);
+        free(c_tmp);
+        free(rev);
+        table->ro_indices = row_pointers(table->ro_table, N + 1, sigma);
+        if (timing) fprintf(stderr, "stralg_amd timing: reverse direction %.1f ms\n", now_ms() - t3);
     }
     return table;
 }

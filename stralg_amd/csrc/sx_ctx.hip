@@ -235,6 +235,14 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         ctx->radix_digit_bits = value;
         return 0;
     }
+    if (flag == SX_FLAG_INDUCE_BATCH_OFF) {
+        ctx->induce_batch_off = value ? 1 : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_INDUCE_BATCH_MIN) {
+        ctx->induce_batch_min = value < 0 ? -1 : (int64_t)value;
+        return 0;
+    }
     if (flag == SX_FLAG_CHAIN_MAX_ENTRIES) {
         ctx->chain_max_override = value < 0 ? -1 : (int64_t)value; // negative: back to the default
         return 0;

@@ -464,4 +464,71 @@ __device__ __forceinline__ uint32_t block_scan_row_inplace(uint32_t *__restrict_
     return carry;
 }
 
+// The same by a workgroup of 1024 threads, for the rows of an induce round's tile counts (a launch of a handful of
+// workgroups between the counting and the scattering launch: its latency is the round's).  A thread owns 8 consecutive
+// counts of each of four 8192-count pieces and loads them as 16-byte pairs, all eight loads in flight together (a wave's
+// load covers 2 KiB of consecutive counts, so nothing has to be turned through LDS); 32 768 counts an iteration: one
+// trip to memory for the 33 000 tile counts of a 1 GiB text's largest round (the 256-thread form above: five).
+constexpr int kRowThreads = 1024, kRowWaves = kRowThreads / kWave, kRowPieces = 4, kRowPer = 8;
+__device__ __forceinline__ uint32_t wide_scan_row_inplace(uint32_t *__restrict__ row, uint64_t count, uint32_t *lds /* kRowPieces * kRowWaves */)
+{
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    uint32_t carry = 0;
+    for (uint64_t start = 0; start < count; start += (uint64_t)kRowPieces * kRowThreads * kRowPer) { // uniform trip count
+        uint32_t v[kRowPieces][kRowPer], s[kRowPieces], inc[kRowPieces];
+#pragma unroll
+        for (int q = 0; q < kRowPieces; ++q) {
+            const uint64_t base = start + (uint64_t)q * kRowThreads * kRowPer + (uint64_t)t * kRowPer;
+            if (base + kRowPer <= count) {
+                __builtin_memcpy(v[q], row + base, sizeof(v[q]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < kRowPer; ++k) v[q][k] = base + k < count ? row[base + k] : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kRowPieces; ++q) {
+            s[q] = 0;
+#pragma unroll
+            for (int k = 0; k < kRowPer; ++k) s[q] += v[q][k];
+            inc[q] = wave_inclusive_scan<OpAdd>(s[q]);
+            if (lane == kWave - 1) lds[q * kRowWaves + w] = inc[q];
+        }
+        __syncthreads();
+        uint32_t before[kRowPieces], run = carry;
+#pragma unroll
+        for (int q = 0; q < kRowPieces; ++q) {
+            uint32_t mine = 0, all = 0;
+#pragma unroll
+            for (int ww = 0; ww < kRowWaves; ++ww) {
+                const uint32_t x = lds[q * kRowWaves + ww];
+                if ((uint32_t)ww < w) mine += x;
+                all += x;
+            }
+            before[q] = run + mine + inc[q] - s[q];
+            run += all;
+        }
+        carry = run;
+        __syncthreads(); // `lds` is rewritten by the next iteration
+#pragma unroll
+        for (int q = 0; q < kRowPieces; ++q) {
+            const uint64_t base = start + (uint64_t)q * kRowThreads * kRowPer + (uint64_t)t * kRowPer;
+            uint32_t o[kRowPer], r = before[q];
+#pragma unroll
+            for (int k = 0; k < kRowPer; ++k) {
+                o[k] = r;
+                r += v[q][k];
+            }
+            if (base + kRowPer <= count) {
+                __builtin_memcpy(row + base, o, sizeof(o));
+            } else {
+#pragma unroll
+                for (int k = 0; k < kRowPer; ++k)
+                    if (base + k < count) row[base + k] = o[k];
+            }
+        }
+    }
+    return carry;
+}
+
 } // namespace sx

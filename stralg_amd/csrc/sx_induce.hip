@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
                 const uint32_t b0 = gather16(S[k][0] & one, S[k][1] & one, S[k][2] & one, S[k][3] & one, 0);
                 const uint32_t b1 = gather16(S[k][0] & (one << 1), S[k][1] & (one << 1), S[k][2] & (one << 1), S[k][3] & (one << 1), 1);
                 const uint32_t b2 = gather16(S[k][0] & (one << 2), S[k][1] & (one << 2), S[k][2] & (one << 2), S[k][3] & (one << 2), 2);
-#define SX_IND_COUNT(A) n_of[A] += (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & inside[k]);
+// (only the symbols the text holds: DNA counts four of the seven, and the launch is bound by vector instructions)
+#define SX_IND_COUNT(A) if ((A) < nkeys) n_of[A] += (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(b0, b1, b2, 1u << ((((A) & 1) << 2) | ((A) & 2) | (((A) >> 2) & 1))) & inside[k]);
                 SX_IND_COUNT(1) SX_IND_COUNT(2) SX_IND_COUNT(3) SX_IND_COUNT(4) SX_IND_COUNT(5) SX_IND_COUNT(6) SX_IND_COUNT(7)
 #undef SX_IND_COUNT
             }
@@ -247,21 +248,27 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
     }
 }
 
-// one workgroup per destination bucket: exclusive prefix over the tiles, cursor update
-__global__ __launch_bounds__(kBlock) void induce_offsets_kernel(uint32_t *__restrict__ hist, uint32_t stride,
+// one workgroup (1024 threads) per destination bucket: exclusive prefix over the tiles, cursor update
+__global__ __launch_bounds__(kRowThreads) void induce_offsets_kernel(uint32_t *__restrict__ hist, uint32_t stride,
                                                                 const uint32_t *__restrict__ range_in,
                                                                 uint32_t *__restrict__ range_out,
                                                                 const uint32_t *__restrict__ cursor_cur,
                                                                 uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
-                                                                uint32_t chain_max)
+                                                                uint32_t chain_max,
+                                                                int only_form /* no chained launch follows (chain_max = 0): an empty range is carried on here */)
 {
-    __shared__ uint32_t lds[kWavesPerBlock];
-    __shared__ uint32_t stage[kScanRowStage];
+    __shared__ uint32_t lds[kRowPieces * kRowWaves];
     const uint32_t len = range_in[1] - range_in[0];
-    if (len <= chain_max) return;
+    if (len <= chain_max) {
+        if (only_form && threadIdx.x == 0) {
+            cursor_nxt[blockIdx.x] = cursor_cur[blockIdx.x];
+            if (blockIdx.x == c && range_out) range_out[0] = range_out[1] = range_in[1];
+        }
+        return;
+    }
     const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
     const uint32_t key = blockIdx.x;
-    const uint32_t total = block_scan_row_inplace(hist + (uint64_t)key * stride, ntiles, lds, stage);
+    const uint32_t total = wide_scan_row_inplace(hist + (uint64_t)key * stride, ntiles, lds);
     if (threadIdx.x == 0) {
         const uint32_t cur = cursor_cur[key];
         cursor_nxt[key] = dir > 0 ? cur + total : cur - total;
@@ -731,7 +738,8 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t nkeys, uint64_t *__restrict__ status, uint32_t epoch,
     uint32_t *__restrict__ ticket,
     uint32_t chain_max /* rounds longer than this are left to the three-launch form; ~0u: take any round */,
-    int tail_follows /* the batch ends with the tail kernel: rounds of up to kTailEntries entries are left to it */)
+    int tail_follows /* the batch ends with the tail kernel: rounds of up to kTailEntries entries are left to it */,
+    int pass_large /* a round longer than chain_max is nobody's here: hand it on as it is (the host queues it again) */)
 {
     __shared__ uint32_t wcount[kWavesPerBlock][256];
     __shared__ uint32_t gpos[256];  // entries of earlier tiles per bucket
@@ -741,8 +749,8 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const uint32_t lo = range_in[0], hi = range_in[1];
     const uint32_t len = hi - lo;
-    if (len > chain_max) return; // a large round: the three-launch form handles it
-    if (len == 0 || (range_out && tail_follows && len <= kTailEntries)) {
+    if (len > chain_max && !pass_large) return; // a large round: the three-launch form handles it
+    if (len == 0 || (range_out && tail_follows && len <= kTailEntries) || len > chain_max) {
         // nothing to do, or a round small enough for the tail kernel that ends the batch: carry the cursors over,
         // hand the range on as it is
         if (blockIdx.x == 0) {
@@ -1261,6 +1269,289 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
     }
 }
 
+// ---- the self rounds of a bucket, eight at a time (at most 8 buckets) ------------------------------------------
+// Round k of bucket c reads what round k-1 appended to c, and on ordinary text every round is a quarter of the one
+// before: after the first (large) round a bucket went through a dozen launches that moved next to nothing, each with
+// its launch latency (1 GiB of DNA: 0.3 ms of 1.0 per bucket region).  An entry's window already says where its
+// descendants go: with a = the number of symbols c immediately to its left, the descendants of rounds 0 .. a-1 stay in
+// bucket c (position - 1 ... position - a) and the one of round a goes to the bucket of the first other symbol, if
+// the type test accepts it (as induce_tail_small_kernel does inside one workgroup).  So kBatchRounds rounds are taken
+// by one counting launch (per tile: outputs per round and bucket), one scan of the 64 count rows and one scatter:
+// round j's outputs into bucket d lie behind those of rounds < j, tiles in order inside a round.  The last round's
+// outputs into bucket c are the next range.  A window that shows only symbols c and is shorter than the rounds ahead
+// is refilled from the text first (by both kernels alike).
+constexpr int kBatchRounds = 8;
+constexpr int kBatchRows = kBatchRounds * 8; // (round, bucket) count rows
+constexpr uint32_t kBatchFrom = 1u << 21;    // rounds expected to hold more entries than this are launches of their own
+
+template <class WT> struct batch_plan {
+    uint32_t a;    // descendants that stay in bucket c (rounds 0 .. a-1), at most kBatchRounds
+    uint32_t tsym; // bucket of the round-a descendant, when `term`
+    bool term;
+};
+
+// field index of the lowest set bit of x (fields of B bits)
+__device__ __forceinline__ uint32_t batch_field_of(uint32_t bit, uint32_t B)
+{
+    return B == 2 ? bit >> 1 : (B == 1 ? bit : (B == 3 ? (bit * 171u) >> 9 : bit >> 2)); // (B uniform, bit < 64)
+}
+
+template <class WT, int MODE>
+__device__ __forceinline__ batch_plan<WT> batch_chain(WT &w, uint32_t p, uint32_t c, const wnd_cfg &cfg, WT cpat,
+                                                        const uint8_t *__restrict__ T)
+{
+    batch_plan<WT> pl;
+    uint32_t cntw = wnd_count<WT>(w);
+    WT x = (w >> kCntBits) ^ cpat;
+    uint32_t r = x ? batch_field_of((uint32_t)(sizeof(WT) == 8 ? __builtin_ctzll((unsigned long long)x) : __builtin_ctz((uint32_t)x)), cfg.B)
+                   : cfg.CW;
+    if (r >= cntw && cntw <= (uint32_t)kBatchRounds && p > cntw) {
+        // every symbol the window holds is c and the text goes on to the left: look further (rare)
+        w = wnd_fill<WT>(T, p, cfg);
+        cntw = wnd_count<WT>(w);
+        x = (w >> kCntBits) ^ cpat;
+        r = x ? batch_field_of((uint32_t)(sizeof(WT) == 8 ? __builtin_ctzll((unsigned long long)x) : __builtin_ctz((uint32_t)x)), cfg.B)
+              : cfg.CW;
+    }
+    uint32_t a = r < cntw ? r : cntw;
+    pl.term = a < (uint32_t)kBatchRounds && a < cntw;
+    if (a > (uint32_t)kBatchRounds) a = (uint32_t)kBatchRounds;
+    pl.a = a;
+    pl.tsym = ((uint32_t)((w >> kCntBits) >> (a * cfg.B)) & cfg.mask) + 1u;
+    pl.term = pl.term && induce_accept(pl.tsym, c, MODE) && pl.tsym < 8u;
+    return pl;
+}
+
+// window of the descendant `depth` + 1 positions to the left (depth + 1 symbols popped), back to the text when it ran dry
+template <class WT>
+__device__ __forceinline__ WT batch_window(WT w, uint32_t depth, uint32_t pos, const wnd_cfg &cfg, const uint8_t *__restrict__ T)
+{
+    const uint32_t cntw = wnd_count<WT>(w);
+    WT nw = ((((w >> kCntBits) >> (depth * cfg.B)) >> cfg.B) << kCntBits) | (WT)(cntw - (depth + 1u));
+    if (pos != 0 && cntw == depth + 1u) nw = wnd_fill<WT>(T, pos, cfg);
+    return nw;
+}
+
+template <class WT> __device__ __forceinline__ WT batch_cpat(uint32_t c, const wnd_cfg &cfg)
+{
+    WT pat = 0;
+    for (uint32_t i = 0; i < cfg.CW; ++i) pat |= (WT)(c - 1u) << (i * cfg.B); // uniform
+    return pat;
+}
+
+// the thread's 8 consecutive entries of the scan order (windows; positions too when wanted)
+template <class WT, bool kRev, bool kWantP>
+__device__ __forceinline__ void batch_load(const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, uint32_t lo, uint32_t len,
+                                           uint32_t i0, uint32_t (&P)[kIndItems], WT (&W)[kIndItems])
+{
+    if (i0 + kIndItems <= len) {
+        const uint32_t first = kRev ? lo + len - i0 - kIndItems : lo + i0;
+        uint32_t Pm[kIndItems];
+        WT Wm[kIndItems];
+        if (kWantP) __builtin_memcpy(Pm, srcP + first, sizeof(Pm));
+        __builtin_memcpy(Wm, srcW + first, sizeof(Wm));
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            P[k] = kWantP ? Pm[kRev ? kIndItems - 1 - k : k] : 0u;
+            W[k] = Wm[kRev ? kIndItems - 1 - k : k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = i0 + (uint32_t)k;
+            const uint32_t idx = i < len ? (kRev ? lo + len - 1u - i : lo + i) : lo;
+            P[k] = (kWantP && i < len) ? srcP[idx] : 0u;
+            W[k] = i < len ? srcW[idx] : (WT)0;
+        }
+    }
+}
+
+// per round: this thread's outputs per bucket, 8-bit fields (at most 8 entries a thread)
+template <class WT, int MODE>
+__device__ __forceinline__ void batch_tally(const batch_plan<WT> &pl, uint32_t c, uint64_t (&cnt)[kBatchRounds])
+{
+#pragma unroll
+    for (int j = 0; j < kBatchRounds; ++j) {
+        const uint64_t self = (uint32_t)j < pl.a ? 1ull << (8u * c) : 0ull;
+        const uint64_t term = (pl.term && pl.a == (uint32_t)j) ? 1ull << (8u * pl.tsym) : 0ull;
+        cnt[j] += self + term;
+    }
+}
+
+template <class WT, int MODE>
+__global__ __launch_bounds__(kBlock) void induce_batch_count_kernel(const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW,
+                                                                    const uint32_t *__restrict__ range_in, uint32_t c, wnd_cfg cfg,
+                                                                    const uint8_t *__restrict__ T, uint32_t *__restrict__ hist /* [row][stride] */,
+                                                                    uint32_t stride, uint32_t min_len)
+{
+    constexpr bool kRev = MODE == MODE_S_FROM_S;
+    constexpr uint64_t kField16 = 0x00FF00FF00FF00FFull;
+    __shared__ uint64_t wtot[kBatchRounds][2][kWavesPerBlock];
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const WT cpat = batch_cpat<WT>(c, cfg);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        const uint32_t i0 = tile * (uint32_t)kIndTile + (uint32_t)t * kIndItems;
+        uint32_t P[kIndItems];
+        WT W[kIndItems];
+        batch_load<WT, kRev, false>(srcP, srcW, lo, len, i0, P, W);
+        uint64_t cnt[kBatchRounds];
+#pragma unroll
+        for (int j = 0; j < kBatchRounds; ++j) cnt[j] = 0;
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t cntw = wnd_count<WT>(W[k]);
+            uint32_t p = cntw; // (the position matters only to a window that may need more symbols: fetched then)
+            if (cntw != 0 && cntw <= (uint32_t)kBatchRounds) {
+                const WT x = (W[k] >> kCntBits) ^ cpat;
+                const WT low = cntw * cfg.B >= sizeof(WT) * 8 ? ~(WT)0 : (((WT)1 << (cntw * cfg.B)) - 1);
+                if ((x & low) == 0) { // all of its symbols are c
+                    const uint32_t i = i0 + (uint32_t)k;
+                    p = srcP[kRev ? lo + len - 1u - i : lo + i];
+                }
+            }
+            const batch_plan<WT> pl = batch_chain<WT, MODE>(W[k], p, c, cfg, cpat, T);
+            batch_tally<WT, MODE>(pl, c, cnt);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatchRounds; ++j) {
+            const uint64_t e = wave_total_packed(cnt[j] & kField16), o = wave_total_packed((cnt[j] >> 8) & kField16);
+            if (lane == 0) wtot[j][0][w] = e, wtot[j][1][w] = o;
+        }
+        __syncthreads();
+        if (t < kBatchRows) { // row (j, d): the tile's outputs of round j into bucket d
+            const int j = t >> 3, d = t & 7;
+            uint64_t sum = 0;
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww) sum += wtot[j][d & 1][ww];
+            hist[(uint64_t)t * stride + tile] = (uint32_t)(sum >> (16 * (d >> 1))) & 0xFFFFu;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per (round, bucket) row: exclusive prefix over the tiles, the row's total aside
+__global__ __launch_bounds__(kRowThreads) void induce_batch_offsets_kernel(uint32_t *__restrict__ hist, uint32_t stride,
+                                                                      const uint32_t *__restrict__ range_in,
+                                                                      uint32_t *__restrict__ totals, uint32_t nk, uint32_t min_len)
+{
+    __shared__ uint32_t lds[kRowPieces * kRowWaves];
+    const uint32_t len = range_in[1] - range_in[0];
+    if (len <= min_len) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const uint32_t row = (blockIdx.x / nk) * 8u + blockIdx.x % nk;
+    const uint32_t total = wide_scan_row_inplace(hist + (uint64_t)row * stride, ntiles, lds);
+    if (threadIdx.x == 0) totals[row] = total;
+}
+
+template <class WT, int MODE>
+__global__ __launch_bounds__(kBlock) void induce_batch_scatter_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in,
+    uint32_t *__restrict__ range_out, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs,
+    uint32_t stride, const uint32_t *__restrict__ totals, const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt,
+    uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t nk, uint32_t min_len)
+{
+    constexpr bool kRev = MODE == MODE_S_FROM_S;
+    constexpr uint64_t kField16 = 0x00FF00FF00FF00FFull;
+    __shared__ uint64_t wsum[kBatchRounds][2][kWavesPerBlock];
+    __shared__ uint32_t s_round0[kBatchRows]; // outputs of earlier rounds into the bucket (the round's first slot, relative)
+    __shared__ uint32_t s_base[kBatchRows];   // destination of the tile's first output of (round, bucket)
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t lo = range_in[0], hi = range_in[1], len = hi - lo;
+    if (len <= min_len) { // not a range for this form: the cursors and the range go on as they are
+        if (blockIdx.x == 0) {
+            if (t < 256) cursor_nxt[t] = cursor_cur[t];
+            if (t == 0 && range_out) range_out[0] = lo, range_out[1] = hi;
+        }
+        return;
+    }
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    __shared__ uint32_t s_tot[kBatchRows];
+    if (t < kBatchRows) s_tot[t] = (uint32_t)(t & 7) < nk ? totals[t] : 0u; // (one trip to memory for all of them)
+    __syncthreads();
+    if (t < kBatchRows) {
+        const int j = t >> 3, d = t & 7;
+        uint32_t before = 0;
+        for (int jj = 0; jj < j; ++jj) before += s_tot[jj * 8 + d];
+        s_round0[t] = before;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t < 256) { // the cursors after all the rounds; the last round's outputs into bucket c are the next range
+        uint32_t all = 0;
+        if ((uint32_t)t < nk) all = s_round0[(kBatchRounds - 1) * 8 + t] + s_tot[(kBatchRounds - 1) * 8 + t];
+        const uint32_t cur = cursor_cur[t];
+        cursor_nxt[t] = kRev ? cur - all : cur + all;
+        if ((uint32_t)t == c && range_out) {
+            const uint32_t last = s_tot[(kBatchRounds - 1) * 8 + t];
+            range_out[0] = kRev ? cur - all : cur + all - last;
+            range_out[1] = kRev ? cur - all + last : cur + all;
+        }
+    }
+    const uint32_t base_d = (uint32_t)(t & 7) < nk && t < kBatchRows ? cursor_cur[t & 7] : 0u;
+    const WT cpat = batch_cpat<WT>(c, cfg);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        if (t < kBatchRows) {
+            const uint32_t rel = s_round0[t] + (((uint32_t)(t & 7) < nk) ? offs[(uint64_t)t * stride + tile] : 0u);
+            s_base[t] = kRev ? base_d - 1u - rel : base_d + rel;
+        }
+        const uint32_t i0 = tile * (uint32_t)kIndTile + (uint32_t)t * kIndItems;
+        uint32_t P[kIndItems];
+        WT W[kIndItems];
+        batch_load<WT, kRev, true>(srcP, srcW, lo, len, i0, P, W);
+        batch_plan<WT> pl[kIndItems];
+        uint64_t cnt[kBatchRounds];
+#pragma unroll
+        for (int j = 0; j < kBatchRounds; ++j) cnt[j] = 0;
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            pl[k] = batch_chain<WT, MODE>(W[k], P[k], c, cfg, cpat, T);
+            batch_tally<WT, MODE>(pl[k], c, cnt);
+        }
+        // outputs of earlier threads per round and bucket: two words of 16-bit fields a round, scanned over the workgroup
+        uint64_t ex0[kBatchRounds], ex1[kBatchRounds];
+#pragma unroll
+        for (int j = 0; j < kBatchRounds; ++j) {
+            const uint64_t own0 = cnt[j] & kField16, own1 = (cnt[j] >> 8) & kField16;
+            const uint64_t inc0 = wave_inclusive_sum_packed(own0), inc1 = wave_inclusive_sum_packed(own1);
+            if (lane == kWave - 1) wsum[j][0][w] = inc0, wsum[j][1][w] = inc1;
+            ex0[j] = inc0 - own0, ex1[j] = inc1 - own1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kBatchRounds; ++j) {
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww)
+                if (ww < w) ex0[j] += wsum[j][0][ww], ex1[j] += wsum[j][1][ww];
+        }
+        uint64_t run[kBatchRounds]; // outputs of this thread's earlier entries, 8-bit fields
+#pragma unroll
+        for (int j = 0; j < kBatchRounds; ++j) run[j] = 0;
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+#pragma unroll
+            for (int j = 0; j < kBatchRounds; ++j) {
+                const bool self = (uint32_t)j < pl[k].a, term = pl[k].term && pl[k].a == (uint32_t)j;
+                if (self || term) {
+                    const uint32_t d = self ? c : pl[k].tsym;
+                    const uint64_t exw = (d & 1u) ? ex1[j] : ex0[j];
+                    const uint32_t r = ((uint32_t)(exw >> (16u * (d >> 1))) & 0xFFFFu) + ((uint32_t)(run[j] >> (8u * d)) & 0xFFu);
+                    const uint32_t sb = s_base[j * 8 + (int)d];
+                    const uint32_t dst = kRev ? sb - r : sb + r;
+                    const uint32_t pos = P[k] - (uint32_t)(j + 1);
+                    const WT nw = batch_window<WT>(W[k], (uint32_t)j, pos, cfg, T);
+                    SA[dst] = pos;
+                    WN[dst] = nw;
+                    BW[dst] = wnd_symbol<WT>(nw, cfg);
+                    run[j] += 1ull << (8u * d);
+                }
+            }
+        }
+        __syncthreads(); // s_base and wsum are rewritten for the next tile
+    }
+}
+
 // ---- very long runs -------------------------------------------------------------------------------------
 // The tail kernel's run jump writes 4096 rounds a step with one workgroup: 11 us a step, 45 ms for the 16 Mi
 // symbols of a gap in a reference assembly (runs of N of up to 30 Mbp, one or more per chromosome, all in one
@@ -1409,7 +1700,9 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
     // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + symbol bytes + control block
     const uint64_t ntiles = (N + kIndTile - 1) / kIndTile + 1;
     const uint64_t wtiles = N / 8192 + 4; // wide alphabets: [tile][256] counts of 8192-entry tiles + chunk sums
+    // (at most 8 buckets: (round, bucket) count rows of the eight-rounds-at-a-time form, over the largest bucket's tiles)
     return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 +
+           (size_t)kBatchRows * (ntiles + 1) * 4 + 1024 +
            (sigma > 8 ? (size_t)(wtiles + wtiles / 256 + 4) * 1024 + 512 : 0) + 16384;
 }
 
@@ -1436,6 +1729,9 @@ template <class WT> struct induce_state {
     uint64_t *status;
     uint32_t chain_max; // rounds up to this many entries take the chained launch
     uint32_t *hist;   // [nk][stride] tile counts of the three-launch form (at most 8 buckets)
+    uint32_t *bhist;  // [round * 8 + bucket][stride] tile counts of the eight-rounds-at-a-time form
+    uint32_t *btotals; // kBatchRows row totals
+    int batch_on;
     uint32_t *whist;  // [tile][256] the same for wide alphabets, tiles of 8192 entries
     uint32_t *wsums;  // [chunk][256] column sums of chunks of 256 tiles
     uint32_t stride;
@@ -1447,7 +1743,8 @@ template <class WT> struct induce_state {
 
 template <class WT>
 void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, int range_slot, int out_slot,
-                  uint32_t tiles_bound, uint32_t tiles_likely, int rev, int mode, uint32_t c, int dir, int tail_follows)
+                  uint32_t tiles_bound, uint32_t tiles_likely, int rev, int mode, uint32_t c, int dir, int tail_follows,
+                  int chained_only_up_to_chain_max = 0, int three_launch_only = 0)
 {
     sx_ctx *ctx = st.ctx;
     uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
@@ -1459,8 +1756,12 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     uint32_t *nxt = st.cursor[st.par ^ 1];
     // tiles_likely: what the round is expected to need (decides which forms are queued);
     // a round that turns out longer is still handled, by the chained form alone if need be.
-    const bool both = (uint64_t)tiles_likely * kIndTile > st.chain_max;
-    const uint32_t chain_max = both ? st.chain_max : ~0u;
+    // three_launch_only (at most 8 buckets): the round is expected to be large for sure, no chained launch is queued behind
+    // the three (they take a range of any length then, an empty one is carried on by the offsets launch)
+    const bool only3 = three_launch_only && st.small_alphabet;
+    const bool both = only3 || (!chained_only_up_to_chain_max && (uint64_t)tiles_likely * kIndTile > st.chain_max);
+    const uint32_t chain_max = only3 ? 0u : ((both || chained_only_up_to_chain_max) ? st.chain_max : ~0u);
+    const int pass_large = chained_only_up_to_chain_max;
     if (both && st.small_alphabet) {
         // the round may be a large one: queue the three-launch form as well
         // (entries of the suffix array have their symbol bytes next to them; the LMS seeds only their windows)
@@ -1469,7 +1770,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
                   (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
-                  dim3(kBlock), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
+                  dim3(kRowThreads), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max, only3 ? 1 : 0);
         {
 #define SX_SCATTER_SMALL(M)                                                                                            \
     sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_scatter_small_kernel<WT, M>, dim3(grid), dim3(kBlock), srcP, srcW, \
@@ -1508,18 +1809,19 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
                   chain_max);
     }
     uint32_t cgrid = grid > 1024 ? 1024 : grid;
-    if (st.small_alphabet)
+    if (only3) {
+    } else if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 3>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
-                  epoch, st.tickets + range_slot, chain_max, tail_follows);
+                  epoch, st.tickets + range_slot, chain_max, tail_follows, pass_large);
     else if (st.nk <= 32)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 5>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
-                  epoch, st.tickets + range_slot, chain_max, tail_follows);
+                  epoch, st.tickets + range_slot, chain_max, tail_follows, pass_large);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_round_kernel<WT, 8>, dim3(cgrid), dim3(kBlock), srcP, srcW,
                   (const uint32_t *)rin, rout, rev, mode, c, st.cfg, st.T, cur, nxt, dir, st.SA, st.WN, st.BW, st.nk, st.status,
-                  epoch, st.tickets + range_slot, chain_max, tail_follows);
+                  epoch, st.tickets + range_slot, chain_max, tail_follows, pass_large);
     st.par ^= 1;
     ctx->stats.induce_rounds++;
 }
@@ -1541,6 +1843,40 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, kTailIters);
     st.par ^= 1;
+}
+
+// kBatchRounds self rounds of bucket c in three launches (at most 8 buckets; ranges the tail kernel can take pass through)
+template <class WT>
+void launch_batch(induce_state<WT> &st, int range_slot, int out_slot, uint32_t tiles_bound, int mode, uint32_t c)
+{
+    sx_ctx *ctx = st.ctx;
+    uint32_t grid = tiles_bound < 1 ? 1 : tiles_bound;
+    if (grid > kInduceGridCap) grid = kInduceGridCap;
+    const uint32_t *rin = st.ranges + 2 * range_slot;
+    uint32_t *rout = st.ranges + 2 * out_slot;
+    const uint32_t *cur = st.cursor[st.par];
+    uint32_t *nxt = st.cursor[st.par ^ 1];
+    const uint32_t min_len = ctx->induce_batch_min >= 0 ? (uint32_t)ctx->induce_batch_min : kTailEntries;
+    if (mode == MODE_L_FROM_L) {
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_batch_count_kernel<WT, MODE_L_FROM_L>, dim3(grid), dim3(kBlock),
+                  (const uint32_t *)st.SA, (const WT *)st.WN, rin, c, st.cfg, st.T, st.bhist, st.stride, min_len);
+    } else {
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_batch_count_kernel<WT, MODE_S_FROM_S>, dim3(grid), dim3(kBlock),
+                  (const uint32_t *)st.SA, (const WT *)st.WN, rin, c, st.cfg, st.T, st.bhist, st.stride, min_len);
+    }
+    sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * kBatchRounds * 8, induce_batch_offsets_kernel,
+              dim3(kBatchRounds * st.nk), dim3(kRowThreads), st.bhist, st.stride, rin, st.btotals, st.nk, min_len);
+    if (mode == MODE_L_FROM_L) {
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_batch_scatter_kernel<WT, MODE_L_FROM_L>, dim3(grid), dim3(kBlock),
+                  (const uint32_t *)st.SA, (const WT *)st.WN, rin, rout, c, st.cfg, st.T, (const uint32_t *)st.bhist, st.stride,
+                  (const uint32_t *)st.btotals, cur, nxt, st.SA, st.WN, st.BW, st.nk, min_len);
+    } else {
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_batch_scatter_kernel<WT, MODE_S_FROM_S>, dim3(grid), dim3(kBlock),
+                  (const uint32_t *)st.SA, (const WT *)st.WN, rin, rout, c, st.cfg, st.T, (const uint32_t *)st.bhist, st.stride,
+                  (const uint32_t *)st.btotals, cur, nxt, st.SA, st.WN, st.BW, st.nk, min_len);
+    }
+    st.par ^= 1;
+    ctx->stats.induce_rounds++;
 }
 
 // all rounds of one region of bucket c: the first range comes from the cursor, every
@@ -1570,7 +1906,35 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         if (first)
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
                       (const uint32_t *)st.cursor[st.par], (int)c, which);
-        for (int k = 0; k < spec; ++k) {
+        const bool batched = st.small_alphabet && st.batch_on && (mode == MODE_L_FROM_L || mode == MODE_S_FROM_S);
+        if (batched) {
+            // First the rounds expected to be large, a launch each -- round k of a bucket holds about share^k of its region
+            // (three launches, and no chained one behind them where the expectation is beyond doubt) --, then eight rounds by
+            // one count / scan / scatter (the rounds that moved next to nothing and cost a launch chain each), the tail
+            // kernel for what eight rounds leave of a range of a million.  A range the tail cannot hold (runs longer than the
+            // rounds taken: poly-A, microsatellites) comes round again: eight more rounds, some chained ones, the tail.
+            int slot = 0;
+            if (first) {
+                double expect = (double)region_entries;
+                // (SX_FLAG_INDUCE_BATCH_MIN, tests: that bound here too, and every such round in the three-launch-only form)
+                const double batch_from = ctx->induce_batch_min >= 0 ? (double)ctx->induce_batch_min : (double)kBatchFrom;
+                for (int k = 0; k < 6 && expect > batch_from; ++k, expect *= share) {
+                    uint32_t tb = sx_div_up((uint64_t)(expect * 2.0 < (double)region_entries ? expect * 2.0 : (double)region_entries), kIndTile);
+                    if (tb < 256) tb = bound_tiles < 256 ? bound_tiles : 256;
+                    const bool sure = ctx->induce_batch_min >= 0 || expect > 4.0 * (double)st.chain_max;
+                    launch_round<WT>(st, st.SA, st.WN, slot, slot + 1, tb, tb, rev, mode, c, dir, 1, 0, sure ? 1 : 0);
+                    ++slot;
+                }
+            }
+            launch_batch<WT>(st, slot, slot + 1, bound_tiles, mode, c);
+            ++slot;
+            if (!first) {
+                for (int k = 0; k < 3; ++k, ++slot)
+                    launch_round<WT>(st, st.SA, st.WN, slot, slot + 1, bound_tiles < 256 ? bound_tiles : 256, 0, rev, mode, c, dir, 1, 1);
+            }
+            spec = slot;
+        }
+        for (int k = 0; k < spec && !batched; ++k) {
             uint32_t tb = bound_tiles >> k;
             const uint32_t floor_tiles = bound_tiles < 256 ? bound_tiles : 256;
             if (tb < floor_tiles) tb = floor_tiles;
@@ -1667,10 +2031,13 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
                                                 : (st.small_alphabet ? 256u * (uint32_t)kIndTile : kTailEntries);
     const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 2) * nk + kChainHeader; // any round may be chained
     st.stride = sx_div_up(largest, kIndTile) + 1;
-    st.hist = st.whist = st.wsums = nullptr;
+    st.hist = st.whist = st.wsums = st.bhist = st.btotals = nullptr;
+    st.batch_on = ctx->induce_batch_off ? 0 : 1;
     if (st.small_alphabet) {
         st.hist = arena.take<uint32_t>((size_t)nk * st.stride);
-        if (!st.hist) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
+        st.bhist = arena.take<uint32_t>((size_t)kBatchRows * st.stride);
+        st.btotals = arena.take<uint32_t>(kBatchRows);
+        if (!st.hist || !st.bhist || !st.btotals) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (tile counts)");
     } else {
         const size_t wt = (size_t)sx_div_up(largest, kWideTile) + 2;
         st.whist = arena.take<uint32_t>(wt * 256);

@@ -25,6 +25,15 @@ for step in "$@"; do
     bench2)
       STRALG_BENCH_BACKEND=gloo STRALG_BENCH_SHARE_GPU=1 timeout -k 10 900 python bench.py --gpus 2 $arg > "$out/bench2_$k.json" 2> "$out/bench2_$k.err"
       rc=$?; tail -c 600 "$out/bench2_$k.err"; head -c 300 "$out/bench2_$k.json"; echo;;
+    trace)
+      # rocprofv3 kernel trace of bench.py ARGS (python3 directly after --), per-kernel stats and the last step's timeline
+      rm -rf "$out/trace_$k"; mkdir -p "$out/trace_$k"
+      ( cd /tmp && TMPDIR=/tmp timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/trace_$k/trace" -- python3 "$GRAFT_REPO_ROOT/bench.py" $arg > "$GRAFT_REPO_ROOT/$out/trace_$k.log" 2>&1 )
+      rc=$?
+      python3 tools/profile_summary.py "$out/trace_$k" > "$out/trace_${k}_summary.txt" 2>&1
+      python3 tools/step_timeline.py "$out/trace_$k" > "$out/trace_${k}_timeline.txt" 2>&1
+      tail -3 "$out/trace_${k}_timeline.txt"
+      find "$out/trace_$k" -name "*.csv" -size +8M -delete;;
     py)
       timeout -k 10 900 python $arg > "$out/py_$k.log" 2>&1
       rc=$?; tail -20 "$out/py_$k.log";;
