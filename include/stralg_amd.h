@@ -83,6 +83,9 @@ typedef struct sx_build_stats {
                                 general path: bit 2: some round ordered small groups by one wave each, bit 3: some round sent
                                 members through radix sorts */
     double ms_total;         /* wall time of the last build on the device stream */
+    uint32_t induce_redo;    /* induced-sort passes run a second time, bucket by bucket with the host looking at every bucket's
+                                last range: the first, unattended run left a bucket short (runs longer than its rounds reach) */
+    uint32_t long_runs;      /* the classification saw a run that fills a 4096-symbol tile: the passes are attended from the start */
 } sx_build_stats;
 
 /* ---- context ------------------------------------------------------------ */
@@ -106,8 +109,12 @@ enum {
                                        key shape allows it, whatever the size, 3 the same with the top 32 bits */
     SX_FLAG_INDUCE_BATCH_OFF = 7,   /* induced-sort passes over at most 8 buckets: 1 = every self round of a bucket is a launch of
                                        its own (no eight-rounds-at-a-time form) */
-    SX_FLAG_INDUCE_BATCH_MIN = 8    /* ranges longer than this many entries take the eight-rounds-at-a-time form (negative: the
+    SX_FLAG_INDUCE_BATCH_MIN = 8,   /* ranges longer than this many entries take the eight-rounds-at-a-time form (negative: the
                                        default, what the one-workgroup tail kernel holds; tests set 0) */
+    SX_FLAG_INDUCE_ATTENDED = 9     /* 0 (default) = alphabets of more than 8 symbols queue an induced-sort pass as a whole and check
+                                       the bucket cursors at its end (a pass that left a bucket short is run again attended),
+                                       smaller ones are attended: the host reads every bucket's last range back before it queues
+                                       the next bucket; 1 = always attended; 2 = never, whatever the alphabet (tests) */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

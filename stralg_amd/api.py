@@ -235,6 +235,11 @@ class Context:
         """SX_FLAG_INDUCE_BATCH_MIN: ranges longer than this take the eight-rounds-at-a-time form (negative: default)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 8, int(entries)), "sx_ctx_set_flag")
 
+    def set_induce_attended(self, mode=1):
+        """SX_FLAG_INDUCE_ATTENDED: 0 default (wide alphabets queue a pass as a whole), 1 the host looks at every
+        bucket's last range, 2 never (any alphabet)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 9, int(mode)), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

@@ -65,7 +65,7 @@ __device__ __forceinline__ void decided_masks(const uint32_t (&c)[17], uint64_t 
 // One wave per tile, 1024 positions a step: almost every tile decides in its first few symbols, so the wave
 // stops after the first step and three quarters of the text are not read by this pass.
 __global__ __launch_bounds__(kWave) void cls_first_kernel(const uint8_t *__restrict__ T, uint64_t n,
-                                                          uint8_t *__restrict__ tile_first)
+                                                          uint8_t *__restrict__ tile_first, uint32_t *__restrict__ open_tiles)
 {
     const int lane = lane_id();
     for (uint32_t seg = 0; seg < (uint32_t)kClsTile / (kWave * kClsPerThread); ++seg) {
@@ -83,7 +83,10 @@ __global__ __launch_bounds__(kWave) void cls_first_kernel(const uint8_t *__restr
             return;
         }
     }
-    if (lane == 0) tile_first[blockIdx.x] = (uint8_t)2;
+    if (lane == 0) {
+        tile_first[blockIdx.x] = (uint8_t)2;
+        atomicAdd(open_tiles, 1u); // (rare: a run of one symbol through the whole tile and beyond)
+    }
 }
 
 // ---- pass 2: tiles made of one symbol whose run continues take the type of the
@@ -505,21 +508,22 @@ int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_t
     ti.sampbits = arena.take<uint16_t>((size_t)ti.ntiles * kBlock);
     ti.tile_u32 = arena.take<uint32_t>((size_t)ti.ntiles * 5);
     ti.tile_first = arena.take<uint8_t>(ti.ntiles);
-    ti.d_hist = arena.take<uint32_t>(3 * 256);
+    ti.d_hist = arena.take<uint32_t>(3 * 256 + 16); // (+ the count of open tiles)
     ti.d_scalar = arena.take<uint32_t>(16);
     if (!ti.lmsbits || !ti.sampbits || !ti.tile_u32 || !ti.tile_first || !ti.d_hist || !ti.d_scalar)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "classify: arena too small");
     uint32_t *tile_lms = ti.tile_u32, *tile_last = ti.tile_u32 + ti.ntiles;
-    SX_CHECK(hipMemsetAsync(ti.d_hist, 0, 3 * 256 * sizeof(uint32_t), ctx->stream));
+    SX_CHECK(hipMemsetAsync(ti.d_hist, 0, (3 * 256 + 1) * sizeof(uint32_t), ctx->stream));
     const dim3 grid(ti.ntiles), block(kBlock);
-    sx_launch(ctx, SX_KC_CLASSIFY, ti.N / 4, cls_first_kernel, grid, dim3(kWave), T, n, ti.tile_first);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N / 4, cls_first_kernel, grid, dim3(kWave), T, n, ti.tile_first, ti.d_hist + 3 * 256);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.ntiles, cls_resolve_kernel, dim3(sx_div_up(ti.ntiles, kBlock * 16)), block, ti.tile_first,
               ti.ntiles);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8, cls_types_kernel, dim3(ti.ntiles < 2048 ? ti.ntiles : 2048), block, T, n,
               (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms, tile_last, ti.d_hist);
     // read the three histograms back: the host drives the bucket loop
-    uint32_t h[3 * 256];
-    SX_TRY(sx_readback(ctx, ti.d_hist, 3 * 256, h));
+    uint32_t h[3 * 256 + 1];
+    SX_TRY(sx_readback(ctx, ti.d_hist, 3 * 256 + 1, h));
+    ti.open_tiles = h[3 * 256];
     memcpy(ti.h_all, h, sizeof ti.h_all);
     memcpy(ti.h_l, h + 256, sizeof ti.h_l);
     memcpy(ti.h_lms, h + 512, sizeof ti.h_lms);

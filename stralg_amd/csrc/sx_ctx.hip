@@ -239,6 +239,11 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         ctx->induce_batch_off = value ? 1 : 0;
         return 0;
     }
+    if (flag == SX_FLAG_INDUCE_ATTENDED) {
+        if (value < 0 || value > 2) return SX_E_ARG;
+        ctx->induce_attended = value;
+        return 0;
+    }
     if (flag == SX_FLAG_INDUCE_BATCH_MIN) {
         ctx->induce_batch_min = value < 0 ? -1 : (int64_t)value;
         return 0;

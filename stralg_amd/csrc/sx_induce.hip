@@ -496,34 +496,66 @@ __global__ __launch_bounds__(kWideThreads) void induce_wide_count_kernel(const W
 }
 
 // counts -> entries of earlier tiles, per bucket; the cursors move on; the range appended to bucket c.
-// One workgroup, a thread per bucket (rounds of up to a few hundred tiles: whole 1 KiB rows, 16 in flight).
-__global__ __launch_bounds__(kBlock) void induce_wide_offsets_kernel(uint32_t *__restrict__ hist,
+// One workgroup of 1024 threads (rounds of up to a few hundred tiles): thread (g, d) owns bucket d over the g-th quarter of
+// the tiles -- whole 1 KiB rows, 16 in flight -- sums it, the quarters' sums meet in LDS, and the second walk writes the
+// prefixes.  (One thread per bucket walking all the tiles, loads and in-place stores alternating: 31 us for the 500 tiles
+// of a byte text's buckets, of the 140 us such a bucket's round took.)
+constexpr int kWideOffGroups = 4;
+__global__ __launch_bounds__(kBlock * kWideOffGroups) void induce_wide_offsets_kernel(uint32_t *__restrict__ hist,
                                                                      const uint32_t *__restrict__ range_in,
                                                                      uint32_t *__restrict__ range_out,
                                                                      const uint32_t *__restrict__ cursor_cur,
                                                                      uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
-                                                                     uint32_t min_len)
+                                                                     uint32_t min_len, int only_form)
 {
+    __shared__ uint32_t gsum[kWideOffGroups][256];
     const uint32_t len = range_in[1] - range_in[0];
-    if (len <= min_len) return;
-    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile, d = threadIdx.x;
+    const uint32_t d = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    if (len <= min_len) {
+        if (only_form && g == 0) { // (no chained launch follows: an empty range is carried on here)
+            cursor_nxt[d] = cursor_cur[d];
+            if (d == c && range_out) range_out[0] = range_out[1] = range_in[1];
+        }
+        return;
+    }
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const uint32_t per = (ntiles + kWideOffGroups - 1) / kWideOffGroups;
+    const uint32_t t0 = g * per < ntiles ? g * per : ntiles, t1 = t0 + per < ntiles ? t0 + per : ntiles;
     constexpr int kBatch = 16;
-    uint32_t run = 0;
-    for (uint32_t tb = 0; tb < ntiles; tb += kBatch) {
+    uint32_t sum = 0;
+    for (uint32_t tb = t0; tb < t1; tb += kBatch) {
         uint32_t x[kBatch];
 #pragma unroll
-        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < ntiles ? hist[(uint64_t)(tb + i) * 256 + d] : 0u;
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + d] : 0u;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) sum += x[i];
+    }
+    gsum[g][d] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll
+    for (int gg = 0; gg < kWideOffGroups; ++gg) {
+        const uint32_t x = gsum[gg][d];
+        if ((uint32_t)gg < g) run += x;
+        all += x;
+    }
+    for (uint32_t tb = t0; tb < t1; tb += kBatch) {
+        uint32_t x[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < t1 ? hist[(uint64_t)(tb + i) * 256 + d] : 0u;
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            if (tb + i < ntiles) hist[(uint64_t)(tb + i) * 256 + d] = run;
+            if (tb + i < t1) hist[(uint64_t)(tb + i) * 256 + d] = run;
             run += x[i];
         }
     }
-    const uint32_t cur = cursor_cur[d];
-    cursor_nxt[d] = dir > 0 ? cur + run : cur - run;
-    if (d == c && range_out) {
-        range_out[0] = dir > 0 ? cur : cur - run;
-        range_out[1] = dir > 0 ? cur + run : cur;
+    if (g == 0) {
+        const uint32_t cur = cursor_cur[d];
+        cursor_nxt[d] = dir > 0 ? cur + all : cur - all;
+        if (d == c && range_out) {
+            range_out[0] = dir > 0 ? cur : cur - all;
+            range_out[1] = dir > 0 ? cur + all : cur;
+        }
     }
 }
 
@@ -555,10 +587,16 @@ __global__ __launch_bounds__(kBlock) void induce_wide_bases_kernel(uint32_t *__r
                                                                    uint32_t *__restrict__ range_out,
                                                                    const uint32_t *__restrict__ cursor_cur,
                                                                    uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
-                                                                   uint32_t min_len)
+                                                                   uint32_t min_len, int only_form)
 {
     const uint32_t len = range_in[1] - range_in[0];
-    if (len <= min_len) return;
+    if (len <= min_len) {
+        if (only_form) {
+            cursor_nxt[threadIdx.x] = cursor_cur[threadIdx.x];
+            if (threadIdx.x == c && range_out) range_out[0] = range_out[1] = range_in[1];
+        }
+        return;
+    }
     const uint32_t ntiles = (len + kWideTile - 1) / kWideTile, nchunks = (ntiles + kWideChunk - 1) / kWideChunk;
     const uint32_t d = threadIdx.x;
     uint32_t run = 0;
@@ -598,17 +636,22 @@ __global__ __launch_bounds__(kBlock) void induce_wide_apply_kernel(uint32_t *__r
     }
 }
 
-template <class WT>
+// A tile of 8192 entries is taken in kWideTile / (512 * ITEMS) steps of ITEMS entries a thread: 16 for 32-bit windows; 8 for
+// 64-bit windows (alphabets of 17 symbols and more), whose 16 entries a thread did not fit 128 registers -- 76 of them
+// were spilled, and a byte text's round of a single tile took 45 us.  A later step's entries go behind the earlier ones'.
+template <class WT, int ITEMS>
 __global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev, int mode,
     uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs /* [tile][256] */,
     const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA, WT *__restrict__ WN,
     uint8_t *__restrict__ BW, uint32_t min_len)
 {
-    __shared__ uint64_t swnd[kWideTile]; // the tile's output in bucket order: windows first, then reused for the positions;
-                                         // the per-wave counters live here while the entries are still in registers
-    __shared__ uint8_t sdig[kWideTile];  // bucket of every staged slot
-    __shared__ uint32_t goff[256];       // destination of the bucket's first staged slot, minus (plus) that slot
+    constexpr int kSub = kWideThreads * ITEMS, kSteps = kWideTile / kSub;
+    static_assert(kWideTile % kSub == 0 && kSub * 8 >= kWideWaves * 256 * 4, "steps tile the tile; the counters fit the staging image");
+    __shared__ uint64_t swnd[kSub]; // the step's output in bucket order: windows first, then reused for the positions;
+                                    // the per-wave counters live here while the entries are still in registers
+    __shared__ uint8_t sdig[kSub];  // bucket of every staged slot
+    __shared__ uint32_t goff[256];  // destination of the bucket's first staged slot, minus (plus) that slot
     __shared__ uint32_t scan_lds[kWideWaves];
     uint32_t *wcount = reinterpret_cast<uint32_t *>(swnd);
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
@@ -617,108 +660,113 @@ __global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
     const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
     const uint32_t base_d = t < 256 ? cursor_cur[t] : 0u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
-        for (int i = t; i < kWideWaves * 256; i += kWideThreads) wcount[i] = 0;
-        const uint32_t pre = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // asked for now, needed after the ranking
-        __syncthreads();
-        const uint32_t wave0 = tile * (uint32_t)kWideTile + (uint32_t)w * (kWave * kWideItems);
-        uint32_t val[kWideItems], lpos[kWideItems]; // position - 1; [12:0] rank, then staged slot, [31:16] bucket, bit 15: taken
-        WT wnd[kWideItems];
-#pragma unroll
-        for (int k = 0; k < kWideItems; ++k) {
-            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
-            val[k] = 0;
-            wnd[k] = 0;
-            bool ok = false;
-            uint32_t dig = 0;
-            if (i < len) {
-                const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                const uint32_t p = srcP[idx];
-                const WT ww = srcW[idx];
-                if (p != 0) {
-                    dig = wnd_first<WT>(ww, cfg);
-                    ok = induce_accept(dig, c, mode);
-                    val[k] = p - 1u;
-                    wnd[k] = wnd_pop<WT>(ww, cfg);
-                }
-            }
-            lpos[k] = ok ? (dig & 0xFFu) << 16 | 0x8000u : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < kWideItems; ++k) {
-            const bool ok = (lpos[k] & 0x8000u) != 0;
-            lpos[k] |= wave_rank_inorder<8, false>(lpos[k] >> 16, ok, wcount + w * 256);
-        }
-        __syncthreads();
-        {
-            uint32_t tot = 0;
-            if (t < 256) {
-#pragma unroll
-                for (int ww = 0; ww < kWideWaves; ++ww) {
-                    const uint32_t x = wcount[ww * 256 + t];
-                    wcount[ww * 256 + t] = tot;
-                    tot += x;
-                }
-            }
-            const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
-            if (lane == kWave - 1) scan_lds[w] = inc;
+        uint32_t pre = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // entries of earlier tiles (and steps) for bucket t
+        for (int step = 0; step < kSteps; ++step) {
+            const uint32_t step0 = tile * (uint32_t)kWideTile + (uint32_t)step * kSub;
+            if (step0 >= len) break; // uniform
+            for (int i = t; i < kWideWaves * 256; i += kWideThreads) wcount[i] = 0;
             __syncthreads();
-            uint32_t base = 0;
-            for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
-            const uint32_t ex = base + inc - tot; // the bucket's first staged slot
-            if (t < 256) {
+            const uint32_t wave0 = step0 + (uint32_t)w * (kWave * ITEMS);
+            uint32_t val[ITEMS], lpos[ITEMS]; // position - 1; [12:0] rank, then staged slot, [31:16] bucket, bit 15: taken
+            WT wnd[ITEMS];
 #pragma unroll
-                for (int ww = 0; ww < kWideWaves; ++ww) wcount[ww * 256 + t] += ex;
-                // staged slot i of bucket t lands at goff + i (L pass) / goff - i (S pass)
-                goff[t] = dir > 0 ? base_d + pre - ex : base_d - 1u - pre + ex;
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+                val[k] = 0;
+                wnd[k] = 0;
+                bool ok = false;
+                uint32_t dig = 0;
+                if (i < len) {
+                    const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                    const uint32_t p = srcP[idx];
+                    const WT ww = srcW[idx];
+                    if (p != 0) {
+                        dig = wnd_first<WT>(ww, cfg);
+                        ok = induce_accept(dig, c, mode);
+                        val[k] = p - 1u;
+                        wnd[k] = wnd_pop<WT>(ww, cfg);
+                    }
+                }
+                lpos[k] = ok ? (dig & 0xFFu) << 16 | 0x8000u : 0u;
             }
-        }
-        __syncthreads();
-        uint32_t produced = 0;
-        for (int ww = 0; ww < kWideWaves; ++ww) produced += scan_lds[ww];
 #pragma unroll
-        for (int k = 0; k < kWideItems; ++k)
-            if (lpos[k] & 0x8000u) lpos[k] = (lpos[k] & 0xFFFF0000u) | 0x8000u | ((lpos[k] & 0x1FFFu) + wcount[w * 256 + (lpos[k] >> 16)]);
-        __syncthreads(); // the counters are part of the staging image
-        // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
-        // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
-        // a seventh of the entries of a byte alphabet, 16 to a thread).
-#pragma unroll
-        for (int k = 0; k < kWideItems; ++k)
-            if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, val[k], cfg);
-#pragma unroll
-        for (int k = 0; k < kWideItems; ++k) {
-            if (lpos[k] & 0x8000u) {
-                const uint32_t slot = lpos[k] & 0x1FFFu;
-                swnd[slot] = (uint64_t)wnd[k];
-                sdig[slot] = (uint8_t)(lpos[k] >> 16);
+            for (int k = 0; k < ITEMS; ++k) {
+                const bool ok = (lpos[k] & 0x8000u) != 0;
+                lpos[k] |= wave_rank_inorder<8, false>(lpos[k] >> 16, ok, wcount + w * 256);
             }
-        }
-        __syncthreads();
-        uint32_t dstv[kWideItems];
+            __syncthreads();
+            uint32_t tot = 0;
+            {
+                if (t < 256) {
 #pragma unroll
-        for (int k = 0; k < kWideItems; ++k) {
-            const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
-            dstv[k] = 0;
-            if (i < produced) {
-                const WT nw = (WT)swnd[i];
-                const uint32_t g = goff[sdig[i]];
-                dstv[k] = dir > 0 ? g + i : g - i;
-                WN[dstv[k]] = nw;
-                BW[dstv[k]] = wnd_symbol<WT>(nw, cfg);
+                    for (int ww = 0; ww < kWideWaves; ++ww) {
+                        const uint32_t x = wcount[ww * 256 + t];
+                        wcount[ww * 256 + t] = tot;
+                        tot += x;
+                    }
+                }
+                const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
+                if (lane == kWave - 1) scan_lds[w] = inc;
+                __syncthreads();
+                uint32_t base = 0;
+                for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
+                const uint32_t ex = base + inc - tot; // the bucket's first staged slot
+                if (t < 256) {
+#pragma unroll
+                    for (int ww = 0; ww < kWideWaves; ++ww) wcount[ww * 256 + t] += ex;
+                    // staged slot i of bucket t lands at goff + i (L pass) / goff - i (S pass)
+                    goff[t] = dir > 0 ? base_d + pre - ex : base_d - 1u - pre + ex;
+                }
             }
-        }
-        __syncthreads();
-        uint32_t *sval = reinterpret_cast<uint32_t *>(swnd);
+            pre += tot;
+            __syncthreads();
+            uint32_t produced = 0;
+            for (int ww = 0; ww < kWideWaves; ++ww) produced += scan_lds[ww];
 #pragma unroll
-        for (int k = 0; k < kWideItems; ++k)
-            if (lpos[k] & 0x8000u) sval[lpos[k] & 0x1FFFu] = val[k];
-        __syncthreads();
+            for (int k = 0; k < ITEMS; ++k)
+                if (lpos[k] & 0x8000u) lpos[k] = (lpos[k] & 0xFFFF0000u) | 0x8000u | ((lpos[k] & 0x1FFFu) + wcount[w * 256 + (lpos[k] >> 16)]);
+            __syncthreads(); // the counters are part of the staging image
+            // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
+            // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
+            // a seventh of the entries of a byte alphabet).
 #pragma unroll
-        for (int k = 0; k < kWideItems; ++k) {
-            const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
-            if (i < produced) SA[dstv[k]] = sval[i];
+            for (int k = 0; k < ITEMS; ++k)
+                if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, val[k], cfg);
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                if (lpos[k] & 0x8000u) {
+                    const uint32_t slot = lpos[k] & 0x1FFFu;
+                    swnd[slot] = (uint64_t)wnd[k];
+                    sdig[slot] = (uint8_t)(lpos[k] >> 16);
+                }
+            }
+            __syncthreads();
+            uint32_t dstv[ITEMS];
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
+                dstv[k] = 0;
+                if (i < produced) {
+                    const WT nw = (WT)swnd[i];
+                    const uint32_t g = goff[sdig[i]];
+                    dstv[k] = dir > 0 ? g + i : g - i;
+                    WN[dstv[k]] = nw;
+                    BW[dstv[k]] = wnd_symbol<WT>(nw, cfg);
+                }
+            }
+            __syncthreads();
+            uint32_t *sval = reinterpret_cast<uint32_t *>(swnd);
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k)
+                if (lpos[k] & 0x8000u) sval[lpos[k] & 0x1FFFu] = val[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
+                if (i < produced) SA[dstv[k]] = sval[i];
+            }
+            __syncthreads(); // LDS is reused by the next step
         }
-        __syncthreads(); // LDS is reused by the next tile
     }
 }
 
@@ -1447,7 +1495,7 @@ __global__ __launch_bounds__(kRowThreads) void induce_batch_offsets_kernel(uint3
 }
 
 template <class WT, int MODE>
-__global__ __launch_bounds__(kBlock) void induce_batch_scatter_kernel(
+__global__ __launch_bounds__(kBlock, 2) void induce_batch_scatter_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in,
     uint32_t *__restrict__ range_out, uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs,
     uint32_t stride, const uint32_t *__restrict__ totals, const uint32_t *__restrict__ cursor_cur, uint32_t *__restrict__ cursor_nxt,
@@ -1732,6 +1780,7 @@ template <class WT> struct induce_state {
     uint32_t *bhist;  // [round * 8 + bucket][stride] tile counts of the eight-rounds-at-a-time form
     uint32_t *btotals; // kBatchRows row totals
     int batch_on;
+    int unattended; // a pass is queued as a whole: no look at a bucket's last range (induce_typed checks the cursors at the pass's end)
     uint32_t *whist;  // [tile][256] the same for wide alphabets, tiles of 8192 entries
     uint32_t *wsums;  // [chunk][256] column sums of chunks of 256 tiles
     uint32_t stride;
@@ -1756,9 +1805,9 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     uint32_t *nxt = st.cursor[st.par ^ 1];
     // tiles_likely: what the round is expected to need (decides which forms are queued);
     // a round that turns out longer is still handled, by the chained form alone if need be.
-    // three_launch_only (at most 8 buckets): the round is expected to be large for sure, no chained launch is queued behind
-    // the three (they take a range of any length then, an empty one is carried on by the offsets launch)
-    const bool only3 = three_launch_only && st.small_alphabet;
+    // three_launch_only: the round is large for sure (its size is known, or expected beyond doubt), no chained launch is
+    // queued behind the three (they take a range of any length then, an empty one is carried on by the offsets launch)
+    const bool only3 = three_launch_only != 0;
     const bool both = only3 || (!chained_only_up_to_chain_max && (uint64_t)tiles_likely * kIndTile > st.chain_max);
     const uint32_t chain_max = only3 ? 0u : ((both || chained_only_up_to_chain_max) ? st.chain_max : ~0u);
     const int pass_large = chained_only_up_to_chain_max;
@@ -1790,23 +1839,24 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
         const uint32_t wtiles = sx_div_up((uint64_t)(tiles_bound < 1 ? 1 : tiles_bound) * kIndTile, kWideTile);
         const uint32_t wgrid = wtiles > 2048 ? 2048 : wtiles;
+        const int only = only3 ? 1 : 0;
         sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_wide_count_kernel<WT>, dim3(wgrid), dim3(kWideThreads), srcW, srcB,
                   (const uint32_t *)rin, rev, mode, c, st.cfg, st.whist, chain_max);
         if (wtiles <= 512) {
-            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_offsets_kernel, dim3(1), dim3(kBlock), st.whist,
-                      (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_offsets_kernel, dim3(1), dim3(kBlock * kWideOffGroups),
+                      st.whist, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max, only);
         } else {
             const uint32_t nchunks = sx_div_up(wtiles, kWideChunk);
             sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 1024, induce_wide_colsum_kernel, dim3(nchunks), dim3(kBlock),
                       (const uint32_t *)st.whist, (const uint32_t *)rin, st.wsums, chain_max);
             sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)nchunks * 2048, induce_wide_bases_kernel, dim3(1), dim3(kBlock), st.wsums,
-                      (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max);
+                      (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max, only);
             sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_apply_kernel, dim3(nchunks), dim3(kBlock), st.whist,
                       (const uint32_t *)rin, (const uint32_t *)st.wsums, chain_max);
         }
-        sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_wide_scatter_kernel<WT>, dim3(wgrid), dim3(kWideThreads), srcP, srcW,
-                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.whist, cur, dir, st.SA, st.WN, st.BW,
-                  chain_max);
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, induce_wide_scatter_kernel<WT, 8>, dim3(wgrid), dim3(kWideThreads),
+                  srcP, srcW, (const uint32_t *)rin, rev, mode, c, st.cfg, st.T, (const uint32_t *)st.whist, cur, dir, st.SA, st.WN,
+                  st.BW, chain_max);
     }
     uint32_t cgrid = grid > 1024 ? 1024 : grid;
     if (only3) {
@@ -1826,8 +1876,10 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
     ctx->stats.induce_rounds++;
 }
 
-// steps of the tail kernel per launch: a run that outlasts them goes to the device-wide jump (run_fill)
-constexpr uint32_t kTailIters = 64;
+// steps of the tail kernel per launch: a run that outlasts them goes to the device-wide jump (run_fill).  In a pass
+// queued as a whole nobody is there to start that jump, so the tail kernel gets the steps of any run that the
+// classification did not report (shorter than two tiles, 8191 symbols: a step of its loop takes a few microseconds).
+constexpr uint32_t kTailIters = 64, kTailItersUnattended = 16384;
 template <class WT>
 void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, int mode, uint32_t c, int dir)
 {
@@ -1837,11 +1889,11 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_small_kernel<WT>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
-                  cur, nxt, dir, kTailIters);
+                  cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
-                  cur, nxt, dir, kTailIters);
+                  cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters);
     st.par ^= 1;
 }
 
@@ -1896,6 +1948,15 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         const int sh = st.small_alphabet ? 2 : 6;
         while (spec < kMaxSpec && (bound_tiles >> (sh * spec)) >= 1) ++spec;
     }
+    if (!st.small_alphabet) {
+        // by the symbol's share of the text: rounds are queued until the one handed to the tail kernel is expected to hold
+        // an eighth of what the kernel takes (a pass queued as a whole has nobody to queue one more: 1 GiB of 20 symbols,
+        // round 3 of a bucket expected at 5400 entries, beyond 8192 in two buckets -- both passes ran twice)
+        double expect = (double)region_entries * share;
+        int by_share = 1;
+        while (by_share < kMaxSpec && expect > (double)kTailEntries / 8.0) ++by_share, expect *= share;
+        if (by_share > spec) spec = by_share;
+    }
     // Every batch ends with the tail kernel, which runs kTailIters rounds unless the range empties first, and a round
     // consumes one symbol of every run it follows: a bucket cannot need more batches than this (a device fault that
     // keeps the range alive must not keep the host here for ever).
@@ -1944,9 +2005,15 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             double expect = 2.0 * (double)bound_tiles;
             for (int i = 0; i < k; ++i) expect *= share;
             const uint32_t likely = expect < (double)bound_tiles ? (uint32_t)expect : bound_tiles;
-            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir, 1);
+            // (the first round of a large region is large beyond doubt: the three-launch form alone)
+            const bool sure = first && k == 0 && (uint64_t)region_entries > 16ull * st.chain_max;
+            launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir, 1, 0, sure ? 1 : 0);
         }
         launch_tail<WT>(st, spec, spec + 1, rev, mode, c, dir);
+        if (st.unattended) { // the tail kernel ends nearly every bucket; one that it does not shows in the cursors at the pass's end
+            if (total_in_region) *total_in_region = 0xFFFFFFFFu;
+            return 0;
+        }
         uint32_t r[2];
         SX_TRY(sx_readback(ctx, st.ranges + 2 * (spec + 1), 2, r));
         if (r[1] == r[0]) {
@@ -2024,11 +2091,12 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     // look-back status words: one per (tile, bucket) of the largest round
     // The look-back walk costs a few microseconds per tile, so long rounds are better off with
     // the three launches: beyond 256 tiles when a wave walks back for each of <= 8 buckets,
-    // With more than 8 buckets every round beyond what the tail kernel takes (8192 entries) goes to the radix-pass
-    // form (induce_wide_*): one look-back thread per bucket and tile made a 2 M-entry round of a 255-symbol text cost
-    // 100 us and more.
+    // With more than 8 buckets every round beyond four times what the tail kernel takes (32 768 entries, the second
+    // round of a byte text's 4 M-entry buckets) goes to the radix-pass form (induce_wide_*): one look-back thread per
+    // bucket and tile made a 2 M-entry round of a 255-symbol text cost 100 us and more, but a round of a few tiles is
+    // one launch of 20 us where the three took 50 (1 GiB of bytes through the induction: 122 -> 111 ms).
     st.chain_max = ctx->chain_max_override >= 0 ? (uint32_t)ctx->chain_max_override
-                                                : (st.small_alphabet ? 256u * (uint32_t)kIndTile : kTailEntries);
+                                                : (st.small_alphabet ? 256u * (uint32_t)kIndTile : 4u * kTailEntries);
     const size_t status_words = ((size_t)sx_div_up(largest, kIndTile) + 2) * nk + kChainHeader; // any round may be chained
     st.stride = sx_div_up(largest, kIndTile) + 1;
     st.hist = st.whist = st.wsums = st.bhist = st.btotals = nullptr;
@@ -2056,44 +2124,87 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     // the sentinel suffix (sa_is.c:463: SA[0] = n)
     sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, st.BW, (uint32_t)ti.n, ti.T, cfg);
 
+    // Both passes are queued as a whole, the host not waiting for any bucket (a wait is 20 - 30 us of idle device: 16 of
+    // them a build at 5 buckets, 1000 at 256): the tail kernel ends nearly every bucket's rounds on its own, and a bucket
+    // it leaves unfinished (runs of a symbol longer than its rounds and jumps reach) receives fewer suffixes than the
+    // classification counted -- every suffix is induced exactly once, so the cursors at the pass's end tell.  The pass is
+    // then run again attended: the host reads every bucket's last range back and carries long runs on (device-wide
+    // jumps).  Texts in which the classification saw a run fill a whole 4096-symbol tile are attended from the start.
+    auto cursors_as_counted = [&](bool &ok) -> int {
+        uint32_t cur[256];
+        SX_TRY(sx_readback(ctx, (const uint32_t *)st.cursor[st.par], nk, cur));
+        ok = true;
+        // both passes end with every cursor between its bucket's L and S suffixes (bucket 0 holds the sentinel's suffix
+        // alone, which no pass induces)
+        for (uint32_t c = 1; c < nk; ++c)
+            if (ti.h_all[c] && cur[c] != begin[c] + ti.h_l[c]) ok = false;
+        return 0;
+    };
     // ---- L pass: buckets ascending, cursors at the bucket heads ------------------------
-    SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    for (uint32_t c = 0; c < nk; ++c) {
-        if (ti.h_all[c] == 0) continue;
-        if (ti.h_l[c]) {
-            uint32_t head_end = 0;
-            SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end, (double)ti.h_all[c] / (double)N));
-            if (head_end - begin[c] != ti.h_l[c])
-                return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
+    auto pass_L = [&](bool unattended) -> int {
+        st.unattended = unattended ? 1 : 0;
+        SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t c = 0; c < nk; ++c) {
+            if (ti.h_all[c] == 0) continue;
+            if (ti.h_l[c]) {
+                uint32_t head_end = 0;
+                SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end, (double)ti.h_all[c] / (double)N));
+                if (!unattended && head_end - begin[c] != ti.h_l[c])
+                    return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
+            }
+            if (ti.h_lms[c]) {
+                SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
+                sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
+                          (const uint32_t *)st.cursor[st.par], (int)c, 0);
+                // (the round's size is known: the one form that takes it, and no launch that finds nothing to do)
+                launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), sx_div_up(ti.h_lms[c], kIndTile), 0,
+                                 MODE_L_FROM_LMS, c, +1, 0, 0, ti.h_lms[c] > st.chain_max ? 1 : 0);
+            }
         }
-        if (ti.h_lms[c]) {
-            SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
-            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
-                      (const uint32_t *)st.cursor[st.par], (int)c, 0);
-            launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), sx_div_up(ti.h_lms[c], kIndTile), 0,
-                             MODE_L_FROM_LMS, c, +1, 0);
-        }
-    }
-
+        return 0;
+    };
     // ---- S pass: buckets descending, cursors at the bucket ends -------------------------
-    SX_CHECK(hipStreamSynchronize(ctx->stream)); // `begin` is about to be reused as the upload source
-    SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    for (uint32_t cc = nk; cc-- > 0;) {
-        const uint32_t c = cc;
-        if (ti.h_all[c] == 0) continue;
-        const uint32_t n_s = ti.h_all[c] - ti.h_l[c];
-        if (c > 0 && n_s) {
-            uint32_t tail_end = 0;
-            SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end, (double)ti.h_all[c] / (double)N));
-            if (begin[c + 1] - tail_end != n_s)
-                return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
+    auto pass_S = [&](bool unattended) -> int {
+        st.unattended = unattended ? 1 : 0;
+        SX_CHECK(hipStreamSynchronize(ctx->stream)); // (the upload source of the pass before may still be in use)
+        SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        for (uint32_t cc = nk; cc-- > 0;) {
+            const uint32_t c = cc;
+            if (ti.h_all[c] == 0) continue;
+            const uint32_t n_s = ti.h_all[c] - ti.h_l[c];
+            if (c > 0 && n_s) {
+                uint32_t tail_end = 0;
+                SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end, (double)ti.h_all[c] / (double)N));
+                if (!unattended && begin[c + 1] - tail_end != n_s)
+                    return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
+            }
+            if (ti.h_l[c]) {
+                SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
+                sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
+                          begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0);
+                launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), sx_div_up(ti.h_l[c], kIndTile), 1,
+                                 MODE_S_FROM_L, c, -1, 0, 0, ti.h_l[c] > st.chain_max ? 1 : 0);
+            }
         }
-        if (ti.h_l[c]) {
-            SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
-            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
-                      begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0);
-            launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), sx_div_up(ti.h_l[c], kIndTile), 1,
-                             MODE_S_FROM_L, c, -1, 0);
+        return 0;
+    };
+    ctx->stats.long_runs = ti.open_tiles ? 1u : 0u;
+    // (At most 8 buckets: attended.  There the waits are 16 a build, and what the tail kernel cannot hold is common in
+    //  real texts -- thousands of poly-A tracts and microsatellites alive in one bucket after the queued rounds --, which
+    //  would cost the pass a second run.  SX_FLAG_INDUCE_ATTENDED 2 lets the tests run such texts unattended.)
+    const bool unattended = ctx->induce_attended != 1 && ti.open_tiles == 0 && (!st.small_alphabet || ctx->induce_attended == 2);
+    for (int pass = 0; pass < 2; ++pass) {
+        bool ok = false;
+        if (unattended) {
+            SX_TRY(pass == 0 ? pass_L(true) : pass_S(true));
+            SX_TRY(cursors_as_counted(ok));
+            if (!ok) ctx->stats.induce_redo++;
+        }
+        if (!ok) {
+            SX_TRY(pass == 0 ? pass_L(false) : pass_S(false));
+            SX_TRY(cursors_as_counted(ok));
+            if (!ok) return sx_fail_msg(ctx, SX_E_INTERNAL, pass == 0 ? "induce L: a bucket did not receive its L-type count"
+                                                                        : "induce S: a bucket did not receive its S-type count");
         }
     }
 

@@ -28,6 +28,7 @@ struct sx_text_info {
     uint32_t *d_hist;   // device: 3 * 256: all symbols, L-type symbols, LMS symbols
     uint32_t *d_scalar; // device: a few u32 results (totals)
     uint32_t h_all[256], h_l[256], h_lms[256];
+    uint32_t open_tiles; // classification tiles made of one symbol whose run goes on: runs of 4096 symbols and more
     uint32_t maxc;      // largest symbol present
     uint64_t m;         // LMS positions incl. the sentinel
     uint64_t M;         // samples

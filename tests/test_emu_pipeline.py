@@ -2,6 +2,8 @@
 oracle and the golden vectors.  This checks kernel logic (ballot ranking, tile
 carries, scans) where there is no GPU; the `-m gpu` tests repeat the parity checks
 on hardware through the product library."""
+import os
+
 import numpy as np
 import pytest
 
@@ -402,6 +404,68 @@ def test_production_genome_through_the_farm(emu_ctx, golden_genomes, tmp_path):
     the unmodified reference's arrays and index file"""
     from conftest import check_genomes
     check_genomes(emu_ctx.lib, golden_genomes, tmp_path, names=("hg38-1000.fa",))
+
+
+def test_induce_round_batches_and_unattended_passes(emu_ctx):
+    """round 3's forms of the induced-sort passes, forced onto small texts: eight self rounds of a bucket by one count /
+    scan / scatter (SX_FLAG_INDUCE_BATCH_MIN), rounds queued in the three-launch form alone, the wide scatter's two steps
+    a tile, passes queued as a whole with the cursor check at their end (SX_FLAG_INDUCE_ATTENDED), and the second,
+    attended run of a pass that left a bucket short; against the oracle"""
+    rng = np.random.default_rng(31)
+    # (the AddressSanitizer run of this file, tests/test_emu_asan.py, takes the small cases only)
+    full = os.environ.get("STRALG_EMU_ASAN") != "1"
+
+    def check(x, sigma):
+        want = oracle.sa_is_strict(x, sigma)
+        sa = emu_ctx.sa_build(x, sigma)
+        assert (sa == want).all(), (sigma, x.size)
+        return emu_ctx.last_stats()
+
+    try:
+        for bmin in (0, 50) if full else (0,):
+            emu_ctx.set_induce_batch_min(bmin)
+            for sigma, n in ((2, 2049), (3, 5000), (5, 20000), (6, 5000), (8, 9000)):
+                check(rng.integers(1, sigma, size=n, dtype=np.uint8), sigma)
+            x = synth(12000, 5, 3)
+            x[1000:1400] = 1
+            x[5000:5030] = 4
+            x[9000:9300] = 2
+            x[9500:11900] = 3
+            check(x, 5)
+        emu_ctx.set_induce_batch_min(-1)
+        emu_ctx.set_induce_batch(False)
+        check(synth(9000, 5, 9), 5)
+        emu_ctx.set_induce_batch(True)
+        # wide alphabets through the induction: the radix-pass round form with every chain_max, unattended by default
+        emu_ctx.set_no_direct_sort(True)
+        for cm in (-1, 0, 300) if full else (0,):
+            emu_ctx.set_chain_max_entries(cm)
+            for sigma, n in ((9, 5000), (21, 12000), (256 if cm < 0 else 40, 6000 if cm < 0 else 12000)) if full else ((21, 3000),):
+                x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+                x[1000:1040] = x[1000]
+                st = check(x, sigma)
+                assert st["induce_redo"] == 0 and st["long_runs"] == 0
+        emu_ctx.set_chain_max_entries(-1)
+        x = rng.integers(1, 20, size=14000, dtype=np.uint8)
+        x[3000:12000] = 7  # a run that fills a whole classification tile: attended from the start
+        assert check(x, 20)["long_runs"] == 1
+        emu_ctx.set_no_direct_sort(False)
+        # 9000 runs of 20 symbols alive in one bucket: more than the tail kernel holds after the queued rounds, so the
+        # unattended pass leaves the bucket short, the cursors tell, and the pass runs again attended
+        unit = np.array([1] * 20 + [2, 3], np.uint8)
+        x = np.tile(unit, 9000)
+        x[21::22] = rng.integers(2, 5, size=9000, dtype=np.uint8)
+        emu_ctx.set_induce_attended(2)
+        assert check(x, 5)["induce_redo"] >= 1
+        check(synth(9000, 5, 11), 5)
+        emu_ctx.set_induce_attended(1)
+        assert check(x, 5)["induce_redo"] == 0
+    finally:
+        emu_ctx.set_induce_attended(0)
+        emu_ctx.set_induce_batch_min(-1)
+        emu_ctx.set_induce_batch(True)
+        emu_ctx.set_chain_max_entries(-1)
+        emu_ctx.set_no_direct_sort(False)
 
 
 def test_primitives(emu_ctx):
