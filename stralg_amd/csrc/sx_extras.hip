@@ -32,6 +32,96 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(const uint32_t *__restr
     else atomicAdd(bad, 1u); // not a suffix array over N positions
 }
 
+// ---- the inverse of a long suffix array in two passes -------------------------------------------------------------
+// inv[sa[i]] = i is one 4-byte store per entry at a random place: every store pulls a line in and pushes it out
+// again (2^28 entries: 9.9 ms, 34 GB of traffic for 2 GiB of arrays).  Two passes keep the stores inside windows
+// the L2 holds: the entries are first dealt into partitions by the top bits of their target -- a partition is a
+// window of 2^19 targets and, the array being a permutation, receives exactly as many entries, so the partitions'
+// places are known in advance and a workgroup only has to reserve its share of each with one atomic add (the
+// order inside a partition does not matter) -- as (target, index) pairs, and a second pass walks the pairs in
+// partition order, every XCD the partitions of its own eighth of the array.  1 + 2 GiB out, 2 + 1 GiB in.
+constexpr int kInvThreads = 512, kInvItems = 16, kInvTile = kInvThreads * kInvItems;
+#ifndef SX_INV_WINDOW_BITS
+#define SX_INV_WINDOW_BITS 19 // (the CPU test harness builds with 8: several partitions on small arrays)
+#endif
+constexpr uint32_t kInvWindowBits = SX_INV_WINDOW_BITS, kInvMaxParts = 8192; // N <= 2^32: at most 8192 partitions of 2^19
+__global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const uint32_t *__restrict__ sa, uint64_t N, uint32_t nparts, uint32_t wbits,
+                                                                         uint32_t *__restrict__ cursor /* entries dealt into each partition so far */,
+                                                                         uint2 *__restrict__ pairs, uint32_t *__restrict__ bad)
+{
+    __shared__ uint32_t cnt[kInvMaxParts]; // the tile's entries per partition, then where its share of the partition begins
+    const uint32_t t = threadIdx.x;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * kInvTile; tile0 < N; tile0 += (uint64_t)gridDim.x * kInvTile) { // uniform
+        for (uint32_t q = t; q < nparts; q += kInvThreads) cnt[q] = 0;
+        __syncthreads();
+        uint32_t p[kInvItems], r[kInvItems];
+#pragma unroll
+        for (int k = 0; k < kInvItems; ++k) {
+            const uint64_t i = tile0 + (uint64_t)k * kInvThreads + t;
+            p[k] = i < N ? sa[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < kInvItems; ++k) {
+            const uint64_t i = tile0 + (uint64_t)k * kInvThreads + t;
+            r[k] = 0;
+            if (i < N) {
+                if ((uint64_t)p[k] < N) r[k] = atomicAdd(&cnt[p[k] >> wbits], 1u);
+                else atomicAdd(bad, 1u); // not a suffix array over N positions
+            }
+        }
+        __syncthreads();
+        for (uint32_t q = t; q < nparts; q += kInvThreads) {
+            const uint32_t c = cnt[q];
+            if (c) {
+                const uint32_t at = atomicAdd(&cursor[q], c);
+                const uint64_t first = (uint64_t)q << wbits, room = (N - first < (1ull << wbits) ? N - first : (1ull << wbits));
+                if ((uint64_t)at + c > room) { // more entries than targets: not a permutation
+                    atomicAdd(bad, 1u);
+                    cnt[q] = 0xFFFFFFFFu;
+                } else {
+                    cnt[q] = (uint32_t)first + at;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kInvItems; ++k) {
+            const uint64_t i = tile0 + (uint64_t)k * kInvThreads + t;
+            if (i < N && (uint64_t)p[k] < N) {
+                const uint32_t base = cnt[p[k] >> wbits];
+                if (base != 0xFFFFFFFFu) {
+                    uint2 e;
+                    e.x = p[k], e.y = (uint32_t)i;
+                    pairs[(uint64_t)base + r[k]] = e;
+                }
+            }
+        }
+        __syncthreads(); // `cnt` is zeroed for the next tile
+    }
+}
+
+// pairs in partition order -> inv; workgroup b of XCD x = b % 8 takes the x-th eighth of the pairs, in order
+__global__ __launch_bounds__(kBlock) void inverse_apply_kernel(const uint2 *__restrict__ pairs, uint64_t N, uint32_t *__restrict__ inv, int by_xcd)
+{
+    constexpr int kPer = 8;
+    const uint64_t chunks = (N + (uint64_t)kBlock * kPer - 1) / ((uint64_t)kBlock * kPer);
+    const uint64_t per_xcd = (chunks + 7) / 8;
+    const uint64_t chunk = by_xcd ? (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (uint64_t)blockIdx.x;
+    if ((by_xcd && (blockIdx.x >> 3) >= per_xcd) || chunk >= chunks) return;
+    const uint64_t j0 = chunk * kBlock * kPer;
+    uint2 e[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint64_t j = j0 + (uint64_t)k * kBlock + threadIdx.x;
+        if (j < N) e[k] = pairs[j];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint64_t j = j0 + (uint64_t)k * kBlock + threadIdx.x;
+        if (j < N) inv[e[k].x] = e[k].y;
+    }
+}
+
 constexpr int kLcpChunk = 64;
 
 // length of the common prefix of text[a..] and text[b..], starting the comparison at offset l
@@ -150,15 +240,37 @@ __global__ __launch_bounds__(kBlock) void bwt_exact_search_kernel(const uint32_t
 
 using namespace sx;
 
+#ifndef SX_INVERSE_TWO_PASS_FROM
+#define SX_INVERSE_TWO_PASS_FROM (1ull << 23) // (shorter arrays' targets fit the caches as they are)
+#endif
 static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv)
 {
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, 4096));
     uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
     SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
-    sx_launch(ctx, SX_KC_LCP, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
+    // (2^28 entries, same box: windows of 2^16 ... 2^21 targets 6.1, 6.2, 5.2, 5.0, 5.3, 6.2 ms; the second pass in plain
+    //  workgroup order instead of XCD by XCD 5.4; the single-pass kernel 9.9)
+    uint32_t wbits = kInvWindowBits;
+    const int by_xcd = 1;
+    while (((N + (1ull << wbits) - 1) >> wbits) > kInvMaxParts) ++wbits;
+    if (N >= SX_INVERSE_TWO_PASS_FROM) {
+        const uint32_t nparts = (uint32_t)((N + (1ull << wbits) - 1) >> wbits);
+        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, N * sizeof(uint2) + (size_t)kInvMaxParts * 4 + 512));
+        uint32_t *cursor = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
+        uint2 *pairs = (uint2 *)((char *)ctx->slab[SX_SLAB_SORT].p + (size_t)kInvMaxParts * 4 + 256);
+        SX_CHECK(hipMemsetAsync(cursor, 0, (size_t)nparts * 4, ctx->stream));
+        uint32_t grid = sx_div_up(N, kInvTile);
+        if (grid > 4096) grid = 4096;
+        sx_launch(ctx, SX_KC_LCP, N * 12, inverse_partition_kernel, dim3(grid), dim3(kInvThreads), d_sa, N, nparts, wbits, cursor, pairs, bad);
+        const uint64_t chunks = (N + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
+        sx_launch(ctx, SX_KC_LCP, N * 12, inverse_apply_kernel, dim3((uint32_t)(((chunks + 7) / 8) * 8)), dim3(kBlock), (const uint2 *)pairs, N,
+                  d_inv, by_xcd);
+    } else {
+        sx_launch(ctx, SX_KC_LCP, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
+    }
     uint32_t h_bad = 0;
     SX_TRY(sx_readback(ctx, bad, 1, &h_bad));
-    if (h_bad) return sx_fail_msg(ctx, SX_E_ARG, "sa holds an entry outside [0, N)");
+    if (h_bad) return sx_fail_msg(ctx, SX_E_ARG, "sa is not a permutation of [0, N)");
     return 0;
 }
 

@@ -34,6 +34,18 @@ for step in "$@"; do
       python3 tools/step_timeline.py "$out/trace_$k" > "$out/trace_${k}_timeline.txt" 2>&1
       tail -3 "$out/trace_${k}_timeline.txt"
       find "$out/trace_$k" -name "*.csv" -size +8M -delete;;
+    prof)
+      # rocprofv3 of `python3 ARG...` (bench.py or a tool): kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in passes of
+      # their own (PMC passes never share a run with a trace: the MI355X guide's HBM section), one summary
+      pd="$out/prof_$k"; rm -rf "$pd"; mkdir -p "$pd"
+      ( cd /tmp && export TMPDIR=/tmp
+        timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$pd/trace" -- python3 $GRAFT_REPO_ROOT/$arg > "$GRAFT_REPO_ROOT/$pd/trace.log" 2>&1 &&
+        timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/$pd/pmc_fetch" -- python3 $GRAFT_REPO_ROOT/$arg > "$GRAFT_REPO_ROOT/$pd/pmc_fetch.log" 2>&1 &&
+        timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/$pd/pmc_write" -- python3 $GRAFT_REPO_ROOT/$arg > "$GRAFT_REPO_ROOT/$pd/pmc_write.log" 2>&1 )
+      rc=$?
+      python3 tools/profile_summary.py "$pd" > "$pd/summary.txt" 2>&1
+      tail -4 "$pd/trace.log"; head -12 "$pd/summary.txt"
+      find "$pd" -name "*.csv" -size +6M -delete;;
     py)
       timeout -k 10 900 python $arg > "$out/py_$k.log" 2>&1
       rc=$?; tail -20 "$out/py_$k.log";;
