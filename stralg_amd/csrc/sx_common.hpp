@@ -67,7 +67,8 @@ struct sx_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     sx_slab slab[SX_NSLABS];
-    uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB)
+    uint32_t *h_pin = nullptr; // pinned read-back page (4 KiB) + word 1024: the sequence number of the last read-back
+    uint32_t readback_seq = 0;
     char *h_stage[2] = {nullptr, nullptr}; // pinned staging of the streaming downloads (allocated on first use)
     // profiling
     uint32_t chain_epoch = 0; // look-back status epoch (24 bits), see sx_device.hpp

@@ -1,4 +1,6 @@
 // sx_ctx.hip -- context lifetime, workspace slabs, HIP-event profiler.
+#include <atomic>
+#include <chrono>
 #include "sx_common.hpp"
 #include "sx_scan.hpp"
 
@@ -86,11 +88,39 @@ int sx_sync(sx_ctx *ctx)
     return 0;
 }
 
+// The values go to the pinned page by a one-workgroup kernel that then stores a sequence number behind them (system
+// scope: the page is host-coherent), and the host polls that word instead of sleeping in hipStreamSynchronize: the
+// stream is in order, so the word's arrival says that everything queued before has run.  A build reads a handful of
+// words back some twenty times (one per bucket region of the induced-sort passes); the wake-up through the runtime
+// cost 10 - 15 us of idle device each time.  The poll gives up after two seconds and falls back to the synchronize
+// (which also reports a device fault).
+namespace sx {
+__global__ void readback_kernel(const uint32_t *__restrict__ src, uint32_t count, uint32_t *__restrict__ page, uint32_t seq)
+{
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) __hip_atomic_store(&page[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&page[1024], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+} // namespace sx
+
 int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst)
 {
-    if (count * sizeof(uint32_t) > 4096) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
-    SX_CHECK(hipMemcpyAsync(ctx->h_pin, d_src, count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SX_CHECK(hipStreamSynchronize(ctx->stream));
+    if (count > 1024) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
+    const uint32_t seq = ++ctx->readback_seq ? ctx->readback_seq : ++ctx->readback_seq; // (never 0: the page starts zeroed)
+    hipLaunchKernelGGL(sx::readback_kernel, dim3(1), dim3(256), 0, ctx->stream, d_src, (uint32_t)count, ctx->h_pin, seq);
+    if (hipGetLastError() != hipSuccess) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback launch refused");
+    volatile uint32_t *flag = ctx->h_pin + 1024;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (*flag != seq) {
+        if ((++spins & 0x3FFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
+    if (*flag != seq) SX_CHECK(hipStreamSynchronize(ctx->stream)); // (slow device, or a fault: let the runtime say)
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag != seq) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback: the sequence word did not arrive");
     if (ctx->launch_err != hipSuccess) return launch_error(ctx);
     memcpy(h_dst, ctx->h_pin, count * sizeof(uint32_t));
     return 0;
@@ -173,11 +203,12 @@ int sx_ctx_create(int device, sx_ctx **out)
     memset(ctx->kstat, 0, sizeof ctx->kstat);
     memset(&ctx->stats, 0, sizeof ctx->stats);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_pin, 4096, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_pin, 8192, hipHostMallocDefault) != hipSuccess) {
         fprintf(stderr, "stralg_amd: cannot initialise device %d\n", device);
         delete ctx;
         return SX_E_INTERNAL;
     }
+    memset(ctx->h_pin, 0, 8192); // (the read-back sequence word starts at 0)
     *out = ctx;
     return 0;
 }

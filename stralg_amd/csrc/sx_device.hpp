@@ -469,7 +469,10 @@ __device__ __forceinline__ uint32_t block_scan_row_inplace(uint32_t *__restrict_
 // counts of each of four 8192-count pieces and loads them as 16-byte pairs, all eight loads in flight together (a wave's
 // load covers 2 KiB of consecutive counts, so nothing has to be turned through LDS); 32 768 counts an iteration: one
 // trip to memory for the 33 000 tile counts of a 1 GiB text's largest round (the 256-thread form above: five).
-constexpr int kRowThreads = 1024, kRowWaves = kRowThreads / kWave, kRowPieces = 4, kRowPer = 8;
+#ifndef SX_ROW_THREADS
+#define SX_ROW_THREADS 1024 // (the CPU test harness builds with 256: a fiber per thread and launch)
+#endif
+constexpr int kRowThreads = SX_ROW_THREADS, kRowWaves = kRowThreads / kWave, kRowPieces = 4, kRowPer = 8;
 __device__ __forceinline__ uint32_t wide_scan_row_inplace(uint32_t *__restrict__ row, uint64_t count, uint32_t *lds /* kRowPieces * kRowWaves */)
 {
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;

@@ -113,7 +113,10 @@ __global__ __launch_bounds__(kBlock) void inverse_apply_kernel(const uint2 *__re
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const uint64_t j = j0 + (uint64_t)k * kBlock + threadIdx.x;
-        if (j < N) e[k] = pairs[j];
+        if (j < N) { // (streaming loads: the pairs are read once and must not push the window's half-written lines out of the L2)
+            const uint64_t raw = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pairs) + j);
+            e[k].x = (uint32_t)raw, e[k].y = (uint32_t)(raw >> 32);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {

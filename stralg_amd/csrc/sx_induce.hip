@@ -500,7 +500,10 @@ __global__ __launch_bounds__(kWideThreads) void induce_wide_count_kernel(const W
 // the tiles -- whole 1 KiB rows, 16 in flight -- sums it, the quarters' sums meet in LDS, and the second walk writes the
 // prefixes.  (One thread per bucket walking all the tiles, loads and in-place stores alternating: 31 us for the 500 tiles
 // of a byte text's buckets, of the 140 us such a bucket's round took.)
-constexpr int kWideOffGroups = 4;
+#ifndef SX_WIDE_OFF_GROUPS
+#define SX_WIDE_OFF_GROUPS 4 // (the CPU test harness: 2)
+#endif
+constexpr int kWideOffGroups = SX_WIDE_OFF_GROUPS;
 __global__ __launch_bounds__(kBlock * kWideOffGroups) void induce_wide_offsets_kernel(uint32_t *__restrict__ hist,
                                                                      const uint32_t *__restrict__ range_in,
                                                                      uint32_t *__restrict__ range_out,
@@ -949,25 +952,29 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         // Tried only when the last round kept every entry (the sign of runs): the check reads memory.
         if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len == prev_len) {
             const uint32_t G = len <= (uint32_t)kTailBlock ? (uint32_t)kTailBlock / len : 1u; // threads per entry
-            const uint32_t L = 16u * G;
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
-            bool all_c = true;
+            // thread (i, q) looks at the q-th 16 symbols to the left of entry i; the nearest piece of any entry that is
+            // not all c bounds the rounds that can be written at once (a run of 3000 symbols: 2992 rounds in one step,
+            // where all G pieces had to be c before -- 16 384 symbols for a single run -- and shorter runs went round by round)
+            uint32_t first_other = G;
             for (uint32_t e = (uint32_t)t; e < len * G; e += kTailBlock) {
                 const uint32_t i = e / G, q = e % G;
                 const uint32_t p = SA[lo + (rev ? len - 1u - i : i)];
-                if (p < 16u * (q + 1u)) {
-                    all_c = false;
-                } else {
+                bool all_c = false;
+                if (p >= 16u * (q + 1u)) {
                     uint64_t o0, o1;
                     load_bytes16(T, (uint64_t)(p - 16u * (q + 1u)), o0, o1);
-                    if (o0 != cpat || o1 != cpat) all_c = false;
+                    all_c = o0 == cpat && o1 == cpat;
                 }
+                if (!all_c && q < first_other) first_other = q;
             }
-            if (t == 0) s_flag = 1;
+            if (t == 0) s_flag = G;
             __syncthreads();
-            if (!all_c) s_flag = 0; // benign race: every writer stores 0
+            if (first_other < G) atomicMin(&s_flag, first_other);
             __syncthreads();
-            if (s_flag) { // uniform
+            const uint32_t L = 16u * s_flag;
+            __syncthreads(); // (s_flag is set again by the next step)
+            if (L) { // uniform
                 const uint32_t cur = gbase[c], total = L * len;
                 for (uint32_t o = (uint32_t)t; o < total; o += kTailBlock) {
                     const uint32_t j = o / len + 1u, i = o % len;
@@ -1112,25 +1119,29 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
         // ---- run jump (as in induce_tail_kernel) --------------------------------------------------------------------
         if (len == prev_len) {
             const uint32_t G = len <= (uint32_t)kTailBlock ? (uint32_t)kTailBlock / len : 1u; // threads per entry
-            const uint32_t L = 16u * G;
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
-            bool all_c = true;
+            // thread (i, q) looks at the q-th 16 symbols to the left of entry i; the nearest piece of any entry that is
+            // not all c bounds the rounds that can be written at once (a run of 3000 symbols: 2992 rounds in one step,
+            // where all G pieces had to be c before -- 16 384 symbols for a single run -- and shorter runs went round by round)
+            uint32_t first_other = G;
             for (uint32_t e = (uint32_t)t; e < len * G; e += kTailBlock) {
                 const uint32_t i = e / G, q = e % G;
                 const uint32_t p = SA[lo + (rev ? len - 1u - i : i)];
-                if (p < 16u * (q + 1u)) {
-                    all_c = false;
-                } else {
+                bool all_c = false;
+                if (p >= 16u * (q + 1u)) {
                     uint64_t o0, o1;
                     load_bytes16(T, (uint64_t)(p - 16u * (q + 1u)), o0, o1);
-                    if (o0 != cpat || o1 != cpat) all_c = false;
+                    all_c = o0 == cpat && o1 == cpat;
                 }
+                if (!all_c && q < first_other) first_other = q;
             }
-            if (t == 0) s_flag = 1;
+            if (t == 0) s_flag = G;
             __syncthreads();
-            if (!all_c) s_flag = 0; // benign race: every writer stores 0
+            if (first_other < G) atomicMin(&s_flag, first_other);
             __syncthreads();
-            if (s_flag) { // uniform
+            const uint32_t L = 16u * s_flag;
+            __syncthreads(); // (s_flag is set again by the next step)
+            if (L) { // uniform
                 const uint32_t cur = gbase[c], total = L * len;
                 for (uint32_t o = (uint32_t)t; o < total; o += kTailBlock) {
                     const uint32_t j = o / len + 1u, i = o % len;
@@ -1688,9 +1699,12 @@ __global__ void run_commit_kernel(uint32_t *__restrict__ range, uint32_t *__rest
 }
 
 // range <- [lo, hi) given by the host, or [a, cursor[c]) / [cursor[c], b) for the first round of a bucket
-__global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, const uint32_t *cursor, int c, int which)
+// (and the tickets of the chained launches that follow are zeroed: one launch instead of a memset and a launch)
+__global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, const uint32_t *cursor, int c, int which,
+                                 uint32_t *tickets, uint32_t ntickets)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (uint32_t i = 0; i < ntickets; ++i) tickets[i] = 0;
         if (which == 1) hi = cursor[c];      // L pass: [bucket begin, head cursor)
         else if (which == 2) lo = cursor[c]; // S pass: [tail cursor, bucket end)
         range[0] = lo;
@@ -1963,10 +1977,11 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
     const uint64_t max_batches = 2 * (st.N / kTailIters) + 64; // (rounds too long for the tail consume > 8192 symbols each)
     for (uint64_t batch = 0;; ++batch) {
         if (batch > max_batches) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: the rounds of a bucket did not come to an end");
-        SX_CHECK(hipMemsetAsync(st.tickets, 0, (kMaxSpec + 2) * sizeof(uint32_t), ctx->stream));
         if (first)
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
-                      (const uint32_t *)st.cursor[st.par], (int)c, which);
+                      (const uint32_t *)st.cursor[st.par], (int)c, which, st.tickets, (uint32_t)(kMaxSpec + 2));
+        else
+            SX_CHECK(hipMemsetAsync(st.tickets, 0, (kMaxSpec + 2) * sizeof(uint32_t), ctx->stream));
         const bool batched = st.small_alphabet && st.batch_on && (mode == MODE_L_FROM_L || mode == MODE_S_FROM_S);
         if (batched) {
             // First the rounds expected to be large, a launch each -- round k of a bucket holds about share^k of its region
@@ -2022,7 +2037,7 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         }
         // a long run of symbol c: carry on from the last range
         sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, r[0], r[1],
-                  (const uint32_t *)st.cursor[st.par], (int)c, 0);
+                  (const uint32_t *)st.cursor[st.par], (int)c, 0, (uint32_t *)nullptr, 0u);
         if (r[1] - r[0] <= kRunEntries) {
             // a handful of entries deep inside runs: the device-wide jump, twice (a run may be longer than one probe looks)
             for (int rep = 0; rep < 2; ++rep) {
@@ -2153,9 +2168,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
                     return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
             }
             if (ti.h_lms[c]) {
-                SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
                 sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
-                          (const uint32_t *)st.cursor[st.par], (int)c, 0);
+                          (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u);
                 // (the round's size is known: the one form that takes it, and no launch that finds nothing to do)
                 launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), sx_div_up(ti.h_lms[c], kIndTile), 0,
                                  MODE_L_FROM_LMS, c, +1, 0, 0, ti.h_lms[c] > st.chain_max ? 1 : 0);
@@ -2179,9 +2193,8 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
                     return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
             }
             if (ti.h_l[c]) {
-                SX_CHECK(hipMemsetAsync(st.tickets, 0, sizeof(uint32_t), ctx->stream));
                 sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
-                          begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0);
+                          begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u);
                 launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), sx_div_up(ti.h_l[c], kIndTile), 1,
                                  MODE_S_FROM_L, c, -1, 0, 0, ti.h_l[c] > st.chain_max ? 1 : 0);
             }

@@ -101,6 +101,7 @@ static void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size
 static inline void __syncthreads() { emu_syncthreads(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 static inline int __lane_id() { return emu_lane(); }
 
 static inline unsigned long long __ballot(int pred)
@@ -215,6 +216,9 @@ static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) 
 #define __ATOMIC_RELAXED_EMU 0
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+#ifndef __HIP_MEMORY_SCOPE_SYSTEM
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
 #endif
 #ifndef __HIP_MEMORY_SCOPE_WORKGROUP
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
