@@ -115,6 +115,8 @@ enum {
                                        the bucket cursors at its end (a pass that left a bucket short is run again attended),
                                        smaller ones are attended: the host reads every bucket's last range back before it queues
                                        the next bucket; 1 = always attended; 2 = never, whatever the alphabet (tests) */
+    ,SX_FLAG_COPY_TEXT_FIRST = 10   /* 1 = the build's padded copy of the text is made by a device copy before the classification
+                                       (rounds 1 and 2); 0 = the classification writes it while it reads the caller's text */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

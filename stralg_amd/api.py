@@ -240,6 +240,11 @@ class Context:
         bucket's last range, 2 never (any alphabet)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 9, int(mode)), "sx_ctx_set_flag")
 
+    def set_copy_text_first(self, on=True):
+        """SX_FLAG_COPY_TEXT_FIRST: a device copy of the text before the classification (True) or the copy made by the
+        classification while it reads the caller's text (default)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 10, 1 if on else 0), "sx_ctx_set_flag")
+
     def trim(self):
         self.lib.sx_ctx_trim(self.h)
 

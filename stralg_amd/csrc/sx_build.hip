@@ -101,8 +101,13 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     const uint64_t padded = (uint64_t)sx_div_up(N, kClsTile) * kClsTile + 128;
     uint8_t *T = an.take<uint8_t>(padded);
     if (!T) return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: text");
-    // only the tail needs zeroing: sentinel + padding
-    SX_CHECK(hipMemcpyAsync(T, d_text, n, hipMemcpyDeviceToDevice, ctx->stream));
+    // The copy of the text: where the classification comes first (no direct sort of all suffixes to be tried) it makes
+    // the copy itself while it reads the text -- all but the last tile or two, which are copied here --; only the tail
+    // needs zeroing: sentinel + padding.
+    uint32_t src_tiles = 0;
+    if (!ctx->copy_text_first && sigma <= 16 && ((uintptr_t)d_text & 15u) == 0 && n >= (uint64_t)kClsTile + 64) src_tiles = (uint32_t)((n - 64) / kClsTile);
+    const uint64_t copied_from = (uint64_t)src_tiles * kClsTile;
+    SX_CHECK(hipMemcpyAsync(T + copied_from, d_text + copied_from, n - copied_from, hipMemcpyDeviceToDevice, ctx->stream));
     SX_CHECK(hipMemsetAsync(T + n, 0, padded - n, ctx->stream));
 
     // Wide alphabets: the induction visits the buckets one after the other, a few dependent launches per bucket
@@ -164,7 +169,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     }
 
     sx_text_info ti;
-    SX_TRY(sx_classify(ctx, T, n, an, ti));
+    SX_TRY(sx_classify(ctx, T, n, an, ti, src_tiles ? d_text : nullptr, src_tiles));
     if (ti.maxc >= sigma) return sx_fail_msg(ctx, SX_E_ARG, "text holds a symbol >= alphabet_size");
     ctx->stats.n_lms = ti.m;
 

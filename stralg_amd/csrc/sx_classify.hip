@@ -64,9 +64,13 @@ __device__ __forceinline__ void decided_masks(const uint32_t (&c)[17], uint64_t 
 // ---- pass 1: type of each tile's first position, if the tile decides it -------
 // One wave per tile, 1024 positions a step: almost every tile decides in its first few symbols, so the wave
 // stops after the first step and three quarters of the text are not read by this pass.
-__global__ __launch_bounds__(kWave) void cls_first_kernel(const uint8_t *__restrict__ T, uint64_t n,
-                                                          uint8_t *__restrict__ tile_first, uint32_t *__restrict__ open_tiles)
+// (src / src_tiles: the first src_tiles tiles are read from the caller's text, which the build has not copied yet -- see
+// cls_types_kernel; T holds the text's tail, the sentinel and the padding from the start)
+__global__ __launch_bounds__(kWave) void cls_first_kernel(const uint8_t *__restrict__ Tcopy, uint64_t n,
+                                                          uint8_t *__restrict__ tile_first, uint32_t *__restrict__ open_tiles,
+                                                          const uint8_t *__restrict__ src, uint32_t src_tiles)
 {
+    const uint8_t *__restrict__ T = blockIdx.x < src_tiles ? src : Tcopy;
     const int lane = lane_id();
     for (uint32_t seg = 0; seg < (uint32_t)kClsTile / (kWave * kClsPerThread); ++seg) {
         const uint64_t p0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)seg * (kWave * kClsPerThread) +
@@ -198,10 +202,14 @@ __device__ __forceinline__ uint32_t carry_from_right(bool has, uint32_t first_va
 //    the 16-bit "is symbol a" masks are one bit operation each, and the counts are popcounts of those masks
 //    (and of their intersections with the type masks) that accumulate in registers over all the tiles a
 //    workgroup walks; they are reduced over the wave once, at the end.
+// The build works on a copy of the text with the sentinel and 16-byte-load padding behind it.  Copying 1 GiB is
+// 0.38 ms of a 23 ms build, and this kernel reads every byte of the text anyway while it waits for its vector
+// unit: it reads the first src_tiles tiles (all but the text's last 32 bytes or so) from the caller's buffer and
+// stores them into the copy as it goes; only the tail was copied beforehand.  (src == nullptr: T is complete.)
 __global__ __launch_bounds__(kBlock) void cls_types_kernel(
-    const uint8_t *__restrict__ T, uint64_t n, const uint8_t *__restrict__ tile_first, uint32_t ntiles,
+    uint8_t *__restrict__ T, uint64_t n, const uint8_t *__restrict__ tile_first, uint32_t ntiles,
     uint16_t *__restrict__ lmsbits, uint32_t *__restrict__ tile_lms, uint32_t *__restrict__ tile_last,
-    uint32_t *__restrict__ g_hist /* 3 * 256 */)
+    uint32_t *__restrict__ g_hist /* 3 * 256 */, const uint8_t *__restrict__ src, uint32_t src_tiles)
 {
     __shared__ uint32_t h[3][256];
     __shared__ uint32_t lds[2 * kWavesPerBlock];
@@ -220,8 +228,10 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform
         const uint64_t tile0 = (uint64_t)tile * kClsTile;
         const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
-        const uint4 v = *reinterpret_cast<const uint4 *>(T + p0);
-        const uint32_t w[5] = {v.x, v.y, v.z, v.w, (uint32_t)T[p0 + 16]};
+        const uint8_t *__restrict__ S = tile < src_tiles ? src : T; // (uniform per workgroup and tile)
+        const uint4 v = *reinterpret_cast<const uint4 *>(S + p0);
+        const uint32_t w[5] = {v.x, v.y, v.z, v.w, (uint32_t)S[p0 + 16]};
+        if (tile < src_tiles) *reinterpret_cast<uint4 *>(T + p0) = v; // the copy the rest of the build reads
         const bool inside = p0 + 16 <= n; // everywhere but at the very end of the text
         uint32_t dmask, vmask;
         if (inside) {
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
         } else if (tile0 == 0) {
             prev_s = 1; // position 0 is never LMS
         } else {
-            const uint32_t a = T[tile0 - 1], b = w[0] & 0xFFu;
+            const uint32_t a = (tile - 1 < src_tiles ? src : T)[tile0 - 1], b = w[0] & 0xFFu; // (the copy of the tile before may not be written yet)
             prev_s = a < b ? 1u : (a > b ? 0u : (smask & 1u));
         }
         // LMS: S-type whose left neighbour is L-type (sa_is.c:155-162)
@@ -498,7 +508,7 @@ int sx_symbol_histogram(sx_ctx *ctx, const uint8_t *T, uint64_t n, uint32_t *d_s
     return sx_readback(ctx, d_scratch256, 256, h_out);
 }
 
-int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti)
+int sx_classify(sx_ctx *ctx, uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti, const uint8_t *src, uint32_t src_tiles)
 {
     ti.T = T;
     ti.n = n;
@@ -515,11 +525,12 @@ int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_t
     uint32_t *tile_lms = ti.tile_u32, *tile_last = ti.tile_u32 + ti.ntiles;
     SX_CHECK(hipMemsetAsync(ti.d_hist, 0, (3 * 256 + 1) * sizeof(uint32_t), ctx->stream));
     const dim3 grid(ti.ntiles), block(kBlock);
-    sx_launch(ctx, SX_KC_CLASSIFY, ti.N / 4, cls_first_kernel, grid, dim3(kWave), T, n, ti.tile_first, ti.d_hist + 3 * 256);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N / 4, cls_first_kernel, grid, dim3(kWave), (const uint8_t *)T, n, ti.tile_first, ti.d_hist + 3 * 256, src, src_tiles);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.ntiles, cls_resolve_kernel, dim3(sx_div_up(ti.ntiles, kBlock * 16)), block, ti.tile_first,
               ti.ntiles);
-    sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8, cls_types_kernel, dim3(ti.ntiles < 2048 ? ti.ntiles : 2048), block, T, n,
-              (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms, tile_last, ti.d_hist);
+    sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8 + (src ? (uint64_t)src_tiles * kClsTile : 0), cls_types_kernel,
+              dim3(ti.ntiles < 2048 ? ti.ntiles : 2048), block, T, n, (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms,
+              tile_last, ti.d_hist, src, src_tiles);
     // read the three histograms back: the host drives the bucket loop
     uint32_t h[3 * 256 + 1];
     SX_TRY(sx_readback(ctx, ti.d_hist, 3 * 256 + 1, h));

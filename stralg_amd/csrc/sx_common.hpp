@@ -80,6 +80,7 @@ struct sx_ctx {
     int sort_mode = 0;        // SX_FLAG_SORT_MODE
     int induce_batch_off = 0; // SX_FLAG_INDUCE_BATCH_OFF
     int induce_attended = 0;  // SX_FLAG_INDUCE_ATTENDED
+    int copy_text_first = 0;  // SX_FLAG_COPY_TEXT_FIRST
     int64_t induce_batch_min = -1; // SX_FLAG_INDUCE_BATCH_MIN; -1 = ranges the tail kernel holds pass the batch form by
     int prof_on = 0;
     int prof_only = -1; // >= 0: only launches of this kernel class are bracketed with events

@@ -270,6 +270,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
         ctx->induce_batch_off = value ? 1 : 0;
         return 0;
     }
+    if (flag == SX_FLAG_COPY_TEXT_FIRST) {
+        ctx->copy_text_first = value ? 1 : 0;
+        return 0;
+    }
     if (flag == SX_FLAG_INDUCE_ATTENDED) {
         if (value < 0 || value > 2) return SX_E_ARG;
         ctx->induce_attended = value;

@@ -37,8 +37,11 @@ struct sx_text_info {
 size_t sx_text_scratch_bytes(uint64_t n);
 // symbol counts of T[0..n) (the sentinel at n is not counted); d_scratch256: 256 u32 of device scratch
 int sx_symbol_histogram(sx_ctx *ctx, const uint8_t *T, uint64_t n, uint32_t *d_scratch256, uint32_t h_out[256]);
-// carve the per-text scratch out of `arena`, run classification, read the histograms back
-int sx_classify(sx_ctx *ctx, const uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti);
+// carve the per-text scratch out of `arena`, run classification, read the histograms back.  src / src_tiles: the first
+// src_tiles classification tiles of T have not been copied from the caller's text `src` yet (16-byte aligned): the
+// classification reads them there and writes them into T as it goes (sx_classify.hip: cls_types_kernel)
+int sx_classify(sx_ctx *ctx, uint8_t *T, uint64_t n, sx_arena &arena, sx_text_info &ti, const uint8_t *src = nullptr,
+                uint32_t src_tiles = 0);
 // sample flags for piece width W (symbols between consecutive samples <= W); sets ti.M
 int sx_sample_flags(sx_ctx *ctx, sx_text_info &ti, uint32_t W);
 // compaction of the sample positions; pos[M], is_lms[M]

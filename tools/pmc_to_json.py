@@ -15,6 +15,8 @@ from collections import defaultdict
 CLASS_OF = [
     ("radix_scatter_kernel", "radix_scatter"), ("radix_hist_kernel", "radix_hist"),
     ("induce_scatter_kernel", "induce_scatter"), ("induce_scatter_small_kernel", "induce_scatter"), ("induce_count_kernel", "induce_gather"),
+    ("induce_batch_scatter_kernel", "induce_scatter"), ("induce_batch_count_kernel", "induce_gather"), ("induce_batch_offsets_kernel", "induce_scan"),
+    ("induce_wide_scatter_kernel", "induce_scatter"), ("induce_wide_count_kernel", "induce_gather"), ("induce_wide_", "induce_scan"),
     ("fill_windows_kernel", "induce_gather"), ("induce_offsets_kernel", "induce_scan"),
     ("induce_round_kernel", "induce_chain"), ("otable_", "otable"), ("bwt_", "bwt_gather"),
     ("cls_", "classify"), ("samp_", "samples"), ("lms_prefix_keys", "keys"), ("lms_tile_keys", "keys"), ("radix_colsum", "scan"), ("radix_bases", "scan"), ("radix_apply", "scan"), ("piece_keys", "keys"),
