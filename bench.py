@@ -55,6 +55,8 @@ def parse_args(argv=None):
                     help="induce rounds of up to this many entries take the single chained launch (default: by alphabet size)")
     ap.add_argument("--no-induce-batch", action="store_true",
                     help="induced-sort passes: every self round of a bucket as a launch of its own (no eight-rounds-at-a-time form)")
+    ap.add_argument("--induce-attended", action="store_true",
+                    help="induced-sort passes: the host reads every bucket's last range back before it queues the next bucket (A/B)")
     ap.add_argument("--copy-text-first", action="store_true", help="the build copies the text before the classification (A/B)")
     ap.add_argument("--cpu-log2n", type=int, default=int(os.environ.get("STRALG_BENCH_CPU_LOG2N", "25")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
@@ -407,6 +409,8 @@ def run_rank(args):
         ctx.set_induce_batch(False)
     if args.copy_text_first:
         ctx.set_copy_text_first(True)
+    if args.induce_attended:
+        ctx.set_induce_attended(1)
     # host work of a rank (staging copies, page faults of pinned and malloc'd buffers) next to its GPU's PCIe root
     numa_node = ctx.bind_to_numa_node()
     if world > 1:

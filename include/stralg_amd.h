@@ -83,8 +83,8 @@ typedef struct sx_build_stats {
                                 general path: bit 2: some round ordered small groups by one wave each, bit 3: some round sent
                                 members through radix sorts */
     double ms_total;         /* wall time of the last build on the device stream */
-    uint32_t induce_redo;    /* induced-sort passes run a second time, bucket by bucket with the host looking at every bucket's
-                                last range: the first, unattended run left a bucket short (runs longer than its rounds reach) */
+    uint32_t induce_redo;    /* buckets of the induced-sort passes whose rounds the queued launches did not finish (runs longer than
+                                the tail kernel's steps reach, more entries alive than it holds): the host carried them on */
     uint32_t long_runs;      /* the classification saw a run that fills a 4096-symbol tile: the passes are attended from the start */
 } sx_build_stats;
 
@@ -111,10 +111,10 @@ enum {
                                        its own (no eight-rounds-at-a-time form) */
     SX_FLAG_INDUCE_BATCH_MIN = 8,   /* ranges longer than this many entries take the eight-rounds-at-a-time form (negative: the
                                        default, what the one-workgroup tail kernel holds; tests set 0) */
-    SX_FLAG_INDUCE_ATTENDED = 9     /* 0 (default) = alphabets of more than 8 symbols queue an induced-sort pass as a whole and check
-                                       the bucket cursors at its end (a pass that left a bucket short is run again attended),
-                                       smaller ones are attended: the host reads every bucket's last range back before it queues
-                                       the next bucket; 1 = always attended; 2 = never, whatever the alphabet (tests) */
+    SX_FLAG_INDUCE_ATTENDED = 9     /* 0 (default) = the buckets of an induced-sort pass are queued one behind the other; a bucket
+                                       whose rounds the tail kernel could not finish leaves word, the launches behind it do nothing,
+                                       and the host carries that bucket on before it queues the rest; 1 = attended: the host reads
+                                       every bucket's last range back before it queues the next bucket (rounds 1 and 2) */
     ,SX_FLAG_COPY_TEXT_FIRST = 10   /* 1 = the build's padded copy of the text is made by a device copy before the classification
                                        (rounds 1 and 2); 0 = the classification writes it while it reads the caller's text */
 };

@@ -236,8 +236,8 @@ class Context:
         self._check(self.lib.sx_ctx_set_flag(self.h, 8, int(entries)), "sx_ctx_set_flag")
 
     def set_induce_attended(self, mode=1):
-        """SX_FLAG_INDUCE_ATTENDED: 0 default (wide alphabets queue a pass as a whole), 1 the host looks at every
-        bucket's last range, 2 never (any alphabet)"""
+        """SX_FLAG_INDUCE_ATTENDED: 0 default (buckets queued one behind the other, a bucket the tail kernel could not
+        finish is carried on by the host), 1 the host looks at every bucket's last range"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 9, int(mode)), "sx_ctx_set_flag")
 
     def set_copy_text_first(self, on=True):

@@ -276,7 +276,7 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     }
     if (flag == SX_FLAG_INDUCE_ATTENDED) {
         if (value < 0 || value > 2) return SX_E_ARG;
-        ctx->induce_attended = value;
+        ctx->induce_attended = value == 1 ? 1 : 0; // (2: what 0 is now)
         return 0;
     }
     if (flag == SX_FLAG_INDUCE_BATCH_MIN) {

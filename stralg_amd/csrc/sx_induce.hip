@@ -43,6 +43,7 @@ constexpr int kTailTile = kTailBlock * kIndItems;
 constexpr uint32_t kTailEntries = (uint32_t)kTailTile;
 
 enum { MODE_L_FROM_L = 0, MODE_L_FROM_LMS = 1, MODE_S_FROM_S = 2, MODE_S_FROM_L = 3 };
+__device__ __forceinline__ void tail_report(uint32_t lo, uint32_t hi, uint32_t c, uint32_t *poison, uint32_t *host_poison);
 
 __device__ __forceinline__ bool induce_accept(uint32_t ch, uint32_t c, int mode)
 {
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                                                              uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
                                                              const uint32_t *__restrict__ cursor_cur,
                                                              uint32_t *__restrict__ cursor_nxt, int dir,
-                                                             uint32_t max_iters)
+                                                             uint32_t max_iters, uint32_t *poison, uint32_t *host_poison)
 {
     constexpr int kDigits = BITS == 3 ? 8 : 256; // buckets that can receive anything
     __shared__ uint32_t wcount[kTailWaves][kDigits];
@@ -1070,6 +1071,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
     if (t == 0) {
         range_out[0] = s_range[0];
         range_out[1] = s_range[1];
+        tail_report(s_range[0], s_range[1], c, poison, host_poison);
     }
 }
 
@@ -1091,7 +1093,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
                                                                        uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
                                                                        const uint32_t *__restrict__ cursor_cur,
                                                                        uint32_t *__restrict__ cursor_nxt, int dir,
-                                                                       uint32_t max_iters)
+                                                                       uint32_t max_iters, uint32_t *poison, uint32_t *host_poison)
 {
     constexpr uint64_t kField16 = 0x00FF00FF00FF00FFull;
     __shared__ uint64_t wsum[kTailBatch][2][kTailWaves];  // per round and half (even / odd buckets): the waves' totals, then their prefix
@@ -1325,6 +1327,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
     if (t == 0) {
         range_out[0] = s_range[0];
         range_out[1] = s_range[1];
+        tail_report(s_range[0], s_range[1], c, poison, host_poison);
     }
 }
 
@@ -1700,16 +1703,30 @@ __global__ void run_commit_kernel(uint32_t *__restrict__ range, uint32_t *__rest
 
 // range <- [lo, hi) given by the host, or [a, cursor[c]) / [cursor[c], b) for the first round of a bucket
 // (and the tickets of the chained launches that follow are zeroed: one launch instead of a memset and a launch)
+// (poison: a bucket earlier in this unattended pass did not come to its end -- see induce_typed --: the range is left
+//  empty, and every launch over an empty range only carries the cursors on)
 __global__ void set_range_kernel(uint32_t *range, uint32_t lo, uint32_t hi, const uint32_t *cursor, int c, int which,
-                                 uint32_t *tickets, uint32_t ntickets)
+                                 uint32_t *tickets, uint32_t ntickets, const uint32_t *poison)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (uint32_t i = 0; i < ntickets; ++i) tickets[i] = 0;
         if (which == 1) hi = cursor[c];      // L pass: [bucket begin, head cursor)
         else if (which == 2) lo = cursor[c]; // S pass: [tail cursor, bucket end)
+        if (poison && poison[0]) lo = hi = 0;
         range[0] = lo;
         range[1] = hi;
     }
+}
+
+// the tail kernel's last word in an unattended pass: a range it could not finish (runs longer than its steps, or more
+// entries than it holds) is recorded once -- bucket and range, on the device and in the host's pinned page -- and
+// stops the rest of the pass (set_range_kernel)
+__device__ __forceinline__ void tail_report(uint32_t lo, uint32_t hi, uint32_t c, uint32_t *poison, uint32_t *host_poison)
+{
+    if (!poison || lo == hi || poison[0]) return;
+    poison[1] = c, poison[2] = lo, poison[3] = hi;
+    poison[0] = 1;
+    __hip_atomic_store(host_poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // bwt[i] = text[SA[i]-1]: the first symbol of slot i's window; the one slot whose entry is
@@ -1794,7 +1811,9 @@ template <class WT> struct induce_state {
     uint32_t *bhist;  // [round * 8 + bucket][stride] tile counts of the eight-rounds-at-a-time form
     uint32_t *btotals; // kBatchRows row totals
     int batch_on;
-    int unattended; // a pass is queued as a whole: no look at a bucket's last range (induce_typed checks the cursors at the pass's end)
+    int unattended; // the buckets are queued one behind the other without a look at a bucket's last range (see induce_typed)
+    uint32_t *poison;      // device: {set, bucket, lo, hi} of the first bucket an unattended pass could not finish
+    uint32_t *host_poison; // the same flag in the host's pinned page (the host looks at it between buckets, without a wait)
     uint32_t *whist;  // [tile][256] the same for wide alphabets, tiles of 8192 entries
     uint32_t *wsums;  // [chunk][256] column sums of chunks of 256 tiles
     uint32_t stride;
@@ -1903,11 +1922,13 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
     if (st.small_alphabet)
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_small_kernel<WT>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
-                  cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters);
+                  cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters, st.unattended ? st.poison : (uint32_t *)nullptr,
+                  st.host_poison);
     else
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
-                  cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters);
+                  cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters, st.unattended ? st.poison : (uint32_t *)nullptr,
+                  st.host_poison);
     st.par ^= 1;
 }
 
@@ -1950,7 +1971,8 @@ void launch_batch(induce_state<WT> &st, int range_slot, int out_slot, uint32_t t
 // host look per batch
 template <class WT>
 int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_entries, int rev, int mode, uint32_t c,
-                    int dir, int which, uint32_t *total_in_region, double share /* of symbol c in the text */)
+                    int dir, int which, uint32_t *total_in_region, double share /* of symbol c in the text */,
+                    const uint32_t *resume = nullptr /* {lo, hi}: the range an unattended pass left of this region: carry on from it */)
 {
     sx_ctx *ctx = st.ctx;
     bool first = true;
@@ -1975,11 +1997,16 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
     // consumes one symbol of every run it follows: a bucket cannot need more batches than this (a device fault that
     // keeps the range alive must not keep the host here for ever).
     const uint64_t max_batches = 2 * (st.N / kTailIters) + 64; // (rounds too long for the tail consume > 8192 symbols each)
+    uint32_t r[2] = {0, 0};
+    bool resuming = resume != nullptr;
+    if (resuming) r[0] = resume[0], r[1] = resume[1];
     for (uint64_t batch = 0;; ++batch) {
         if (batch > max_batches) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: the rounds of a bucket did not come to an end");
+        if (!resuming) {
         if (first)
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
-                      (const uint32_t *)st.cursor[st.par], (int)c, which, st.tickets, (uint32_t)(kMaxSpec + 2));
+                      (const uint32_t *)st.cursor[st.par], (int)c, which, st.tickets, (uint32_t)(kMaxSpec + 2),
+                      (const uint32_t *)(st.unattended ? st.poison : nullptr));
         else
             SX_CHECK(hipMemsetAsync(st.tickets, 0, (kMaxSpec + 2) * sizeof(uint32_t), ctx->stream));
         const bool batched = st.small_alphabet && st.batch_on && (mode == MODE_L_FROM_L || mode == MODE_S_FROM_S);
@@ -2025,19 +2052,20 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
             launch_round<WT>(st, st.SA, st.WN, k, k + 1, tb, first && k == 0 ? bound_tiles : likely, rev, mode, c, dir, 1, 0, sure ? 1 : 0);
         }
         launch_tail<WT>(st, spec, spec + 1, rev, mode, c, dir);
-        if (st.unattended) { // the tail kernel ends nearly every bucket; one that it does not shows in the cursors at the pass's end
+        if (st.unattended) { // the tail kernel ends nearly every bucket; one that it does not leaves word (tail_report)
             if (total_in_region) *total_in_region = 0xFFFFFFFFu;
             return 0;
         }
-        uint32_t r[2];
         SX_TRY(sx_readback(ctx, st.ranges + 2 * (spec + 1), 2, r));
         if (r[1] == r[0]) {
             if (total_in_region) *total_in_region = dir > 0 ? r[1] : r[0];
             return 0;
         }
+        } // (!resuming)
+        resuming = false;
         // a long run of symbol c: carry on from the last range
         sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, r[0], r[1],
-                  (const uint32_t *)st.cursor[st.par], (int)c, 0, (uint32_t *)nullptr, 0u);
+                  (const uint32_t *)st.cursor[st.par], (int)c, 0, (uint32_t *)nullptr, 0u, (const uint32_t *)nullptr);
         if (r[1] - r[0] <= kRunEntries) {
             // a handful of entries deep inside runs: the device-wide jump, twice (a run may be longer than one probe looks)
             for (int rep = 0; rep < 2; ++rep) {
@@ -2139,12 +2167,19 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     // the sentinel suffix (sa_is.c:463: SA[0] = n)
     sx_launch(ctx, SX_KC_MISC, 0, set_entry_kernel<WT>, dim3(1), dim3(1), SA, st.WN, st.BW, (uint32_t)ti.n, ti.T, cfg);
 
-    // Both passes are queued as a whole, the host not waiting for any bucket (a wait is 20 - 30 us of idle device: 16 of
-    // them a build at 5 buckets, 1000 at 256): the tail kernel ends nearly every bucket's rounds on its own, and a bucket
-    // it leaves unfinished (runs of a symbol longer than its rounds and jumps reach) receives fewer suffixes than the
-    // classification counted -- every suffix is induced exactly once, so the cursors at the pass's end tell.  The pass is
-    // then run again attended: the host reads every bucket's last range back and carries long runs on (device-wide
-    // jumps).  Texts in which the classification saw a run fill a whole 4096-symbol tile are attended from the start.
+    // Unattended passes.  After a bucket's queued rounds the host used to read the bucket's last range back and wait
+    // (20 - 30 us of idle device: 16 times a build at 5 buckets, 1000 times at 256) -- almost always to learn that the tail
+    // kernel had finished the bucket.  Now the buckets are queued one behind the other.  A tail kernel that cannot finish
+    // its bucket (runs of a symbol longer than its steps and jumps reach, or more entries alive than it holds: thousands
+    // of poly-A tracts) leaves word: the bucket and its last range, on the device and in the host's pinned page
+    // (tail_report).  From then on every set_range_kernel leaves its range empty, and launches over an empty range only
+    // carry the cursors on -- the device's state stays what it was when the bucket stopped.  The host looks at the
+    // pinned word between buckets (a plain load, no wait), stops queuing, reads the record, carries that bucket on
+    // attended (read-backs, device-wide run jumps) and goes on unattended behind it.  Texts in which the classification
+    // saw a run fill a whole 4096-symbol tile are attended from the start.
+    st.poison = arena.take<uint32_t>(4);
+    if (!st.poison) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
+    st.host_poison = ctx->h_pin + 1040;
     auto cursors_as_counted = [&](bool &ok) -> int {
         uint32_t cur[256];
         SX_TRY(sx_readback(ctx, (const uint32_t *)st.cursor[st.par], nk, cur));
@@ -2155,21 +2190,27 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             if (ti.h_all[c] && cur[c] != begin[c] + ti.h_l[c]) ok = false;
         return 0;
     };
-    // ---- L pass: buckets ascending, cursors at the bucket heads ------------------------
-    auto pass_L = [&](bool unattended) -> int {
-        st.unattended = unattended ? 1 : 0;
-        SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        for (uint32_t c = 0; c < nk; ++c) {
+    const bool unattended_ok = ctx->induce_attended != 1 && ti.open_tiles == 0;
+    auto stopped = [&]() -> bool { return st.unattended && *(volatile uint32_t *)st.host_poison != 0; };
+    // ---- L pass: buckets ascending, cursors at the bucket heads; from bucket `from` on (resume: that bucket's L region
+    // carries on from the range an unattended run left)
+    auto pass_L = [&](uint32_t from, const uint32_t *resume) -> int {
+        for (uint32_t c = from; c < nk; ++c) {
             if (ti.h_all[c] == 0) continue;
+            if (stopped()) return 0;
+            const bool carry_on = resume && c == from;
             if (ti.h_l[c]) {
                 uint32_t head_end = 0;
-                SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end, (double)ti.h_all[c] / (double)N));
-                if (!unattended && head_end - begin[c] != ti.h_l[c])
+                st.unattended = (unattended_ok && !carry_on) ? 1 : 0;
+                SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end, (double)ti.h_all[c] / (double)N,
+                                           carry_on ? resume : nullptr));
+                if (!st.unattended && head_end - begin[c] != ti.h_l[c])
                     return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
+                st.unattended = unattended_ok ? 1 : 0;
             }
             if (ti.h_lms[c]) {
                 sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
-                          (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u);
+                          (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u, (const uint32_t *)(st.unattended ? st.poison : nullptr));
                 // (the round's size is known: the one form that takes it, and no launch that finds nothing to do)
                 launch_round<WT>(st, sorted_lms, seedW, 0, -1, sx_div_up(ti.h_lms[c], kIndTile), sx_div_up(ti.h_lms[c], kIndTile), 0,
                                  MODE_L_FROM_LMS, c, +1, 0, 0, ti.h_lms[c] > st.chain_max ? 1 : 0);
@@ -2178,23 +2219,26 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         return 0;
     };
     // ---- S pass: buckets descending, cursors at the bucket ends -------------------------
-    auto pass_S = [&](bool unattended) -> int {
-        st.unattended = unattended ? 1 : 0;
-        SX_CHECK(hipStreamSynchronize(ctx->stream)); // (the upload source of the pass before may still be in use)
-        SX_CHECK(hipMemcpyAsync(st.cursor[st.par], begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        for (uint32_t cc = nk; cc-- > 0;) {
+    auto pass_S = [&](uint32_t from, const uint32_t *resume) -> int {
+        for (uint32_t cc = from + 1; cc-- > 0;) {
             const uint32_t c = cc;
             if (ti.h_all[c] == 0) continue;
+            if (stopped()) return 0;
+            const bool carry_on = resume && c == from;
             const uint32_t n_s = ti.h_all[c] - ti.h_l[c];
             if (c > 0 && n_s) {
                 uint32_t tail_end = 0;
-                SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end, (double)ti.h_all[c] / (double)N));
-                if (!unattended && begin[c + 1] - tail_end != n_s)
+                st.unattended = (unattended_ok && !carry_on) ? 1 : 0;
+                SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end, (double)ti.h_all[c] / (double)N,
+                                           carry_on ? resume : nullptr));
+                if (!st.unattended && begin[c + 1] - tail_end != n_s)
                     return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
+                st.unattended = unattended_ok ? 1 : 0;
             }
             if (ti.h_l[c]) {
                 sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
-                          begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u);
+                          begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u,
+                          (const uint32_t *)(st.unattended ? st.poison : nullptr));
                 launch_round<WT>(st, SA, st.WN, 0, -1, sx_div_up(ti.h_l[c], kIndTile), sx_div_up(ti.h_l[c], kIndTile), 1,
                                  MODE_S_FROM_L, c, -1, 0, 0, ti.h_l[c] > st.chain_max ? 1 : 0);
             }
@@ -2202,23 +2246,31 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         return 0;
     };
     ctx->stats.long_runs = ti.open_tiles ? 1u : 0u;
-    // (At most 8 buckets: attended.  There the waits are 16 a build, and what the tail kernel cannot hold is common in
-    //  real texts -- thousands of poly-A tracts and microsatellites alive in one bucket after the queued rounds --, which
-    //  would cost the pass a second run.  SX_FLAG_INDUCE_ATTENDED 2 lets the tests run such texts unattended.)
-    const bool unattended = ctx->induce_attended != 1 && ti.open_tiles == 0 && (!st.small_alphabet || ctx->induce_attended == 2);
     for (int pass = 0; pass < 2; ++pass) {
+        st.unattended = unattended_ok ? 1 : 0;
+        if (pass == 1) SX_CHECK(hipStreamSynchronize(ctx->stream)); // (`begin`, the L pass's upload source, may still be in use)
+        SX_CHECK(hipMemcpyAsync(st.cursor[st.par], pass == 0 ? begin : begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        uint32_t from = pass == 0 ? 0u : nk - 1u, rec[4] = {0, 0, 0, 0};
+        const uint32_t *resume = nullptr;
+        for (uint32_t attempt = 0;; ++attempt) {
+            if (attempt > 2 * nk + 4) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a pass did not come to its end");
+            if (unattended_ok) {
+                *(volatile uint32_t *)st.host_poison = 0;
+                SX_CHECK(hipMemsetAsync(st.poison, 0, 4 * sizeof(uint32_t), ctx->stream));
+            }
+            SX_TRY(pass == 0 ? pass_L(from, resume) : pass_S(from, resume));
+            if (!unattended_ok) break;
+            SX_TRY(sx_readback(ctx, (const uint32_t *)st.poison, 4, rec));
+            if (!rec[0]) break;
+            // bucket rec[1] stopped with the range [rec[2], rec[3]) alive: carry it on attended, then the buckets behind it
+            ctx->stats.induce_redo++;
+            from = rec[1];
+            resume = rec + 2;
+        }
         bool ok = false;
-        if (unattended) {
-            SX_TRY(pass == 0 ? pass_L(true) : pass_S(true));
-            SX_TRY(cursors_as_counted(ok));
-            if (!ok) ctx->stats.induce_redo++;
-        }
-        if (!ok) {
-            SX_TRY(pass == 0 ? pass_L(false) : pass_S(false));
-            SX_TRY(cursors_as_counted(ok));
-            if (!ok) return sx_fail_msg(ctx, SX_E_INTERNAL, pass == 0 ? "induce L: a bucket did not receive its L-type count"
-                                                                        : "induce S: a bucket did not receive its S-type count");
-        }
+        SX_TRY(cursors_as_counted(ok));
+        if (!ok) return sx_fail_msg(ctx, SX_E_INTERNAL, pass == 0 ? "induce L: a bucket did not receive its L-type count"
+                                                                    : "induce S: a bucket did not receive its S-type count");
     }
 
     {

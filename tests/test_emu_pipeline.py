@@ -409,8 +409,8 @@ def test_production_genome_through_the_farm(emu_ctx, golden_genomes, tmp_path):
 def test_induce_round_batches_and_unattended_passes(emu_ctx):
     """round 3's forms of the induced-sort passes, forced onto small texts: eight self rounds of a bucket by one count /
     scan / scatter (SX_FLAG_INDUCE_BATCH_MIN), rounds queued in the three-launch form alone, the wide scatter's two steps
-    a tile, passes queued as a whole with the cursor check at their end (SX_FLAG_INDUCE_ATTENDED), and the second,
-    attended run of a pass that left a bucket short; against the oracle"""
+    a tile, buckets queued one behind the other without a wait (SX_FLAG_INDUCE_ATTENDED), and the host carrying on a
+    bucket whose tail kernel left word that it could not finish it; against the oracle"""
     rng = np.random.default_rng(31)
     # (the AddressSanitizer run of this file, tests/test_emu_asan.py, takes the small cases only)
     full = os.environ.get("STRALG_EMU_ASAN") != "1"
@@ -451,12 +451,18 @@ def test_induce_round_batches_and_unattended_passes(emu_ctx):
         assert check(x, 20)["long_runs"] == 1
         emu_ctx.set_no_direct_sort(False)
         # 9000 runs of 20 symbols alive in one bucket: more than the tail kernel holds after the queued rounds, so the
-        # unattended pass leaves the bucket short, the cursors tell, and the pass runs again attended
+        # tail kernel leaves word, the launches behind it do nothing, and the host carries the bucket on (both alphabets'
+        # kernels); attended, the same text needs no such thing
         unit = np.array([1] * 20 + [2, 3], np.uint8)
         x = np.tile(unit, 9000)
         x[21::22] = rng.integers(2, 5, size=9000, dtype=np.uint8)
-        emu_ctx.set_induce_attended(2)
         assert check(x, 5)["induce_redo"] >= 1
+        if full:
+            y = x.copy()
+            y[21::22] = rng.integers(2, 30, size=9000, dtype=np.uint8)
+            emu_ctx.set_no_direct_sort(True)
+            assert check(y, 30)["induce_redo"] >= 1
+            emu_ctx.set_no_direct_sort(False)
         check(synth(9000, 5, 11), 5)
         emu_ctx.set_induce_attended(1)
         assert check(x, 5)["induce_redo"] == 0
