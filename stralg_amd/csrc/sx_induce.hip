@@ -430,8 +430,12 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
 // bucket's run leaves as a contiguous block.  (The kernels above -- 2048-entry tiles, a bucket-major table read with
 // a 64-byte sector per count, one look-back thread per bucket and tile -- took 92 of 142 ms of a 1 GiB text of 255
 // symbols, whose buckets of 2 M entries they visit one after the other: 50 MB moved in 100 us and more.)
-constexpr int kWideThreads = 512, kWideWaves = kWideThreads / kWave, kWideItems = 16;
-constexpr int kWideTile = kWideThreads * kWideItems; // 8192 entries
+#ifndef SX_WIDE_ITEMS
+#define SX_WIDE_ITEMS 16 // entries a thread and tile: 8192-entry tiles, taken in two steps by the scatter (8: 4096-entry tiles --
+                         // 1 GiB of bytes 100 against 102 ms, but 12 symbols 53.4 against 49.9: long rounds want the larger tile)
+#endif
+constexpr int kWideThreads = 512, kWideWaves = kWideThreads / kWave, kWideItems = SX_WIDE_ITEMS;
+constexpr int kWideTile = kWideThreads * kWideItems;
 constexpr uint32_t kWideChunk = 256;                  // tiles per chunk of the column sums (long rounds)
 
 template <class WT>
@@ -1778,7 +1782,7 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
 {
     // windows for every SA slot (8 bytes worst case) + seed windows (N/2) + symbol bytes + control block
     const uint64_t ntiles = (N + kIndTile - 1) / kIndTile + 1;
-    const uint64_t wtiles = N / 8192 + 4; // wide alphabets: [tile][256] counts of 8192-entry tiles + chunk sums
+    const uint64_t wtiles = N / 4096 + 4; // wide alphabets: [tile][256] counts of (at least) 4096-entry tiles + chunk sums
     // (at most 8 buckets: (round, bucket) count rows of the eight-rounds-at-a-time form, over the largest bucket's tiles)
     return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 +
            (size_t)kBatchRows * (ntiles + 1) * 4 + 1024 +

@@ -53,12 +53,19 @@ for k in range(cases):
     ctx.force_general_path(flag == 1)
     ctx.set_no_direct_sort(flag == 2)
     ctx.set_prefix_symbols(int(rng.choice([0, 0, 0, 12, 14, 15, 16, 17, 18, 19, 23])))  # the key kernel's static forms too
+    # round 3's forms of the induced-sort passes: eight rounds at a time from ranges of any length on, every self round a
+    # launch of its own, the host looking at every bucket or queuing them one behind the other, the text copied first or
+    # by the classification
+    ctx.set_induce_batch_min(int(rng.choice([-1, -1, 0, 100, 3000])))
+    ctx.set_induce_batch(bool(rng.integers(0, 5)))
+    ctx.set_induce_attended(int(rng.choice([0, 0, 1])))
+    ctx.set_copy_text_first(bool(rng.integers(0, 4) == 0))
     # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
     want = oracle.sa_is_strict(x, sigma) if sigma == n + 1 else oracle.sa_is(x, sigma)
     sa = np.zeros(n + 1, np.uint32)
     got = ctx.sa_build(x, sigma)
     st = ctx.last_stats()
-    pk = (st["lms_path"], st["sort_local"], st["refine_tiers"])
+    pk = (st["lms_path"], st["sort_local"], st["refine_tiers"], min(st["induce_redo"], 1), st["long_runs"])
     paths[pk] = paths.get(pk, 0) + 1
     assert (got == want).all(), ("SA", k, sigma, n, kind, flag)
     if sigma <= 128 and n < 70000:
@@ -70,4 +77,5 @@ for k in range(cases):
         assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
 ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(-1); ctx.set_prefix_symbols(0)
 ctx.set_sort_mode(0); ctx.set_radix_digit_bits(0)
+ctx.set_induce_batch_min(-1); ctx.set_induce_batch(True); ctx.set_induce_attended(0); ctx.set_copy_text_first(False)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
