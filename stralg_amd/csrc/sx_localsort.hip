@@ -32,15 +32,10 @@ constexpr int kLsCap = kLsThreads * kLsItems; // pairs a workgroup can hold: 614
 #define SX_LS_SPAN 5120
 #endif
 constexpr int kLsSpan = SX_LS_SPAN;           // a workgroup owns the sub-buckets that start in its span of the array
-#ifndef SX_LS_FIRST
-#define SX_LS_FIRST 12
-#endif
-constexpr int kLsFirstItems = SX_LS_FIRST;    // loaded at once (all of the reach now; a smaller first load is followed by the rest only when needed)
 constexpr int kLsWords = kLsCap / 32;
 constexpr int kLsBins = 8192;  // bins of the counting pass: 16 KiB of packed 16-bit counters in the (then unused) key image
 constexpr int kLsMaxBin = 16;  // a bin with more pairs than this: stable passes instead (equal keys crowd one bin)
 static_assert(kLsBins / 2 % kLsThreads == 0 && (kLsBins / 2 + 1) * 8 <= kLsCap * 8, "counter words per thread; both counter sets fit the key image");
-static_assert(kLsThreads * kLsFirstItems >= kLsSpan && kLsFirstItems <= kLsItems, "first load covers the span");
 
 // One workgroup: local indices i = global index - g0, g0 = blockIdx.x * kLsSpan.
 //   s = first sub-bucket start at i >= 0, e = first sub-bucket start (or the end of the array) at i >= kLsSpan;
@@ -70,50 +65,38 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         s_kprev[0] = (uint32_t)kp, s_kprev[1] = (uint32_t)(kp >> 32);
     }
     for (int i = t; i < kLsWords; i += kLsThreads) bnd[i] = 0;
-    // ---- load the keys in reach (index order: coalesced), the part behind span + 1024 only if it is needed ----------
-    uint32_t loaded = avail < (uint32_t)(kLsThreads * kLsFirstItems) ? avail : (uint32_t)(kLsThreads * kLsFirstItems);
+    // ---- load the keys in reach (index order: coalesced) ------------------------------------------------------------------
     {
         // (all loads of a thread in flight together: keys and positions of the whole reach, not only of the range the
-        // workgroup turns out to own -- a loop over that range would wait for every load before issuing the next)
-        uint64_t kk[kLsFirstItems];
-        uint32_t vv[kLsFirstItems];
+        // workgroup turns out to own -- a loop over that range would wait for every load before issuing the next; a
+        // smaller first load followed by the rest only when a sub-bucket crossed the span's end was no faster)
+        uint64_t kk[kLsItems];
+        uint32_t vv[kLsItems];
 #pragma unroll
-        for (int k = 0; k < kLsFirstItems; ++k) {
+        for (int k = 0; k < kLsItems; ++k) {
             const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
-            kk[k] = i < loaded ? __builtin_nontemporal_load(kin + g0 + i) : 0ull;
-            vv[k] = i < loaded ? __builtin_nontemporal_load(vin + g0 + i) : 0u;
+            kk[k] = i < avail ? __builtin_nontemporal_load(kin + g0 + i) : 0ull;
+            vv[k] = i < avail ? __builtin_nontemporal_load(vin + g0 + i) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < kLsFirstItems; ++k) {
+        for (int k = 0; k < kLsItems; ++k) {
             const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
-            if (i < loaded) K[i] = kk[k], V[i] = vv[k];
+            if (i < avail) K[i] = kk[k], V[i] = vv[k];
         }
     }
     __syncthreads();
     const uint64_t kprev = pack64(s_kprev[0], s_kprev[1]);
-    uint32_t from = 0;
-    for (int part = 0; part < 2; ++part) { // uniform
-        // sub-bucket starts among the keys loaded in this part
-        for (uint32_t i = from + (uint32_t)t; i < loaded; i += kLsThreads) {
-            const uint64_t idc = (K[i] & kmask) >> L;
-            const bool start = i == 0 ? (g0 == 0 || ((kprev & kmask) >> L) != idc) : ((K[i - 1] & kmask) >> L) != idc;
-            if (start) {
-                atomicOr(&bnd[i >> 5], 1u << (i & 31u));
-                if (i < (uint32_t)kLsSpan) atomicMin(&s_first, i);
-                else atomicMin(&s_end, i);
-            }
+    // sub-bucket starts among the keys in reach
+    for (uint32_t i = (uint32_t)t; i < avail; i += kLsThreads) {
+        const uint64_t idc = (K[i] & kmask) >> L;
+        const bool start = i == 0 ? (g0 == 0 || ((kprev & kmask) >> L) != idc) : ((K[i - 1] & kmask) >> L) != idc;
+        if (start) {
+            atomicOr(&bnd[i >> 5], 1u << (i & 31u));
+            if (i < (uint32_t)kLsSpan) atomicMin(&s_first, i);
+            else atomicMin(&s_end, i);
         }
-        __syncthreads();
-        if (part == 1 || s_end != kNone || loaded == avail) break; // uniform
-        from = loaded;
-#pragma unroll
-        for (int k = kLsFirstItems; k < kLsItems; ++k) {
-            const uint32_t i = (uint32_t)t + (uint32_t)k * kLsThreads;
-            if (i < avail) K[i] = kin[g0 + i], V[i] = vin[g0 + i];
-        }
-        loaded = avail;
-        __syncthreads();
     }
+    __syncthreads();
     uint32_t s = s_first, e = s_end;
     if (e == kNone && end_in_reach) e = avail; // (a last workgroup whose reach ends inside the span)
     if (s == kNone || s >= e) { // no sub-bucket starts in the span: nothing of its own (uniform)
