@@ -86,29 +86,22 @@ __device__ __forceinline__ void load_quad(const uint64_t *__restrict__ p, uint64
     o[0] = pack64(v0.x, v0.y), o[1] = pack64(v0.z, v0.w), o[2] = pack64(v1.x, v1.y), o[3] = pack64(v1.z, v1.w);
 }
 
-// Counting reads one byte per entry, not the entry: every writer of (SA, WN) leaves the entry's symbol
-// text[SA[i] - 1] in a byte array next to them (0 for the entry of position 0, which induces nothing) --
-// the array that is the BWT in the end.  The LMS seeds have no such bytes (srcB == NULL); there the windows are
-// read: a stored window is empty exactly when its entry is position 0, every other window is refilled from the
-// text the moment it runs dry.  The counts of a tile do not depend on the order of its entries, so the tile's
-// index range is read as aligned 16-byte pieces; the one or two pieces that straddle the range ends are read
-// entry by entry.  BITS = 3 (at most 8 buckets): a wave per tile, symbol masks and popcounts per lane
-// (sx_device.hpp: gather16) reduced over the wave, instead of 64 lanes queueing on a handful of LDS words.
-template <class WT, int BITS>
-__global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restrict__ srcW,
-                                                              const uint8_t *__restrict__ srcB,
-                                                              const uint32_t *__restrict__ range_in, int rev,
-                                                              int mode, uint32_t c, wnd_cfg cfg,
-                                                              uint32_t *__restrict__ hist, uint32_t stride,
-                                                              uint32_t nkeys, uint32_t chain_max,
-                                                              uint64_t src_len /* entries of the source arrays */)
+// The byte form for at most 8 buckets as a kernel of its own: as one branch of the template below it shared that kernel's
+// 118 registers (the window form keeps 36 words of windows in flight) and ran four waves a SIMD, each alive for one
+// 2 KiB tile: the launches reached 1 TB/s of their byte per entry, bound by nothing but the waves' own latencies.
+__global__ __launch_bounds__(kBlock) void induce_count_bytes_kernel(const uint8_t *__restrict__ srcB,
+                                                                    const uint32_t *__restrict__ range_in, int rev, int mode,
+                                                                    uint32_t c, uint32_t *__restrict__ hist, uint32_t stride,
+                                                                    uint32_t nkeys, uint32_t chain_max, uint64_t src_len)
 {
-    __shared__ uint32_t h[256];
     const uint32_t lo = range_in[0], len = range_in[1] - lo;
     if (len <= chain_max) return;
     const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
-    const bool aligned = srcB ? ((uintptr_t)srcB & 15u) == 0 : ((uintptr_t)srcW & 15u) == 0;
-    if (BITS == 3 && srcB) {
+    const bool aligned = ((uintptr_t)srcB & 15u) == 0;
+    // (Measured and dropped: a lane on 32 consecutive bytes of the tile as two unaligned 16-byte loads -- no straddling
+    //  pieces, a third less vector work, but 1.30 against 1.00 ms a step: the launch is bound by its line requests, and a
+    //  wave's load then spans 32 lines half used instead of 16 whole ones; grids of 512 ... 16 384 workgroups: no difference.)
+    {
         // a wave per tile, all of the tile's pieces in flight at once, no LDS and no barrier
         constexpr int kPieces = kIndTile / 16 / kWave + 1; // the tile's range may start inside a piece
         const int lane = lane_id();
@@ -156,9 +149,33 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
                 hist[(uint64_t)lane * stride + tile] = lane != 0 && induce_accept((uint32_t)lane, c, mode) ? v : 0u;
             }
         }
-        return;
     }
-    if (BITS == 3) {
+}
+
+// Counting reads one byte per entry, not the entry: every writer of (SA, WN) leaves the entry's symbol
+// text[SA[i] - 1] in a byte array next to them (0 for the entry of position 0, which induces nothing) --
+// the array that is the BWT in the end.  The LMS seeds have no such bytes (srcB == NULL); there the windows are
+// read: a stored window is empty exactly when its entry is position 0, every other window is refilled from the
+// text the moment it runs dry.  The counts of a tile do not depend on the order of its entries, so the tile's
+// index range is read as aligned 16-byte pieces; the one or two pieces that straddle the range ends are read
+// entry by entry.  BITS = 3 (at most 8 buckets): a wave per tile, symbol masks and popcounts per lane
+// (sx_device.hpp: gather16) reduced over the wave, instead of 64 lanes queueing on a handful of LDS words.
+template <class WT, int BITS>
+__global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restrict__ srcW,
+                                                              const uint8_t *__restrict__ srcB,
+                                                              const uint32_t *__restrict__ range_in, int rev,
+                                                              int mode, uint32_t c, wnd_cfg cfg,
+                                                              uint32_t *__restrict__ hist, uint32_t stride,
+                                                              uint32_t nkeys, uint32_t chain_max,
+                                                              uint64_t src_len /* entries of the source arrays */)
+{
+    static_assert(BITS == 3, "the window form of at most 8 buckets (more buckets: induce_wide_count_kernel)");
+    const uint32_t lo = range_in[0], len = range_in[1] - lo;
+    if (len <= chain_max) return;
+    const uint32_t ntiles = (len + kIndTile - 1) / kIndTile;
+    const bool aligned = ((uintptr_t)srcW & 15u) == 0;
+    (void)srcB;
+    {
         // a wave per tile, all of the tile's quads in flight at once, no LDS and no barrier
         constexpr int kQuads = kIndTile / 4 / kWave + 1; // the tile's range may start inside a quad
         const int lane = lane_id();
@@ -166,30 +183,39 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
             const uint32_t tile0 = tile * (uint32_t)kIndTile;
             const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
             const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
-            WT W[kQuads][4];
-            uint32_t inside[kQuads]; // (whole aligned quads are loaded, the entries outside [a, b) masked: see above)
-#pragma unroll
-            for (int k = 0; k < kQuads; ++k) {
-                const uint64_t e0 = ((uint64_t)(a >> 2) + (uint64_t)lane + (uint64_t)k * kWave) * 4u;
-                W[k][0] = W[k][1] = W[k][2] = W[k][3] = 0;
-                const uint32_t from = e0 < a ? (uint32_t)(a - e0) : 0u, to = e0 >= b ? 0u : (b - e0 < 4u ? (uint32_t)(b - e0) : 4u);
-                inside[k] = from < to ? ((1u << to) - 1u) & ~((1u << from) - 1u) : 0u;
-                if (aligned && e0 + 4u <= src_len) {
-                    if (inside[k]) load_quad(srcW + e0, W[k]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if ((inside[k] >> e) & 1u) W[k][e] = srcW[e0 + e];
-                }
-            }
+            // (one test for the wave: every quad it may load lies inside the array -- all tiles but the array's last)
+            const bool whole = aligned && ((uint64_t)(a >> 2) + (uint64_t)kQuads * kWave) * 4u <= src_len;
             uint64_t packed = 0; // one 8-bit counter per bucket (a lane sees at most 4 * kQuads entries)
+            // The tile in two halves of kHalf quads a lane: all nine at once kept 36 windows and as many addresses alive,
+            // 118 registers, four waves a SIMD -- and the launch is bound by its waves' latencies, not by their work.
+            constexpr int kHalf = (kQuads + 1) / 2;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                WT W[kHalf][4];
+                uint32_t inside[kHalf]; // (whole aligned quads are loaded, the entries outside [a, b) masked: see above)
 #pragma unroll
-            for (int k = 0; k < kQuads; ++k) {
+                for (int kk = 0; kk < kHalf; ++kk) {
+                    const int k = h * kHalf + kk;
+                    const uint64_t e0 = ((uint64_t)(a >> 2) + (uint64_t)lane + (uint64_t)k * kWave) * 4u;
+                    const uint32_t from = e0 < a ? (uint32_t)(a - e0) : 0u, to = e0 >= b ? 0u : (b - e0 < 4u ? (uint32_t)(b - e0) : 4u);
+                    inside[kk] = (k < kQuads && from < to) ? ((1u << to) - 1u) & ~((1u << from) - 1u) : 0u;
+                    W[kk][0] = W[kk][1] = W[kk][2] = W[kk][3] = 0;
+                    if (whole) {
+                        if (k < kQuads) load_quad(srcW + e0, W[kk]);
+                    } else { // (the array's last tile)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t ch = wnd_first<WT>(W[k][e], cfg) & 7u;
-                    const bool ok = ((inside[k] >> e) & 1u) && wnd_count<WT>(W[k][e]) != 0 && induce_accept(ch, c, mode);
-                    packed += (uint64_t)(ok ? 1u : 0u) << (8u * ch);
+                        for (int e = 0; e < 4; ++e)
+                            if ((inside[kk] >> e) & 1u) W[kk][e] = srcW[e0 + e];
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < kHalf; ++kk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t ch = wnd_first<WT>(W[kk][e], cfg) & 7u;
+                        const bool ok = ((inside[kk] >> e) & 1u) && wnd_count<WT>(W[kk][e]) != 0 && induce_accept(ch, c, mode);
+                        packed += (uint64_t)(ok ? 1u : 0u) << (8u * ch);
+                    }
                 }
             }
             uint64_t even = packed & 0x00FF00FF00FF00FFull, odd = (packed >> 8) & 0x00FF00FF00FF00FFull; // 16-bit fields
@@ -199,53 +225,6 @@ __global__ __launch_bounds__(kBlock) void induce_count_kernel(const WT *__restri
                 hist[(uint64_t)lane * stride + tile] = (uint32_t)(((lane & 1) ? odd : even) >> (16 * (lane >> 1))) & 0xFFFFu;
         }
         return;
-    }
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
-        h[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t tile0 = tile * (uint32_t)kIndTile;
-        const uint32_t cnt = len - tile0 < (uint32_t)kIndTile ? len - tile0 : (uint32_t)kIndTile;
-        const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b)
-        if (srcB) {
-            for (uint64_t q = (uint64_t)(a >> 4) + threadIdx.x; q * 16u < b; q += kBlock) {
-                const uint64_t e0 = q * 16u;
-                uint32_t S[4] = {0, 0, 0, 0};
-                if (aligned && e0 >= a && e0 + 16u <= b) {
-                    load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (e0 + e >= a && e0 + e < b) S[e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t ch = (S[e >> 2] >> (8 * (e & 3))) & 0xFFu;
-                    if (ch != 0 && induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
-                }
-            }
-        } else {
-            for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kBlock) {
-                const uint64_t e0 = q * 4u;
-                WT W[4] = {0, 0, 0, 0};
-                if (aligned && e0 >= a && e0 + 4u <= b) {
-                    load_quad(srcW + e0, W);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
-                        const uint32_t ch = wnd_first<WT>(W[e], cfg);
-                        if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < nkeys) hist[(uint64_t)threadIdx.x * stride + tile] = h[threadIdx.x];
-        __syncthreads();
     }
 }
 
@@ -1853,8 +1832,12 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         // (entries of the suffix array have their symbol bytes next to them; the LMS seeds only their windows)
         const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
         const uint64_t src_len = srcP == st.SA ? st.N : st.m;
-        sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
-                  (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
+        if (srcB)
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_bytes_kernel, dim3(grid), dim3(kBlock), srcB, (const uint32_t *)rin, rev,
+                      mode, c, st.hist, st.stride, st.nk, chain_max, src_len);
+        else
+            sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_count_kernel<WT, 3>, dim3(grid), dim3(kBlock), srcW, srcB,
+                      (const uint32_t *)rin, rev, mode, c, st.cfg, st.hist, st.stride, st.nk, chain_max, src_len);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)tiles_bound * st.nk * 8, induce_offsets_kernel, dim3(st.nk),
                   dim3(kRowThreads), st.hist, st.stride, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max, only3 ? 1 : 0);
         {
