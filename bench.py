@@ -266,7 +266,7 @@ def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_dir
     out = {"n": n, "alphabet_size": sigma, "tables": tables, "steps": steps, "ms_per_step": round(ms, 3),
            "Msuffixes_per_s": round(N / (ms * 1e-3) / 1e6, 1),
            "lms_path": stats.get("lms_path"), "algorithm": LMS_PATHS.get(stats.get("lms_path"), "?"),
-           "induce_rounds": stats.get("induce_rounds"),
+           "induce_rounds": stats.get("induce_rounds"), "recursion_levels": stats.get("recursion_levels"),
            "dominant_class": dom, "dominant_ms_per_step": round(d["ms"], 3),
            "roofline_frac": round(d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d["ms"] > 0 else 0.0,
            "whole_step_frac_of_peak": round(alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -286,7 +286,8 @@ def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_dir
 def other_configs(ctx, dev, steps, cuda=True, log2n=30):
     """BASELINE.json configs[1] and [3] and one hard text, so that the driver's line carries them too:
     256 MiB DNA; 1 GiB of random bytes by the default path (direct prefix sort) and through the LMS sort + induced-sort
-    passes (the "wide-alphabet LDS-histogram path" configs[3] names); a genome-like 1 GiB text."""
+    passes (the "wide-alphabet LDS-histogram path" configs[3] names); a genome-like 1 GiB text; a Fibonacci string
+    (every LMS substring repeats: the general path, its reduced strings sorted by the pipeline itself level below level)."""
     out = {}
 
     def size(n):
@@ -297,7 +298,8 @@ def other_configs(ctx, dev, steps, cuda=True, log2n=30):
             (f"dna_{size(quarter)}", "dna", quarter, 5, True, False),
             (f"bytes_{size(big)}", "bytes", big, 256, False, False),
             (f"bytes_{size(big)}_induced", "bytes", big, 256, False, True),
-            (f"genome_like_{size(big)}", "genome_like", big, 5, True, False)):
+            (f"genome_like_{size(big)}", "genome_like", big, 5, True, False),
+            (f"fibonacci_{size(big)}", "periodic", big, 3, True, False)):
         try:
             out[name] = measure_config(ctx, dev, gen, n, sig, 42, steps, tables, no_direct, cuda)
         except Exception as e:  # noqa: BLE001 -- an extra must not take the headline line down with it

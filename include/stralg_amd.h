@@ -86,6 +86,8 @@ typedef struct sx_build_stats {
     uint32_t induce_redo;    /* buckets of the induced-sort passes whose rounds the queued launches did not finish (runs longer than
                                 the tail kernel's steps reach, more entries alive than it holds): the host carried them on */
     uint32_t long_runs;      /* the classification saw a run that fills a 4096-symbol tile: the passes are attended from the start */
+    uint32_t recursion_levels; /* reduced strings over a byte alphabet that were sorted by the pipeline itself, one below the other */
+    uint32_t reserved;
 } sx_build_stats;
 
 /* ---- context ------------------------------------------------------------ */
@@ -115,6 +117,9 @@ enum {
                                        whose rounds the tail kernel could not finish leaves word, the launches behind it do nothing,
                                        and the host carries that bucket on before it queues the rest; 1 = attended: the host reads
                                        every bucket's last range back before it queues the next bucket (rounds 1 and 2) */
+    ,SX_FLAG_RECURSE_MIN = 11      /* a reduced string of at most 255 names and at least this many symbols is sorted by the whole
+                                       pipeline again (in a child context) instead of by prefix doubling; negative: the default
+                                       (2^20); tests set small values */
     ,SX_FLAG_COPY_TEXT_FIRST = 10   /* 1 = the build's padded copy of the text is made by a device copy before the classification
                                        (rounds 1 and 2); 0 = the classification writes it while it reads the caller's text */
 };

@@ -240,6 +240,10 @@ class Context:
         finish is carried on by the host), 1 the host looks at every bucket's last range"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 9, int(mode)), "sx_ctx_set_flag")
 
+    def set_recurse_min(self, symbols):
+        """SX_FLAG_RECURSE_MIN: reduced strings of at most 255 names recurse from this length on (negative: default)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 11, int(symbols)), "sx_ctx_set_flag")
+
     def set_copy_text_first(self, on=True):
         """SX_FLAG_COPY_TEXT_FIRST: a device copy of the text before the classification (True) or the copy made by the
         classification while it reads the caller's text (default)"""

@@ -21,6 +21,13 @@ namespace sx {
 
 __global__ void write_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
 
+// names of the reduced string as symbols of a byte text (at most 255 names besides the sentinel's 0)
+__global__ __launch_bounds__(kBlock) void names_to_bytes_kernel(const uint32_t *__restrict__ R, uint64_t count, uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) out[i] = (uint8_t)R[i];
+}
+
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i)
 {
     uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
@@ -249,8 +256,29 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         SX_TRY(sx_name_pieces(ctx, ks, vs, M, rb, &n_names));
         ctx->stats.n_names = n_names;
         const uint32_t *sa_r;
+        const uint64_t recurse_min = ctx->recurse_min >= 0 ? (uint64_t)ctx->recurse_min : (1ull << 20);
         if (n_names == M) {
             sa_r = vs; // every piece is unique: sorted pieces == sorted suffixes (sa_is.c:423-428)
+        } else if (n_names <= 256 && M - 1 >= recurse_min && ctx->depth < 48) {
+            // The recursion of sa_is.c:370-387, where it costs nothing new: a reduced string of at most 255 names (and
+            // the sentinel's name 0) *is* a remapped byte text, and this pipeline sorts those -- in a child context with
+            // its own workspace, the general path forced (a text that got here has too many ties for a prefix sort).
+            // These are the texts prefix doubling is worst on -- periodic and Fibonacci strings, a handful of distinct
+            // LMS substrings however long the text: log n rounds over all samples -- and every level is a third to a half
+            // as long as the one above, so the levels together cost what the first costs twice over.
+            uint8_t *rbytes = reinterpret_cast<uint8_t *>(rb.kb); // (the key buffers are free once the pieces have their names)
+            sx_launch(ctx, SX_KC_NAMES, M * 5, names_to_bytes_kernel, dim3(sx_div_up(M, kBlock)), dim3(kBlock), (const uint32_t *)rb.R,
+                      M - 1, rbytes);
+            SX_TRY(sx_sync(ctx));
+            sx_ctx *child = nullptr;
+            SX_TRY(sx_child_begin(ctx, &child));
+            const int rc = sx_sa_build_impl(child, rbytes, M - 1, (uint32_t)n_names, rb.sa_r, nullptr);
+            sx_child_end(ctx, child);
+            if (rc != 0) return sx_fail_msg(ctx, rc, sx_last_error(child));
+            ctx->stats.recursion_levels = 1 + child->stats.recursion_levels;
+            ctx->stats.doubling_rounds += child->stats.doubling_rounds;
+            ctx->stats.sort_passes += child->stats.sort_passes;
+            sa_r = rb.sa_r;
         } else {
             SX_TRY(sx_reduced_suffix_sort(ctx, M, n_names, rb));
             sa_r = rb.sa_r;

@@ -81,6 +81,9 @@ struct sx_ctx {
     int induce_batch_off = 0; // SX_FLAG_INDUCE_BATCH_OFF
     int induce_attended = 0;  // SX_FLAG_INDUCE_ATTENDED
     int copy_text_first = 0;  // SX_FLAG_COPY_TEXT_FIRST
+    int64_t recurse_min = -1; // SX_FLAG_RECURSE_MIN; -1 = the default length from which a reduced string of <= 255 names recurses
+    sx_ctx *child = nullptr;  // the context a reduced string over a byte alphabet is sorted in (sx_build.hip), created on first use
+    int depth = 0;            // 0 for a caller's context, 1 + the parent's for a child
     int64_t induce_batch_min = -1; // SX_FLAG_INDUCE_BATCH_MIN; -1 = ranges the tail kernel holds pass the batch form by
     int prof_on = 0;
     int prof_only = -1; // >= 0: only launches of this kernel class are bracketed with events
@@ -103,6 +106,11 @@ int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_ds
 int sx_chain_slab(sx_ctx *ctx, int which, size_t bytes);
 // a fresh epoch for one chained launch (24 bits; every status slab is zeroed when they wrap)
 uint32_t sx_chain_next_epoch(sx_ctx *ctx);
+
+// the child context of ctx (created on first use; it takes over the behaviour switches and the profiling state), and the
+// end of a build in it: its event times and launch counts are added to the parent's
+int sx_child_begin(sx_ctx *ctx, sx_ctx **child);
+void sx_child_end(sx_ctx *ctx, sx_ctx *child);
 
 void sx_prof_begin(sx_ctx *ctx, int kclass);
 void sx_prof_end(sx_ctx *ctx, int kclass, uint64_t alg_bytes);

@@ -160,6 +160,43 @@ static void prof_drain(sx_ctx *ctx)
     ctx->ev_used.clear();
 }
 
+int sx_child_begin(sx_ctx *ctx, sx_ctx **out)
+{
+    if (!ctx->child) {
+        int rc = sx_ctx_create(ctx->device, &ctx->child);
+        if (rc != 0) return sx_fail_msg(ctx, rc, "cannot create the context of the reduced string");
+        ctx->child->depth = ctx->depth + 1;
+    }
+    sx_ctx *c = ctx->child;
+    c->chain_max_override = ctx->chain_max_override;
+    c->radix_digit_bits = ctx->radix_digit_bits;
+    c->sort_mode = ctx->sort_mode;
+    c->induce_batch_off = ctx->induce_batch_off;
+    c->induce_batch_min = ctx->induce_batch_min;
+    c->induce_attended = ctx->induce_attended;
+    c->copy_text_first = ctx->copy_text_first;
+    c->recurse_min = ctx->recurse_min;
+    c->no_direct = 1;      // (a reduced string that got here has too many ties for any prefix sort)
+    c->force_general = 1;
+    c->prefix_symbols = 0;
+    c->prof_on = ctx->prof_on;
+    c->prof_only = ctx->prof_only;
+    *out = c;
+    return 0;
+}
+
+void sx_child_end(sx_ctx *ctx, sx_ctx *c)
+{
+    prof_drain(c);
+    for (int k = 0; k < SX_KC_COUNT; ++k) {
+        ctx->kstat[k].launches += c->kstat[k].launches;
+        ctx->kstat[k].ms += c->kstat[k].ms;
+        ctx->kstat[k].alg_bytes += c->kstat[k].alg_bytes;
+    }
+    memset(c->kstat, 0, sizeof c->kstat);
+    c->prof_on = 0;
+}
+
 extern "C" {
 
 int sx_device_count(void)
@@ -216,6 +253,7 @@ int sx_ctx_create(int device, sx_ctx **out)
 void sx_ctx_trim(sx_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->child) sx_ctx_trim(ctx->child);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < SX_NSLABS; ++i) {
@@ -228,6 +266,8 @@ void sx_ctx_trim(sx_ctx *ctx)
 void sx_ctx_destroy(sx_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->child) sx_ctx_destroy(ctx->child);
+    ctx->child = nullptr;
     sx_ctx_trim(ctx);
     prof_drain(ctx);
     for (sx_event_pair &ep : ctx->ev_free) {
@@ -268,6 +308,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     }
     if (flag == SX_FLAG_INDUCE_BATCH_OFF) {
         ctx->induce_batch_off = value ? 1 : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_RECURSE_MIN) {
+        ctx->recurse_min = value < 0 ? -1 : (int64_t)value;
         return 0;
     }
     if (flag == SX_FLAG_COPY_TEXT_FIRST) {

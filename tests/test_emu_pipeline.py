@@ -474,6 +474,44 @@ def test_induce_round_batches_and_unattended_passes(emu_ctx):
         emu_ctx.set_no_direct_sort(False)
 
 
+def test_reduced_string_recursion(emu_ctx):
+    """sa_is.c:370-387 where it costs nothing new: a reduced string of at most 255 names is a remapped byte text, which the
+    pipeline sorts itself, level below level in child contexts (SX_FLAG_RECURSE_MIN brings the levels onto small texts):
+    Fibonacci, Thue-Morse, periodic strings; the same texts through prefix doubling; the BWT and tables on top"""
+    rng = np.random.default_rng(5)
+
+    def fib(n):
+        a, b = b"\x02", b"\x02\x01"
+        while len(b) < n:
+            a, b = b, b + a
+        return np.frombuffer(b[:n], np.uint8).copy()
+
+    tm = np.array([1], np.uint8)
+    while tm.size < 20000:
+        tm = np.concatenate([tm, 3 - tm])
+    cases = [(fib(30000), 3), (fib(50000) + 2, 5), (np.tile(rng.integers(1, 5, size=7, dtype=np.uint8), 4000), 5),
+             (np.tile(rng.integers(1, 5, size=50, dtype=np.uint8), 500), 5), (tm, 3),
+             (np.tile(rng.integers(1, 40, size=9, dtype=np.uint8), 3000), 40)]
+    try:
+        levels = []
+        for rmin in (100, 3000, -1):
+            emu_ctx.set_recurse_min(rmin)
+            for x, sigma in cases:
+                want = oracle.sa_is_strict(x, sigma)
+                sa, bw = np.zeros(x.size + 1, np.uint32), np.zeros(x.size + 1, np.uint8)
+                emu_ctx.sa_bwt_build_dev(x, x.size, sigma, sa, bw)
+                assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (rmin, sigma, x.size)
+                levels.append((rmin, emu_ctx.last_stats()["recursion_levels"]))
+        assert max(l for r, l in levels if r == 100) >= 5 and all(l == 0 for r, l in levels if r == -1), levels
+        emu_ctx.set_recurse_min(100)
+        x = fib(20000)
+        sa, c, o = emu_ctx.build_tables(x, 3)
+        want = oracle.sa_is_strict(x, 3)
+        assert (sa == want).all() and (c == oracle.c_table(x, 3)).all() and (o == oracle.o_table(x, want, 3)).all()
+    finally:
+        emu_ctx.set_recurse_min(-1)
+
+
 def test_primitives(emu_ctx):
     rng = np.random.default_rng(1)
     n = 5000

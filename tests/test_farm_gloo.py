@@ -132,7 +132,7 @@ def test_bench_default_run_carries_the_other_configs(emu_ctx):
     doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert doc["verified"] is True and doc["metric"].startswith("Msuffixes/s (SA-IS + BWT C/O tables")
     oc = doc["other_configs"]
-    assert set(oc) == {"dna_1024B", "bytes_4096B", "bytes_4096B_induced", "genome_like_4096B"}
+    assert set(oc) == {"dna_1024B", "bytes_4096B", "bytes_4096B_induced", "genome_like_4096B", "fibonacci_4096B"}
     for name, c in oc.items():
         assert c.get("verified") is True, (name, c)
         assert c["ms_per_step"] > 0 and "roofline_frac" in c and "lms_path" in c

@@ -1099,6 +1099,45 @@ def test_copies_at_the_wave_window_boundaries(gpu_ctx):
         assert st["lms_path"] == 2, (copies, extra, st)
 
 
+def test_reduced_string_recursion(gpu_ctx):
+    """texts whose reduced string has a handful of names (Fibonacci, Thue-Morse, periodic): the pipeline sorts the reduced
+    string itself, level below level (sa_is.c:370-387), instead of doubling over all samples; bit-exact against the
+    oracle at 4 Mi symbols, by the properties at 256 Mi, and against the doubling path on the same input"""
+    import torch
+    from stralg_amd import verify, workloads
+
+    def fib(n):
+        a, b = b"\x02", b"\x02\x01"
+        while len(b) < n:
+            a, b = b, b + a
+        return np.frombuffer(b[:n], np.uint8).copy()
+
+    tm = np.array([1], np.uint8)
+    while tm.size < (1 << 22):
+        tm = np.concatenate([tm, 3 - tm])
+    rng = np.random.default_rng(8)
+    try:
+        for x, sigma in ((fib(1 << 22), 3), (tm, 3), (np.tile(rng.integers(1, 5, size=11, dtype=np.uint8), 400000), 5)):
+            want = oracle.sa_is(x, sigma)
+            for rmin, lv in ((-1, 1), (1 << 30, 0), (5000, 1)):  # (how many levels depends on the text: at least one)
+                gpu_ctx.set_recurse_min(rmin)
+                sa = gpu_ctx.sa_build(x, sigma)
+                st = gpu_ctx.last_stats()
+                assert (sa == want).all(), (sigma, rmin)
+                assert st["lms_path"] == 2 and (st["recursion_levels"] >= lv if lv else st["recursion_levels"] == 0), str((rmin, st))
+        gpu_ctx.set_recurse_min(-1)
+        n = 1 << 28
+        text, sigma = workloads.make_text(gpu_ctx, "periodic", n, 0, 1, torch.device("cuda", 0))
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+        gpu_ctx.sa_bwt_build_dev(text, n, sigma, sa, bw)
+        assert gpu_ctx.last_stats()["recursion_levels"] >= 4
+        gpu_ctx.trim()
+        verify.verify_build_on_device(text, n, sigma, sa, bw, None, None)
+    finally:
+        gpu_ctx.set_recurse_min(-1)
+
+
 def test_differential_fuzz():
     """tools/fuzz_gpu.py: 250 random (size, alphabet, structure, path flag) combinations against the oracle --
     suffix array, C and O tables from (text, sa) and from the fused build.  (This is the harness that found the

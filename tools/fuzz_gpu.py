@@ -60,12 +60,13 @@ for k in range(cases):
     ctx.set_induce_batch(bool(rng.integers(0, 5)))
     ctx.set_induce_attended(int(rng.choice([0, 0, 1])))
     ctx.set_copy_text_first(bool(rng.integers(0, 4) == 0))
+    ctx.set_recurse_min(int(rng.choice([-1, -1, 50, 3000])))  # reduced strings of few names sorted by the pipeline itself
     # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
     want = oracle.sa_is_strict(x, sigma) if sigma == n + 1 else oracle.sa_is(x, sigma)
     sa = np.zeros(n + 1, np.uint32)
     got = ctx.sa_build(x, sigma)
     st = ctx.last_stats()
-    pk = (st["lms_path"], st["sort_local"], st["refine_tiers"], min(st["induce_redo"], 1), st["long_runs"])
+    pk = (st["lms_path"], st["sort_local"], st["refine_tiers"], min(st["induce_redo"], 1), st["long_runs"], min(st["recursion_levels"], 2))
     paths[pk] = paths.get(pk, 0) + 1
     assert (got == want).all(), ("SA", k, sigma, n, kind, flag)
     if sigma <= 128 and n < 70000:
@@ -77,5 +78,5 @@ for k in range(cases):
         assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
 ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(-1); ctx.set_prefix_symbols(0)
 ctx.set_sort_mode(0); ctx.set_radix_digit_bits(0)
-ctx.set_induce_batch_min(-1); ctx.set_induce_batch(True); ctx.set_induce_attended(0); ctx.set_copy_text_first(False)
+ctx.set_induce_batch_min(-1); ctx.set_induce_batch(True); ctx.set_induce_attended(0); ctx.set_copy_text_first(False); ctx.set_recurse_min(-1)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
