@@ -87,7 +87,8 @@ typedef struct sx_build_stats {
                                 the tail kernel's steps reach, more entries alive than it holds): the host carried them on */
     uint32_t long_runs;      /* the classification saw a run that fills a 4096-symbol tile: the passes are attended from the start */
     uint32_t recursion_levels; /* reduced strings over a byte alphabet that were sorted by the pipeline itself, one below the other */
-    uint32_t reserved;
+    uint32_t sample_tied_permille; /* 0: no sample was looked at; else 1 + the tied share (per mille) of the sampled suffixes under
+                                      the longest prefix key: from 300 on the prefix-key sort is not attempted */
 } sx_build_stats;
 
 /* ---- context ------------------------------------------------------------ */
@@ -120,6 +121,8 @@ enum {
     ,SX_FLAG_RECURSE_MIN = 11      /* a reduced string of at most 255 names and at least this many symbols is sorted by the whole
                                        pipeline again (in a child context) instead of by prefix doubling; negative: the default
                                        (2^20); tests set small values */
+    ,SX_FLAG_SAMPLE_MIN = 12       /* texts of more than 8 symbols and at least this many suffixes get a look at a sample before a
+                                       prefix-key sort (negative: the default, 2^20; tests set small values) */
     ,SX_FLAG_COPY_TEXT_FIRST = 10   /* 1 = the build's padded copy of the text is made by a device copy before the classification
                                        (rounds 1 and 2); 0 = the classification writes it while it reads the caller's text */
 };

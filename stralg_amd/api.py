@@ -244,6 +244,10 @@ class Context:
         """SX_FLAG_RECURSE_MIN: reduced strings of at most 255 names recurse from this length on (negative: default)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 11, int(symbols)), "sx_ctx_set_flag")
 
+    def set_sample_min(self, suffixes):
+        """SX_FLAG_SAMPLE_MIN: wide-alphabet texts of at least this many suffixes get the look at a sample (negative: default)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 12, int(suffixes)), "sx_ctx_set_flag")
+
     def set_copy_text_first(self, on=True):
         """SX_FLAG_COPY_TEXT_FIRST: a device copy of the text before the classification (True) or the copy made by the
         classification while it reads the caller's text (default)"""

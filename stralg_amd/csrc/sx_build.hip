@@ -48,6 +48,10 @@ __global__ __launch_bounds__(kBlock) void synth_kernel(uint8_t *__restrict__ out
 
 using namespace sx;
 
+// a sample's tied share under the longest prefix key from which both attempts of the prefix-key sort are skipped (the sort
+// gives up at a quarter of its suffixes tied; the sample's share is a lower bound of the whole's)
+static constexpr double kDoomedTiedShare = 0.30;
+
 // bits per symbol, symbols per key, bits of the length field (tests/model.py key_layout)
 static void key_layout(uint32_t maxc, uint32_t &bits, uint32_t &slots, uint32_t &lenbits)
 {
@@ -155,7 +159,10 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
             const uint32_t *sorted = nullptr;
             const void *prev_symbols = nullptr; // one-symbol windows, when the keys had room for them
             int resolved = 0;
-            SX_TRY(sx_sort_lms_by_prefix(ctx, td, am, &sorted, &prev_symbols, &resolved, true));
+            double tied_share = -1.0; // (a look at a sample first: a word text ties most suffixes on any prefix)
+            SX_TRY(sx_prefix_ties_sampled(ctx, td, am, true, &tied_share));
+            ctx->stats.sample_tied_permille = tied_share < 0 ? 0u : (uint32_t)(tied_share * 1000.0) + 1u;
+            if (tied_share < kDoomedTiedShare) SX_TRY(sx_sort_lms_by_prefix(ctx, td, am, &sorted, &prev_symbols, &resolved, true));
             if (resolved) {
                 ctx->stats.lms_path = 3;
                 ctx->stats.n_samples = N;
@@ -198,7 +205,10 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         am.base = (char *)ctx->slab[SX_SLAB_M].p;
         am.cap = ctx->slab[SX_SLAB_M].cap;
         int resolved = 0;
-        SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, &sorted_lms, &seed_windows, &resolved));
+        double tied_share = -1.0;
+        SX_TRY(sx_prefix_ties_sampled(ctx, ti, am, false, &tied_share));
+        if (tied_share >= 0) ctx->stats.sample_tied_permille = (uint32_t)(tied_share * 1000.0) + 1u;
+        if (tied_share < kDoomedTiedShare) SX_TRY(sx_sort_lms_by_prefix(ctx, ti, am, &sorted_lms, &seed_windows, &resolved));
         if (resolved) {
             ctx->stats.lms_path = 1;
             ctx->stats.n_samples = ti.m;

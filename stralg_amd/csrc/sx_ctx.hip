@@ -176,6 +176,7 @@ int sx_child_begin(sx_ctx *ctx, sx_ctx **out)
     c->induce_attended = ctx->induce_attended;
     c->copy_text_first = ctx->copy_text_first;
     c->recurse_min = ctx->recurse_min;
+    c->sample_min = ctx->sample_min;
     c->no_direct = 1;      // (a reduced string that got here has too many ties for any prefix sort)
     c->force_general = 1;
     c->prefix_symbols = 0;
@@ -308,6 +309,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     }
     if (flag == SX_FLAG_INDUCE_BATCH_OFF) {
         ctx->induce_batch_off = value ? 1 : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_SAMPLE_MIN) {
+        ctx->sample_min = value < 0 ? -1 : (int64_t)value;
         return 0;
     }
     if (flag == SX_FLAG_RECURSE_MIN) {

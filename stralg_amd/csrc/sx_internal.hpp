@@ -75,6 +75,9 @@ int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const 
 // ---- sx_lmssort.hip
 size_t sx_lms_prefix_bytes(uint64_t m);
 int sx_bwt_from_seed_windows(sx_ctx *ctx, const uint32_t *seedw, uint64_t N, uint32_t maxc, uint8_t *bwt_out);
+// tied share of a sample under the longest prefix key (a lower bound of the whole's); < 0: no look taken (at most 8 symbols,
+// short texts)
+int sx_prefix_ties_sampled(sx_ctx *ctx, const sx_text_info &ti, sx_arena am, bool all_suffixes, double *share);
 int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, const uint32_t **out,
                           const void **seed_windows, int *resolved, bool all_suffixes = false);
 

@@ -923,9 +923,87 @@ struct OutStillTied {
     }
 };
 
+
+// ---- a look at a sample before a prefix sort of a wide-alphabet text ------------------------------------------------
+// Natural-language-like texts (words, phrases, mark-up) tie most suffixes on any 63-bit prefix: the prefix-key sort
+// fails its tie bound twice (40 bits, then the longest key) and the general path takes over -- after 5 + 8 radix passes
+// over every LMS suffix, or 5 over every suffix where the direct sort was tried first (a 1 GiB word text: 60 of 244 ms).
+// A suffix that is tied inside a sample is tied in the whole, so the tied share of a 1-in-16 sample under the *longest*
+// key is a lower bound of what the second attempt would meet: above the bound, both attempts are skipped.  Only texts
+// of more than 8 symbols are looked at (uniform DNA pays 1.5 ms for a look that never tells it anything).
+__global__ __launch_bounds__(kBlock) void sample_keys_kernel(const uint8_t *__restrict__ T, const uint16_t *__restrict__ lmsbits /* or null */,
+                                                            uint64_t N, uint32_t step, uint32_t base, uint32_t C,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                            uint32_t *__restrict__ count, uint32_t cap)
+{
+    const uint64_t w = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * step; // one 16-position word in `step`
+    if (w * 16u >= N) return;
+    uint32_t mask = lmsbits ? lmsbits[w] : 1u; // (all suffixes: the word's first position stands for it)
+    while (mask) {
+        const uint32_t bit = (uint32_t)__ffs(mask) - 1u;
+        mask &= mask - 1u;
+        const uint64_t p = w * 16u + bit;
+        if (p >= N) break;
+        uint64_t key = 0;
+        for (uint32_t i = 0; i < C; ++i) {
+            const uint64_t q = p + i;
+            key = key * base + (q < N - 1 ? (uint64_t)T[q] : 0ull); // (the sentinel and what lies behind it: digit 0)
+        }
+        const uint32_t slot = atomicAdd(count, 1u);
+        if (slot < cap) keys[slot] = key, vals[slot] = slot;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sample_ties_kernel(const uint64_t *__restrict__ ks, uint32_t S, uint32_t *__restrict__ tied)
+{
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const bool t = j < S && ((j > 0 && ks[j - 1] == ks[j]) || (j + 1 < S && ks[j + 1] == ks[j]));
+    const uint64_t b = __ballot(t ? 1 : 0);
+    if (b && lane_id() == __ffsll((unsigned long long)b) - 1) atomicAdd(tied, (uint32_t)__popcll(b));
+}
 } // namespace sx
 
 using namespace sx;
+
+// tied share of a 1-in-16 sample of the LMS suffixes (all suffixes: of the positions) under the longest prefix key a 64-bit
+// word holds; scratch from `am` (by value: handed back).  share < 0: no look was taken.
+int sx_prefix_ties_sampled(sx_ctx *ctx, const sx_text_info &ti, sx_arena am, bool all_suffixes, double *share)
+{
+    *share = -1.0;
+    const uint64_t m = all_suffixes ? ti.N : ti.m;
+    const uint64_t look_from = ctx->sample_min >= 0 ? (uint64_t)ctx->sample_min : (1ull << 20);
+    if (ti.maxc < 8 || m < look_from || ctx->prefix_symbols > 0) return 0; // (a forced prefix length: a test of that sort)
+    const uint32_t base = ti.maxc + 1;
+    uint32_t Cmax = 0;
+    for (double cap63 = 9.2e18, v = 1.0; v * base <= cap63 && Cmax < 63; v *= base) ++Cmax;
+    if (Cmax < 1) Cmax = 1;
+    uint64_t top = 1;
+    for (uint32_t i = 0; i < Cmax; ++i) top *= base;
+    const int kbits = sx_bitlen(top - 1);
+    // one position word in 16: LMS suffixes keep their density, positions are thinned 256-fold (short texts, which only
+    // tests send here: every word)
+    const uint32_t step = m >= (1ull << 22) ? 16 : 1;
+    const uint64_t words = (ti.N + 15) / 16, threads = (words + step - 1) / step;
+    const uint32_t cap = (uint32_t)(all_suffixes ? threads + 16 : m / step * 2 + 4096);
+    uint64_t *ka = am.take<uint64_t>(cap), *kb = am.take<uint64_t>(cap);
+    uint32_t *va = am.take<uint32_t>(cap), *vb = am.take<uint32_t>(cap), *cnt = am.take<uint32_t>(4);
+    if (!ka || !kb || !va || !vb || !cnt) return 0; // (no room: no look)
+    SX_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+    sx_launch(ctx, SX_KC_KEYS, threads * 40, sample_keys_kernel, dim3(sx_div_up(threads, kBlock)), dim3(kBlock), ti.T,
+              (const uint16_t *)(all_suffixes ? nullptr : ti.lmsbits), ti.N, step, base, Cmax, ka, va, cnt, cap);
+    uint32_t S = 0;
+    SX_TRY(sx_readback(ctx, cnt, 1, &S));
+    if (S > cap) S = cap;
+    if (S < 1024) return 0;
+    int in_b = 0;
+    SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, S, 0, kbits, &in_b));
+    sx_launch(ctx, SX_KC_NAMES, (uint64_t)S * 8, sample_ties_kernel, dim3(sx_div_up(S, kBlock)), dim3(kBlock),
+              (const uint64_t *)(in_b ? kb : ka), S, cnt + 1);
+    uint32_t tied = 0;
+    SX_TRY(sx_readback(ctx, cnt + 1, 1, &tied));
+    *share = (double)tied / (double)S;
+    return 0;
+}
 
 size_t sx_lms_prefix_bytes(uint64_t m)
 {

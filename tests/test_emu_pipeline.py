@@ -512,6 +512,35 @@ def test_reduced_string_recursion(emu_ctx):
         emu_ctx.set_recurse_min(-1)
 
 
+def test_look_at_a_sample_before_the_prefix_sorts(emu_ctx):
+    """texts of more than 8 symbols: the tied share of a sample under the longest 63-bit key decides whether the prefix-key
+    sorts are tried at all (a word text ties most of its suffixes and goes to the general path at once; random symbols
+    keep the direct sort) -- same arrays either way (SX_FLAG_SAMPLE_MIN brings the look onto small texts)"""
+    rng = np.random.default_rng(9)
+    words = [rng.integers(2, 28, size=int(rng.integers(2, 9)), dtype=np.uint8) for _ in range(200)]
+    w = 1.0 / np.arange(1, 201) ** 1.2
+    ids = rng.choice(200, size=8000, p=w / w.sum())
+    x = np.concatenate([np.concatenate([words[i], [1]]) for i in ids]).astype(np.uint8)
+    y = rng.integers(1, 28, size=40000, dtype=np.uint8)
+    try:
+        for smin, nd in ((1000, False), (1000, True), (-1, False)):
+            emu_ctx.set_sample_min(smin)
+            emu_ctx.set_no_direct_sort(nd)
+            sa, bw = np.zeros(x.size + 1, np.uint32), np.zeros(x.size + 1, np.uint8)
+            emu_ctx.sa_bwt_build_dev(x, x.size, 28, sa, bw)
+            want = oracle.sa_is_strict(x, 28)
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (smin, nd)
+            st = emu_ctx.last_stats()
+            assert st["lms_path"] == 2 and (st["sample_tied_permille"] > 300) == (smin > 0), (smin, nd, st)
+            got = emu_ctx.sa_build(y, 28)
+            st = emu_ctx.last_stats()
+            assert (got == oracle.sa_is_strict(y, 28)).all() and st["lms_path"] == (1 if nd else 3), (smin, nd, st)
+            assert st["sample_tied_permille"] <= 5, st
+    finally:
+        emu_ctx.set_sample_min(-1)
+        emu_ctx.set_no_direct_sort(False)
+
+
 def test_primitives(emu_ctx):
     rng = np.random.default_rng(1)
     n = 5000
