@@ -931,35 +931,41 @@ struct OutStillTied {
 // A suffix that is tied inside a sample is tied in the whole, so the tied share of a 1-in-16 sample under the *longest*
 // key is a lower bound of what the second attempt would meet: above the bound, both attempts are skipped.  Only texts
 // of more than 8 symbols are looked at (uniform DNA pays 1.5 ms for a look that never tells it anything).
+constexpr uint32_t kSampleBins = 512; // (tied and valid counts: one read-back of 1024 words)
 __global__ __launch_bounds__(kBlock) void sample_keys_kernel(const uint8_t *__restrict__ T, const uint16_t *__restrict__ lmsbits /* or null */,
                                                             uint64_t N, uint32_t step, uint32_t base, uint32_t C,
-                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                            uint32_t *__restrict__ count, uint32_t cap)
+                                                            uint64_t threads, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    const uint64_t w = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * step; // one 16-position word in `step`
-    if (w * 16u >= N) return;
-    uint32_t mask = lmsbits ? lmsbits[w] : 1u; // (all suffixes: the word's first position stands for it)
-    while (mask) {
-        const uint32_t bit = (uint32_t)__ffs(mask) - 1u;
-        mask &= mask - 1u;
-        const uint64_t p = w * 16u + bit;
-        if (p >= N) break;
-        uint64_t key = 0;
-        for (uint32_t i = 0; i < C; ++i) {
-            const uint64_t q = p + i;
+    // one 16-position word in `step` a thread, one suffix of it: its first LMS position (all suffixes: its first
+    // position); a word without one leaves the largest key, which the count of ties skips
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= threads) return;
+    const uint64_t w = i * step;
+    const uint32_t mask = w * 16u >= N ? 0u : (lmsbits ? lmsbits[w] : 1u);
+    uint64_t key = ~0ull;
+    const uint64_t p = w * 16u + (mask ? (uint32_t)__ffs(mask) - 1u : 0u);
+    if (mask && p < N) {
+        key = 0;
+        for (uint32_t k = 0; k < C; ++k) {
+            const uint64_t q = p + k;
             key = key * base + (q < N - 1 ? (uint64_t)T[q] : 0ull); // (the sentinel and what lies behind it: digit 0)
         }
-        const uint32_t slot = atomicAdd(count, 1u);
-        if (slot < cap) keys[slot] = key, vals[slot] = slot;
     }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(kBlock) void sample_ties_kernel(const uint64_t *__restrict__ ks, uint32_t S, uint32_t *__restrict__ tied)
+__global__ __launch_bounds__(kBlock) void sample_ties_kernel(const uint64_t *__restrict__ ks, uint32_t S, uint32_t *__restrict__ bins)
 {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    const bool t = j < S && ((j > 0 && ks[j - 1] == ks[j]) || (j + 1 < S && ks[j + 1] == ks[j]));
-    const uint64_t b = __ballot(t ? 1 : 0);
-    if (b && lane_id() == __ffsll((unsigned long long)b) - 1) atomicAdd(tied, (uint32_t)__popcll(b));
+    const bool valid = j < S && ks[j] != ~0ull;
+    const bool t = valid && ((j > 0 && ks[j - 1] == ks[j]) || (j + 1 < S && ks[j + 1] == ks[j]));
+    const uint64_t bt = __ballot(t ? 1 : 0), bv = __ballot(valid ? 1 : 0);
+    const uint32_t bin = (blockIdx.x * (uint32_t)kWavesPerBlock + (uint32_t)wave_id()) & (kSampleBins - 1u);
+    if (lane_id() == 0) {
+        if (bt) atomicAdd(&bins[bin], (uint32_t)__popcll(bt));
+        if (bv) atomicAdd(&bins[kSampleBins + bin], (uint32_t)__popcll(bv));
+    }
 }
 } // namespace sx
 
@@ -980,27 +986,26 @@ int sx_prefix_ties_sampled(sx_ctx *ctx, const sx_text_info &ti, sx_arena am, boo
     uint64_t top = 1;
     for (uint32_t i = 0; i < Cmax; ++i) top *= base;
     const int kbits = sx_bitlen(top - 1);
-    // one position word in 16: LMS suffixes keep their density, positions are thinned 256-fold (short texts, which only
-    // tests send here: every word)
-    const uint32_t step = m >= (1ull << 22) ? 16 : 1;
+    // one suffix a sampled word: LMS suffixes are thinned to about one in 19 (a word in four, its first LMS position),
+    // positions 256-fold (short texts, which only tests send here: every word)
+    const uint32_t step = m < (1ull << 22) ? 1 : all_suffixes ? 16 : 4;
     const uint64_t words = (ti.N + 15) / 16, threads = (words + step - 1) / step;
-    const uint32_t cap = (uint32_t)(all_suffixes ? threads + 16 : m / step * 2 + 4096);
+    const uint32_t cap = (uint32_t)threads;
     uint64_t *ka = am.take<uint64_t>(cap), *kb = am.take<uint64_t>(cap);
-    uint32_t *va = am.take<uint32_t>(cap), *vb = am.take<uint32_t>(cap), *cnt = am.take<uint32_t>(4);
-    if (!ka || !kb || !va || !vb || !cnt) return 0; // (no room: no look)
-    SX_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(uint32_t), ctx->stream));
+    uint32_t *va = am.take<uint32_t>(cap), *vb = am.take<uint32_t>(cap), *bins = am.take<uint32_t>(2 * kSampleBins);
+    if (!ka || !kb || !va || !vb || !bins) return 0; // (no room: no look)
+    SX_CHECK(hipMemsetAsync(bins, 0, 2 * kSampleBins * sizeof(uint32_t), ctx->stream));
     sx_launch(ctx, SX_KC_KEYS, threads * 40, sample_keys_kernel, dim3(sx_div_up(threads, kBlock)), dim3(kBlock), ti.T,
-              (const uint16_t *)(all_suffixes ? nullptr : ti.lmsbits), ti.N, step, base, Cmax, ka, va, cnt, cap);
-    uint32_t S = 0;
-    SX_TRY(sx_readback(ctx, cnt, 1, &S));
-    if (S > cap) S = cap;
-    if (S < 1024) return 0;
+              (const uint16_t *)(all_suffixes ? nullptr : ti.lmsbits), ti.N, step, base, Cmax, threads, ka, va);
     int in_b = 0;
-    SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, S, 0, kbits, &in_b));
-    sx_launch(ctx, SX_KC_NAMES, (uint64_t)S * 8, sample_ties_kernel, dim3(sx_div_up(S, kBlock)), dim3(kBlock),
-              (const uint64_t *)(in_b ? kb : ka), S, cnt + 1);
-    uint32_t tied = 0;
-    SX_TRY(sx_readback(ctx, cnt + 1, 1, &tied));
+    SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, cap, 0, kbits < 64 ? kbits + 1 : 64, &in_b)); // (+1: the empty slots' key sorts last)
+    sx_launch(ctx, SX_KC_NAMES, (uint64_t)cap * 8, sample_ties_kernel, dim3(sx_div_up(cap, kBlock)), dim3(kBlock),
+              (const uint64_t *)(in_b ? kb : ka), cap, bins);
+    uint32_t h_bins[2 * kSampleBins];
+    SX_TRY(sx_readback(ctx, bins, 2 * kSampleBins, h_bins));
+    uint64_t tied = 0, S = 0;
+    for (uint32_t i = 0; i < kSampleBins; ++i) tied += h_bins[i], S += h_bins[kSampleBins + i];
+    if (S < 1024) return 0;
     *share = (double)tied / (double)S;
     return 0;
 }

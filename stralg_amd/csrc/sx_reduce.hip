@@ -91,6 +91,47 @@ struct OutGidRank {
     }
 };
 
+// the same after a round: a member's rank is written only where its group's number changed.  A group's number is a
+// list position inside the group (any one: the intervals of different groups do not overlap, so the numbers order the
+// groups); the sub-group that holds the old number's position keeps it, and with it the ranks of all its members --
+// in a collection of near-identical sequences most rounds only peel one member off a group, and the scattered write
+// of every member's rank was the most expensive step of a round (8.7 of 20 ms at 3.1e8 names).  Groups split by the
+// radix sorts are numbered by their first member's position: the first sub-group keeps the number, if the old one was
+// the group's first position.  oldkeys: (old group number << rb | rank ahead), slot by slot
+struct OutGidRankChanged {
+    const uint32_t *sa;
+    uint32_t *gid, *rank;
+    const uint64_t *oldkeys;
+    uint32_t rb;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const
+    {
+        const uint32_t g = (excl > v ? excl : v) - 1u;
+        gid[t] = g;
+        if ((uint32_t)(oldkeys[t] >> rb) != g) rank[sa[t]] = g;
+    }
+};
+// the members the radix sorts ordered inside a wave-tier round (sorted sub-list slot j = list slot sub_t[j])
+struct InSubHeadPos {
+    const uint64_t *k2s;
+    const uint32_t *sub_t, *pos2;
+    __device__ __forceinline__ uint32_t operator()(uint64_t j) const
+    {
+        return (j == 0 || k2s[j] != k2s[j - 1]) ? pos2[sub_t[j]] + 1u : 0u;
+    }
+};
+struct OutSubGidRank {
+    const uint64_t *k2s;
+    const uint32_t *sas, *sub_t;
+    uint32_t *gid, *rank;
+    uint32_t rb;
+    __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const
+    {
+        const uint32_t g = (excl > v ? excl : v) - 1u;
+        gid[sub_t[j]] = g;
+        if ((uint32_t)(k2s[j] >> rb) != g) rank[sas[j]] = g;
+    }
+};
+
 // keep the members of groups with more than one element
 struct InKeep {
     const uint8_t *head;
@@ -170,7 +211,9 @@ __global__ __launch_bounds__(kBlock) void doubling_wave_groups_kernel(const uint
                                                                       uint8_t *__restrict__ head2,
                                                                       uint32_t *__restrict__ sa_r,
                                                                       uint8_t *__restrict__ done,
-                                                                      uint32_t *__restrict__ n_heads)
+                                                                      uint32_t *__restrict__ n_heads,
+                                                                      uint32_t *__restrict__ gid_out,
+                                                                      uint32_t *__restrict__ rank)
 {
     const uint64_t base = ((uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)wave_id()) * kWaveStride;
     if (base >= A) return; // (the whole wave)
@@ -199,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void doubling_wave_groups_kernel(const uint
     const int my_end = later ? __ffsll((unsigned long long)later) - 1 : kWave; // lane after the group's last member
     uint32_t reach = owned ? (uint32_t)(my_end - first) : 0u;
     reach = wave_reduce_max(reach);
-    uint32_t less = 0, same_left = 0;
+    uint32_t less = 0, same_left = 0, same_right = 0;
     if (reach <= 24u) { // uniform
         for (uint32_t o = 1; o < reach; ++o) {
             const uint32_t gu = __shfl_up(g, o, kWave), ru = __shfl_up(r, o, kWave);
@@ -208,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void doubling_wave_groups_kernel(const uint
             less += (mate_u && ru < r) ? 1u : 0u;
             same_left += (mate_u && ru == r) ? 1u : 0u;
             less += (mate_d && rd < r) ? 1u : 0u;
+            same_right += (mate_d && rd == r) ? 1u : 0u;
         }
     } else {
 #pragma unroll
@@ -216,16 +260,24 @@ __global__ __launch_bounds__(kBlock) void doubling_wave_groups_kernel(const uint
             const bool mate = gd == g;
             less += (mate && rd < r) ? 1u : 0u;
             same_left += (mate && rd == r && d < l) ? 1u : 0u;
+            same_right += (mate && rd == r && d > l) ? 1u : 0u;
         }
     }
     const int at = first + (int)(less + same_left); // lane whose slot the member moves to
     const uint32_t p_at = __shfl(ps, at < 0 ? 0 : at, kWave);
+    const uint32_t p_first = __shfl(ps, first < 0 ? 0 : first, kWave); // (a group's list positions are consecutive)
     if (owned) {
         const uint64_t slot = base + (uint64_t)at;
         v_out[slot] = val;
         head2[slot] = same_left == 0 ? 1 : 0; // first of its run of equal ranks (the group's first member included)
         sa_r[p_at] = val;
         done[slot] = 1;
+        // the members of equal rank ahead form a sub-group at positions p_first + less ... + same: it keeps the group's
+        // number if that position is one of its own (nothing to write then), and takes its middle position otherwise
+        const uint32_t same = same_left + same_right + 1u, at_g = g - p_first;
+        const uint32_t g_new = (at_g >= less && at_g < less + same) ? g : p_first + less + ((same - 1u) >> 1);
+        gid_out[slot] = g_new;
+        if (g_new != g) rank[val] = g_new;
     }
     count_heads(owned && same_left == 0, n_heads);
 }
@@ -315,13 +367,16 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
     uint64_t A = M;
     uint64_t h = q;
     bool waves_pay = true; // until a round leaves more than a quarter of its members to the radix sorts all the same
+    // a. group numbers and ranks of all suffixes; the rounds keep both up to date (a rank is written again only where
+    // the group's number changed).  The numbers travel with the list in one of two arrays, the other is a round's scratch
+    // (the reduced string itself is not read again once its names are packed)
+    uint32_t *gid = rb.gid, *gid2 = rb.R;
+    SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidRank{sa, gid, rb.rank}, nullptr, SX_KC_DOUBLING,
+                               A * (1 + 4 + 4 + 4 + 4))));
     for (int round = 0; round < 64; ++round) {
-        // a. group ids and ranks of the active suffixes
-        SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidRank{sa, rb.gid, rb.rank}, nullptr,
-                                   SX_KC_DOUBLING, A * (1 + 4 + 4 + 4 + 4))));
         // b+d. drop singleton groups; build (group, rank[i+h]) keys for the rest
         SX_TRY((device_compact(ctx, A, InKeep{head, A},
-                                   OutKeep{pos, sa, rb.gid, rb.rank, pos2, vfree, kfree, h, M, rbits},
+                                   OutKeep{pos, sa, gid, rb.rank, pos2, vfree, kfree, h, M, rbits},
                                    rb.d_scalar, SX_KC_DOUBLING, A * (2 + 4 + 4 + 4 + 4 + 16))));
         uint32_t A2 = 0;
         SX_TRY(sx_readback(ctx, rb.d_scalar, 1, &A2));
@@ -346,10 +401,10 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
             const uint64_t waves = sx_div_up(A2, kWaveStride);
             sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A2 * (8 + 4 + 4 + 4 + 4 + 2), doubling_wave_groups_kernel,
                       dim3(sx_div_up(waves, kWavesPerBlock)), block, (const uint64_t *)kfree, (const uint32_t *)vfree,
-                      (const uint32_t *)pos2, (uint64_t)A2, rbits, sa, head2, rb.sa_r, done, n_heads);
+                      (const uint32_t *)pos2, (uint64_t)A2, rbits, sa, head2, rb.sa_r, done, n_heads, gid2, rb.rank);
             // the members of groups no wave owned: radix sorts of the compacted sub-list, then back to their slots
             uint64_t *k_in = ks;     // (the sorted keys are not needed once the groups are marked)
-            uint32_t *v_in = rb.gid; // (free after the compaction above)
+            uint32_t *v_in = gid;    // (free after the compaction above)
             SX_TRY((device_compact(ctx, A2, InNotDone{done}, OutNotDone{kfree, vfree, k_in, v_in, rb.sub_t},
                                    rb.d_scalar + 1, SX_KC_DOUBLING, (uint64_t)A2 * 2)));
             uint32_t A3 = 0;
@@ -364,6 +419,11 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
                           dim3(sx_div_up(A3, kBlock)), block, (const uint64_t *)(in_b ? k_other : k_in),
                           (const uint32_t *)(in_b ? v_other : v_in), (const uint32_t *)rb.sub_t, (const uint32_t *)pos2,
                           (uint64_t)A3, sa, rb.sa_r, head2, n_heads);
+                const uint64_t *k2s = in_b ? k_other : k_in;
+                const uint32_t *sas = in_b ? v_other : v_in;
+                SX_TRY((device_scan<OpMax>(ctx, A3, InSubHeadPos{k2s, rb.sub_t, pos2},
+                                           OutSubGidRank{k2s, sas, rb.sub_t, gid2, rb.rank, rbits}, nullptr, SX_KC_DOUBLING,
+                                           (uint64_t)A3 * (8 + 4 + 4 + 4 + 4 + 4))));
             }
         } else {
             // e. sort the active suffixes inside their groups by the rank h symbols ahead
@@ -380,11 +440,14 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
                       dim3(sx_div_up(A2, kBlock)), block, (const uint64_t *)ks, (const uint32_t *)vs,
                       (const uint32_t *)pos2, (uint64_t)A2, rb.sa_r, head2, n_heads);
             sa = vs;
+            SX_TRY((device_scan<OpMax>(ctx, A2, InHeadPos{head2, pos2}, OutGidRankChanged{sa, gid2, rb.rank, ks, rbits},
+                                       nullptr, SX_KC_DOUBLING, (uint64_t)A2 * (1 + 4 + 4 + 8 + 4 + 4))));
         }
         A = A2;
         h *= 2;
         uint32_t *tp = pos; pos = pos2; pos2 = tp;
         uint8_t *th = head; head = head2; head2 = th;
+        uint32_t *tg = gid; gid = gid2; gid2 = tg;
     }
     return sx_fail_msg(ctx, SX_E_INTERNAL, "doubling: did not converge");
 }
