@@ -512,6 +512,39 @@ def test_reduced_string_recursion(emu_ctx):
         emu_ctx.set_recurse_min(-1)
 
 
+def test_doubling_group_numbers_survive_splits(emu_ctx):
+    """collections of near-identical sequences through the general path: groups of as many members as copies lose a
+    member or two a round; the sub-group that holds the group's number keeps it (no rank is written for its members),
+    the others take their middle position -- wave tier, the radix sub-list for long groups, and the plain-passes mode"""
+    rng = np.random.default_rng(11)
+    try:
+        emu_ctx.force_general_path(True)
+        seen = 0
+        for sigma, L, copies, div, mode in ((5, 1500, 16, 0.001, 0), (5, 700, 39, 0.01, 0), (9, 2500, 28, 0.001, 0),
+                                            (28, 380, 25, 0.001, 0), (28, 3000, 21, 0.0, 0), (5, 2000, 12, 0.01, 1),
+                                            (3, 2900, 34, 0.001, 1)):
+            g = rng.integers(1, sigma, size=L, dtype=np.uint8)
+            parts = []
+            for _ in range(copies):
+                x = g.copy()
+                mm = rng.random(L) < div
+                x[mm] = rng.integers(1, sigma, size=int(mm.sum()), dtype=np.uint8)
+                parts.append(x)
+            x = np.concatenate(parts)
+            emu_ctx.set_sort_mode(mode)
+            sa, bw = np.zeros(x.size + 1, np.uint32), np.zeros(x.size + 1, np.uint8)
+            emu_ctx.sa_bwt_build_dev(x, x.size, sigma, sa, bw)
+            want = oracle.sa_is_strict(x, sigma)
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (sigma, L, copies, div, mode)
+            st = emu_ctx.last_stats()
+            assert st["lms_path"] == 2 and st["doubling_rounds"] >= 3, st
+            seen |= st["refine_tiers"]
+        assert seen & 4 and seen & 8, seen  # the wave tier and the radix sorts both ordered groups
+    finally:
+        emu_ctx.force_general_path(False)
+        emu_ctx.set_sort_mode(0)
+
+
 def test_look_at_a_sample_before_the_prefix_sorts(emu_ctx):
     """texts of more than 8 symbols: the tied share of a sample under the longest 63-bit key decides whether the prefix-key
     sorts are tried at all (a word text ties most of its suffixes and goes to the general path at once; random symbols
