@@ -45,7 +45,8 @@ constexpr int kInvThreads = 512, kInvItems = 16, kInvTile = kInvThreads * kInvIt
 #define SX_INV_WINDOW_BITS 19 // (the CPU test harness builds with 8: several partitions on small arrays)
 #endif
 constexpr uint32_t kInvWindowBits = SX_INV_WINDOW_BITS, kInvMaxParts = 8192; // N <= 2^32: at most 8192 partitions of 2^19
-__global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const uint32_t *__restrict__ sa, uint64_t N, uint32_t nparts, uint32_t wbits,
+__global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ values /* or null: the index */,
+                                                                         uint64_t N, uint32_t nparts, uint32_t wbits,
                                                                          uint32_t *__restrict__ cursor /* entries dealt into each partition so far */,
                                                                          uint2 *__restrict__ pairs, uint32_t *__restrict__ bad)
 {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const ui
                 const uint32_t base = cnt[p[k] >> wbits];
                 if (base != 0xFFFFFFFFu) {
                     uint2 e;
-                    e.x = p[k], e.y = (uint32_t)i;
+                    e.x = p[k], e.y = values ? values[i] : (uint32_t)i;
                     pairs[(uint64_t)base + r[k]] = e;
                 }
             }
@@ -246,28 +247,42 @@ using namespace sx;
 #ifndef SX_INVERSE_TWO_PASS_FROM
 #define SX_INVERSE_TWO_PASS_FROM (1ull << 23) // (shorter arrays' targets fit the caches as they are)
 #endif
-static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv)
+bool sx_scatter_permutation_applies(uint64_t N) { return N >= SX_INVERSE_TWO_PASS_FROM; }
+size_t sx_scatter_permutation_cursor_words() { return kInvMaxParts; }
+// out[targets[i]] = values[i] (values == null: i) for a permutation `targets` of [0, N), in the two passes above.
+// pairs: N x 8 bytes, cursor: sx_scatter_permutation_cursor_words() words, bad: one word the caller has zeroed (counts
+// what is not a permutation)
+int sx_scatter_permutation(sx_ctx *ctx, const uint32_t *targets, const uint32_t *values, uint64_t N, uint32_t *out, void *pairs_scratch,
+                           uint32_t *cursor, uint32_t *bad, int kclass)
 {
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, 4096));
-    uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
-    SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
     // (2^28 entries, same box: windows of 2^16 ... 2^21 targets 6.1, 6.2, 5.2, 5.0, 5.3, 6.2 ms; the second pass in plain
     //  workgroup order instead of XCD by XCD 5.4; the single-pass kernel 9.9)
     uint32_t wbits = kInvWindowBits;
     const int by_xcd = 1;
     while (((N + (1ull << wbits) - 1) >> wbits) > kInvMaxParts) ++wbits;
-    if (N >= SX_INVERSE_TWO_PASS_FROM) {
-        const uint32_t nparts = (uint32_t)((N + (1ull << wbits) - 1) >> wbits);
+    const uint32_t nparts = (uint32_t)((N + (1ull << wbits) - 1) >> wbits);
+    uint2 *pairs = (uint2 *)pairs_scratch;
+    SX_CHECK(hipMemsetAsync(cursor, 0, (size_t)nparts * 4, ctx->stream));
+    uint32_t grid = sx_div_up(N, kInvTile);
+    if (grid > 4096) grid = 4096;
+    sx_launch(ctx, kclass, N * (values ? 16 : 12), inverse_partition_kernel, dim3(grid), dim3(kInvThreads), targets, values, N, nparts, wbits,
+              cursor, pairs, bad);
+    const uint64_t chunks = (N + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
+    sx_launch(ctx, kclass, N * 12, inverse_apply_kernel, dim3((uint32_t)(((chunks + 7) / 8) * 8)), dim3(kBlock), (const uint2 *)pairs, N, out,
+              by_xcd);
+    return 0;
+}
+
+static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv)
+{
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, 4096));
+    uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
+    SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+    if (sx_scatter_permutation_applies(N)) {
         SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, N * sizeof(uint2) + (size_t)kInvMaxParts * 4 + 512));
         uint32_t *cursor = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
-        uint2 *pairs = (uint2 *)((char *)ctx->slab[SX_SLAB_SORT].p + (size_t)kInvMaxParts * 4 + 256);
-        SX_CHECK(hipMemsetAsync(cursor, 0, (size_t)nparts * 4, ctx->stream));
-        uint32_t grid = sx_div_up(N, kInvTile);
-        if (grid > 4096) grid = 4096;
-        sx_launch(ctx, SX_KC_LCP, N * 12, inverse_partition_kernel, dim3(grid), dim3(kInvThreads), d_sa, N, nparts, wbits, cursor, pairs, bad);
-        const uint64_t chunks = (N + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
-        sx_launch(ctx, SX_KC_LCP, N * 12, inverse_apply_kernel, dim3((uint32_t)(((chunks + 7) / 8) * 8)), dim3(kBlock), (const uint2 *)pairs, N,
-                  d_inv, by_xcd);
+        void *pairs = (char *)ctx->slab[SX_SLAB_SORT].p + (size_t)kInvMaxParts * 4 + 256;
+        SX_TRY(sx_scatter_permutation(ctx, d_sa, nullptr, N, d_inv, pairs, cursor, bad, SX_KC_LCP));
     } else {
         sx_launch(ctx, SX_KC_LCP, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
     }

@@ -102,6 +102,13 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);
 int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
               const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena);
 
+// ---- sx_extras.hip: out[targets[i]] = values[i] (null: i) for a permutation of [0, N), in two passes that keep the stores
+// inside windows the L2 holds (half the time of the plain scatter from 2^23 entries on)
+bool sx_scatter_permutation_applies(uint64_t N);
+size_t sx_scatter_permutation_cursor_words();
+int sx_scatter_permutation(sx_ctx *ctx, const uint32_t *targets, const uint32_t *values, uint64_t N, uint32_t *out, void *pairs_scratch,
+                           uint32_t *cursor, uint32_t *bad, int kclass);
+
 // ---- sx_build.hip / sx_bwt.hip (shared by the fused host entry point)
 int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t sigma, uint32_t *d_sa, uint8_t *d_bwt);
 int sx_tables_from_bwt_impl(sx_ctx *ctx, const uint8_t *d_bwt, uint64_t N, uint32_t sigma, uint32_t *d_c, uint32_t *d_o);

@@ -33,6 +33,11 @@ struct OutNames {
     }
 };
 
+struct OutNamesInOrder { // (the names in sorted order: the two-pass scatter takes them to their places)
+    uint32_t *names;
+    __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const { names[j] = excl + v; }
+};
+
 // ---- prefix doubling -------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void pack_names_kernel(const uint32_t *__restrict__ R, uint64_t M,
                                                             uint32_t b, uint32_t q, uint64_t *__restrict__ keys,
@@ -91,6 +96,10 @@ struct OutGidRank {
     }
 };
 
+struct OutGidOnly { // (the ranks follow by the two-pass scatter)
+    uint32_t *gid;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t v) const { gid[t] = (excl > v ? excl : v) - 1u; }
+};
 // the same after a round: a member's rank is written only where its group's number changed.  A group's number is a
 // list position inside the group (any one: the intervals of different groups do not overlap, so the numbers order the
 // groups); the sub-group that holds the old number's position keeps it, and with it the ranks of all its members --
@@ -333,8 +342,18 @@ using namespace sx;
 int sx_name_pieces(sx_ctx *ctx, const uint64_t *ks, const uint32_t *vs, uint64_t M, sx_reduce_bufs &rb,
                    uint64_t *n_names)
 {
-    SX_TRY((device_compact(ctx, M, InKeyBoundary{ks}, OutNames{vs, rb.R}, rb.d_scalar, SX_KC_NAMES,
+    const bool two_pass = sx_scatter_permutation_applies(M) && M > sx_scatter_permutation_cursor_words() + 64;
+    if (two_pass) {
+        // R[vs[j]] = name of sorted piece j is one random 4-byte store a sample (3.1e8: 11.5 ms); the names in sorted
+        // order first, then the two passes of sx_extras.hip (the sort buffer the pieces did not end in holds the pairs)
+        SX_TRY((device_compact(ctx, M, InKeyBoundary{ks}, OutNamesInOrder{rb.rank}, rb.d_scalar, SX_KC_NAMES, M * (2 * 8 + 4))));
+        uint32_t *cursor = rb.sub_t, *bad = rb.sub_t + sx_scatter_permutation_cursor_words();
+        SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+        SX_TRY(sx_scatter_permutation(ctx, vs, rb.rank, M, rb.R, ks == rb.ka ? (void *)rb.kb : (void *)rb.ka, cursor, bad, SX_KC_NAMES));
+    } else {
+        SX_TRY((device_compact(ctx, M, InKeyBoundary{ks}, OutNames{vs, rb.R}, rb.d_scalar, SX_KC_NAMES,
                                M * (2 * 8 + 4 + 4))));
+    }
     uint32_t boundaries = 0;
     SX_TRY(sx_readback(ctx, rb.d_scalar, 1, &boundaries));
     *n_names = (uint64_t)boundaries + 1;
@@ -371,8 +390,17 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
     // the group's number changed).  The numbers travel with the list in one of two arrays, the other is a round's scratch
     // (the reduced string itself is not read again once its names are packed)
     uint32_t *gid = rb.gid, *gid2 = rb.R;
-    SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidRank{sa, gid, rb.rank}, nullptr, SX_KC_DOUBLING,
-                               A * (1 + 4 + 4 + 4 + 4))));
+    if (sx_scatter_permutation_applies(M) && M > sx_scatter_permutation_cursor_words() + 64) {
+        // (every suffix's first rank: 3.1e8 random 4-byte stores took 13.6 ms; the numbers in list order, then the two
+        // passes of sx_extras.hip, the pairs in the free key buffer)
+        SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidOnly{gid}, nullptr, SX_KC_DOUBLING, A * (1 + 4 + 4))));
+        uint32_t *cursor = rb.sub_t, *bad = rb.sub_t + sx_scatter_permutation_cursor_words();
+        SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+        SX_TRY(sx_scatter_permutation(ctx, sa, gid, M, rb.rank, kfree, cursor, bad, SX_KC_DOUBLING));
+    } else {
+        SX_TRY((device_scan<OpMax>(ctx, A, InHeadPos{head, pos}, OutGidRank{sa, gid, rb.rank}, nullptr, SX_KC_DOUBLING,
+                                   A * (1 + 4 + 4 + 4 + 4))));
+    }
     for (int round = 0; round < 64; ++round) {
         // b+d. drop singleton groups; build (group, rank[i+h]) keys for the rest
         SX_TRY((device_compact(ctx, A, InKeep{head, A},
