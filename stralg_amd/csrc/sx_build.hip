@@ -12,6 +12,7 @@
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_internal.hpp"
+#include "sx_window.hpp"
 #include "sx_pager.hpp"
 
 #include <chrono>
@@ -293,7 +294,19 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
             SX_TRY(sx_reduced_suffix_sort(ctx, M, n_names, rb));
             sa_r = rb.sa_r;
         }
-        SX_TRY(sx_sorted_lms(ctx, sa_r, pos, is_lms, M, ti.m, slms, rb.d_scalar));
+        {
+            // positions and windows of the sorted LMS suffixes from one gather; the scratch: the key buffers (32-bit
+            // windows), or the key buffers as one and the four list arrays as the other (64-bit windows: 16 bytes a sample)
+            wnd_cfg wc;
+            const bool wide = sx_window_cfg(ti.maxc, wc);
+            void *buf_a = rb.ka, *buf_b = wide ? (void *)rb.pos_a : (void *)rb.kb;
+            const bool room = !wide || ((char *)rb.kb + M * 8 >= (char *)rb.ka + M * 16 && (char *)rb.sub_t + M * 4 >= (char *)rb.pos_a + M * 16 &&
+                                        (char *)rb.kb > (char *)rb.ka && (char *)rb.sub_t > (char *)rb.pos_a);
+            if (room)
+                SX_TRY(sx_sorted_lms_windows(ctx, ti, sa_r, pos, is_lms, M, ti.m, buf_a, buf_b, slms, &seed_windows, rb.d_scalar));
+            else
+                SX_TRY(sx_sorted_lms(ctx, sa_r, pos, is_lms, M, ti.m, slms, rb.d_scalar));
+        }
         uint32_t got = 0;
         SX_TRY(sx_readback(ctx, rb.d_scalar, 1, &got));
         if (got != ti.m) return sx_fail_msg(ctx, SX_E_INTERNAL, "sorted LMS count differs from the LMS count");

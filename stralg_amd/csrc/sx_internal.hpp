@@ -72,6 +72,12 @@ int sx_reduced_suffix_sort(sx_ctx *ctx, uint64_t M, uint64_t n_names, sx_reduce_
 int sx_sorted_lms(sx_ctx *ctx, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms, uint64_t M,
                   uint64_t m, uint32_t *sorted_lms, uint32_t *d_total);
 
+// the same with every suffix's window (sx_window.hpp; what sx_induce takes as seed_windows) from one gather; buf_a, buf_b:
+// scratch of M x 8 bytes each (M x 16 for texts of more than 16 symbols, whose windows are 64-bit words); *seed_windows
+// lies in one of them
+int sx_sorted_lms_windows(sx_ctx *ctx, const sx_text_info &ti, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms, uint64_t M,
+                          uint64_t m, void *buf_a, void *buf_b, uint32_t *sorted_lms, const void **seed_windows, uint32_t *d_total);
+
 // ---- sx_lmssort.hip
 size_t sx_lms_prefix_bytes(uint64_t m);
 int sx_bwt_from_seed_windows(sx_ctx *ctx, const uint32_t *seedw, uint64_t N, uint32_t maxc, uint8_t *bwt_out);

@@ -1224,6 +1224,15 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 ctx->stats.sort_local = 1u | (res[1] & 2u) | (top_bits == 32 ? 4u : 0u); // (bit 1: some workgroup ordered its pairs by stable passes)
             } else {
                 // a sub-bucket too long for a workgroup (a repeated prefix): plain LSD passes over all key bits from here
+                // -- unless the workgroups that did finish have listed more tied suffixes already than the refinement
+                // takes, and more than a longer key would be tried for: the general path's turn at once (a collection of
+                // near-identical sequences: five passes over all pairs and the pass that marks the ties, 11 of 210 ms)
+                if (res[0] > cap - 1024 && (attempt != 0 || C >= Cmax || (uint64_t)res[0] * 2 > m)) {
+                    ctx->stats.n_names = m - res[0];
+                    ctx->stats.key_slots = C;
+                    ctx->stats.key_bits = (uint32_t)kbits;
+                    return 0;
+                }
                 uint64_t *k0 = in_b ? kb : ka, *k1 = in_b ? ka : kb;
                 uint32_t *v0 = in_b ? vb : va, *v1 = in_b ? va : vb;
                 int f = 0;

@@ -13,6 +13,7 @@
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
 #include "sx_internal.hpp"
+#include "sx_window.hpp"
 
 namespace sx {
 
@@ -335,9 +336,96 @@ __global__ __launch_bounds__(kBlock) void gather_pos_kernel(const uint32_t *__re
     if (j == 0) *d_total = (uint32_t)M;
 }
 
+// ---- sorted LMS suffixes with their windows: one random read a suffix ----------------------------------------------------
+// The induction starts from (position, window of the symbols to its left) of every sorted LMS suffix.  pos[sa_r[j]]
+// and then the text around that position were two random reads a suffix (gather_pos + fill_windows: 13.6 ms at
+// 3.1e8).  The windows are cheap in *text* order (the samples' positions ascend: the text is read front to back),
+// so they are made there, next to the position (cuts: no position), and one gather in suffix order fetches both.
+constexpr uint32_t kNoLms = 0xFFFFFFFFu;
+template <class WT> struct pos_wnd;
+template <> struct pos_wnd<uint32_t> { uint32_t p, w; };                       // 8 bytes
+template <> struct __attribute__((aligned(16))) pos_wnd<uint64_t> { uint32_t p, pad; uint64_t w; }; // 16 bytes
+
+template <class WT>
+__global__ __launch_bounds__(kBlock) void sample_windows_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ pos,
+                                                               const uint8_t *__restrict__ is_lms, uint64_t M, wnd_cfg cfg,
+                                                               pos_wnd<WT> *__restrict__ pw)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= M) return;
+    const uint32_t p = pos[k];
+    pos_wnd<WT> e = {};
+    e.p = is_lms[k] ? p : kNoLms;
+    e.w = (is_lms[k] && p) ? wnd_fill<WT>(T, p, cfg) : (WT)0;
+    pw[k] = e;
+}
+// every sample is an LMS position: straight to the outputs
+template <class WT>
+__global__ __launch_bounds__(kBlock) void gather_pos_windows_kernel(const uint32_t *__restrict__ sa_r, const pos_wnd<WT> *__restrict__ pw,
+                                                                   uint64_t M, uint32_t *__restrict__ out_pos, WT *__restrict__ out_w,
+                                                                   pos_wnd<WT> *__restrict__ out_pw /* or null */, uint32_t *__restrict__ d_total)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < M) {
+        const pos_wnd<WT> e = pw[sa_r[j]];
+        if (out_pw) out_pw[j] = e;
+        else out_pos[j] = e.p, out_w[j] = e.w;
+    }
+    if (j == 0 && d_total) *d_total = (uint32_t)M;
+}
+template <class WT> struct InHasLms {
+    const pos_wnd<WT> *g;
+    __device__ __forceinline__ uint32_t operator()(uint64_t j) const { return g[j].p != kNoLms ? 1u : 0u; }
+};
+template <class WT> struct OutPosWindow {
+    const pos_wnd<WT> *g;
+    uint32_t *out_pos;
+    WT *out_w;
+    __device__ __forceinline__ void operator()(uint64_t j, uint32_t excl, uint32_t v) const
+    {
+        if (v) out_pos[excl] = g[j].p, out_w[excl] = g[j].w;
+    }
+};
+
 } // namespace sx
 
 using namespace sx;
+
+template <class WT>
+static int sorted_lms_windows_typed(sx_ctx *ctx, const sx_text_info &ti, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms,
+                                    uint64_t M, uint64_t m, void *buf_a, void *buf_b, uint32_t *sorted_lms, const void **seed_windows,
+                                    uint32_t *d_total, const wnd_cfg &cfg)
+{
+    pos_wnd<WT> *pw = (pos_wnd<WT> *)buf_a;
+    sx_launch(ctx, SX_KC_DOUBLING, M * (5 + sizeof(pos_wnd<WT>)) + ti.N, sample_windows_kernel<WT>, dim3(sx_div_up(M, kBlock)), dim3(kBlock),
+              ti.T, pos, is_lms, M, cfg, pw);
+    if (M == m) {
+        WT *seed = (WT *)buf_b;
+        sx_launch(ctx, SX_KC_DOUBLING, M * (4 + 64 + 4 + sizeof(WT)), gather_pos_windows_kernel<WT>, dim3(sx_div_up(M, kBlock)), dim3(kBlock),
+                  sa_r, (const pos_wnd<WT> *)pw, M, sorted_lms, seed, (pos_wnd<WT> *)nullptr, d_total);
+        *seed_windows = seed;
+        return 0;
+    }
+    // cuts among the samples: both fields in suffix order first, then the compaction reads them front to back
+    pos_wnd<WT> *g = (pos_wnd<WT> *)buf_b;
+    sx_launch(ctx, SX_KC_DOUBLING, M * (4 + 64 + sizeof(pos_wnd<WT>)), gather_pos_windows_kernel<WT>, dim3(sx_div_up(M, kBlock)), dim3(kBlock),
+              sa_r, (const pos_wnd<WT> *)pw, M, (uint32_t *)nullptr, (WT *)nullptr, g, (uint32_t *)nullptr);
+    WT *seed = (WT *)buf_a; // (the text-order pairs are done with)
+    SX_TRY((device_compact(ctx, M, InHasLms<WT>{g}, OutPosWindow<WT>{g, sorted_lms, seed}, d_total, SX_KC_DOUBLING,
+                           M * 2 * sizeof(pos_wnd<WT>))));
+    *seed_windows = seed;
+    return 0;
+}
+
+// buf_a, buf_b: M x 16 bytes each (M x 8 for texts of at most 16 symbols' windows, which are 32-bit words)
+int sx_sorted_lms_windows(sx_ctx *ctx, const sx_text_info &ti, const uint32_t *sa_r, const uint32_t *pos, const uint8_t *is_lms, uint64_t M,
+                          uint64_t m, void *buf_a, void *buf_b, uint32_t *sorted_lms, const void **seed_windows, uint32_t *d_total)
+{
+    wnd_cfg cfg;
+    const bool wide = sx_window_cfg(ti.maxc, cfg);
+    if (!wide) return sorted_lms_windows_typed<uint32_t>(ctx, ti, sa_r, pos, is_lms, M, m, buf_a, buf_b, sorted_lms, seed_windows, d_total, cfg);
+    return sorted_lms_windows_typed<uint64_t>(ctx, ti, sa_r, pos, is_lms, M, m, buf_a, buf_b, sorted_lms, seed_windows, d_total, cfg);
+}
 
 int sx_name_pieces(sx_ctx *ctx, const uint64_t *ks, const uint32_t *vs, uint64_t M, sx_reduce_bufs &rb,
                    uint64_t *n_names)

@@ -1044,11 +1044,12 @@ def test_duplication_beyond_the_comparison_cap(gpu_ctx):
 
 
 def test_near_identical_copies_double_by_waves(gpu_ctx):
-    """16 copies of one random 1 Mi-symbol text with 0.1 % of the symbols replaced (what a collection of assemblies of one
+    """16 copies of one random 2 Mi-symbol text with 0.1 % of the symbols replaced (what a collection of assemblies of one
     species looks like): the general path's doubling rounds order the groups of 16 by one wave each; the plain-passes
-    mode orders them by radix sorts; both match the oracle"""
+    mode orders them by radix sorts; both match the oracle.  More than 2^23 samples: names and first ranks take the
+    two-pass permutation scatter"""
     rng = np.random.default_rng(23)
-    one = rng.integers(1, 5, size=1 << 20, dtype=np.uint8)
+    one = rng.integers(1, 5, size=1 << 21, dtype=np.uint8)
     parts = []
     for _ in range(16):
         c = one.copy()
@@ -1062,7 +1063,7 @@ def test_near_identical_copies_double_by_waves(gpu_ctx):
             gpu_ctx.set_sort_mode(mode)
             assert (gpu_ctx.sa_build(x, 5) == want).all(), mode
             st = gpu_ctx.last_stats()
-            assert st["lms_path"] == 2 and st["refine_tiers"] & bits, (mode, st)
+            assert st["lms_path"] == 2 and st["refine_tiers"] & bits and st["n_samples"] > 1 << 23, (mode, st)
     finally:
         gpu_ctx.set_sort_mode(0)
 
