@@ -176,11 +176,15 @@ void dealloc_fasta_iter(struct fasta_iter *iter);
 int stralg_amd_set_device(int device);
 /* release the calling thread's context and its cached device memory */
 void stralg_amd_release(void);
-/* Build tables for `count` independent strings over the listed devices, one host thread per device, each pinned
- * to its GPU's NUMA node; strings are dealt longest first to the least loaded device (LPT by length).
+/* Build tables for `count` independent strings over the listed devices by host threads pinned to their GPU's NUMA
+ * node -- one a device for long records, up to four for records too short to fill a GPU
+ * (stralg_amd_farm_workers_per_device); strings are dealt longest first to the least loaded worker (LPT by length).
  * out[k] receives build_complete_table(strings[k], ...). */
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out);
+/* workers (contexts, host threads) the farm runs on each device for records of these lengths; $STRALG_AMD_FARM_WORKERS
+ * overrides */
+int stralg_amd_farm_workers_per_device(const size_t *lengths, size_t count, int n_devices);
 /* the assignment the farm uses: assignment[k] = lane (0 .. lanes-1) of record k */
 int stralg_amd_lpt_assign(const size_t *lengths, size_t count, int lanes, int *assignment);
 /* pin the calling thread to the CPUs of `device`'s NUMA node; returns the node, or -1 when it is unknown */

@@ -878,7 +878,7 @@ bool next_fasta_record(struct fasta_iter *iter, struct fasta_record *rec)
 
 void dealloc_fasta_iter(struct fasta_iter *iter) { (void)iter; }
 
-/* ---- batch farm: independent records, one host thread per GPU ------------------------
+/* ---- batch farm: independent records, host threads per GPU ------------------------------
  * Records are dealt longest first to the device with the least work so far (LPT by length, SURVEY.md section 8e:
  * a build's time is close to linear in the record's length), and every worker thread is pinned to the CPUs of
  * its GPU's NUMA node (sx_device_numa_node reads the PCI device's node from sysfs): its staging copies and the
@@ -978,10 +978,61 @@ int stralg_amd_lpt_assign(const size_t *lengths, size_t count, int lanes, int *a
     return 0;
 }
 
+/* Workers a device.  A record too short to fill the GPU leaves it idle between its launches and read-backs (a build
+ * takes 0.45 ms however short the record; 2^22 symbols: 0.85 ms = 4.9 Gsuffixes/s against 46 at 2^30), and a host-buffer
+ * call spends most of its time on the host (page faults of the malloc'd tables, staging copies).  Several workers a
+ * device -- each with its own context, stream and workspace -- fill those gaps: resident data, one MI355X, four workers:
+ * 3.3 - 3.7 times the records per second up to 2^20 symbols, 2.7 times at 2^22, 2.2 times at 2^24
+ * (tools/small_concurrent.py).  By the longest record (a worker's workspace grows with it: 24 B a symbol + the tables):
+ * up to 2^24 symbols 4, up to 2^26 2, longer records 1; never more workers than records a device;
+ * $STRALG_AMD_FARM_WORKERS overrides (1 ... 16). */
+int stralg_amd_farm_workers_per_device(const size_t *lengths, size_t count, int n_devices)
+{
+    if (n_devices <= 0 || count == 0) return 1;
+    int w = 1;
+    const char *env = getenv("STRALG_AMD_FARM_WORKERS");
+    if (env && *env) {
+        const long v = strtol(env, NULL, 10);
+        w = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
+    } else {
+        size_t longest = 0;
+        for (size_t k = 0; k < count; ++k)
+            if (lengths[k] > longest) longest = lengths[k];
+        w = longest <= ((size_t)1 << 24) ? 4 : (longest <= ((size_t)1 << 26) ? 2 : 1);
+    }
+    const size_t per_device = (count + (size_t)n_devices - 1) / (size_t)n_devices;
+    if ((size_t)w > per_device) w = (int)per_device;
+    return w < 1 ? 1 : w;
+}
+
+static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count, bool include_reverse, const int *devices,
+                                    int n_devices, struct bwt_table **out, const size_t *lengths_in);
+
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out)
 {
     if (!strings || !out || n_devices <= 0 || !devices) return -1;
+    size_t *lengths = malloc((count ? count : 1) * sizeof *lengths);
+    if (!lengths) return -2;
+    for (size_t k = 0; k < count; ++k) lengths[k] = strlen((const char *)strings[k]);
+    /* every device `workers` times in the list of lanes, device-major: LPT deals the records over all of them */
+    const int workers = stralg_amd_farm_workers_per_device(lengths, count, n_devices);
+    int *lanes = malloc((size_t)n_devices * (size_t)workers * sizeof *lanes);
+    if (!lanes) {
+        free(lengths);
+        return -2;
+    }
+    for (int w = 0; w < workers; ++w)
+        for (int d = 0; d < n_devices; ++d) lanes[w * n_devices + d] = devices[d];
+    const int rc = build_tables_batch_lanes(strings, count, include_reverse, lanes, n_devices * workers, out, lengths);
+    free(lanes);
+    free(lengths);
+    return rc;
+}
+
+static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count, bool include_reverse, const int *devices,
+                                    int n_devices, struct bwt_table **out, const size_t *lengths_in)
+{
     pthread_t *threads = malloc((size_t)n_devices * sizeof *threads);
     struct farm_job *jobs = malloc((size_t)n_devices * sizeof *jobs);
     size_t *lengths = malloc((count ? count : 1) * sizeof *lengths);
@@ -991,7 +1042,7 @@ int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, b
         free(threads), free(jobs), free(lengths), free(lane), free(order);
         return -2;
     }
-    for (size_t k = 0; k < count; ++k) lengths[k] = strlen((const char *)strings[k]);
+    for (size_t k = 0; k < count; ++k) lengths[k] = lengths_in[k];
     int rc = stralg_amd_lpt_assign(lengths, count, n_devices, lane);
     if (rc == 0) {
         /* every lane's records, longest first, as consecutive runs of `order` */

@@ -45,6 +45,32 @@ def test_c_lpt_assignment_matches_python():
     assert lib.stralg_amd_lpt_assign(None, 0, 0, None) == -1
 
 
+def test_c_farm_workers_per_device(monkeypatch):
+    """stralg_amd_farm_workers_per_device: short records get up to four workers a device (never more than records a
+    device), long ones a single worker; $STRALG_AMD_FARM_WORKERS overrides"""
+    import ctypes as C
+    from stralg_amd import _lib
+    lib = _lib.load()
+    fn = lib.stralg_amd_farm_workers_per_device
+    fn.argtypes = [C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
+    fn.restype = C.c_int
+
+    def workers(lengths, devices):
+        arr = (C.c_size_t * max(1, len(lengths)))(*lengths)
+        return fn(arr, len(lengths), devices)
+
+    monkeypatch.delenv("STRALG_AMD_FARM_WORKERS", raising=False)
+    assert workers([1000] * 64, 1) == 4 and workers([1 << 24] * 64, 8) == 4
+    assert workers([(1 << 24) + 1] * 64, 1) == 2 and workers([1 << 26] * 64, 1) == 2
+    assert workers([1 << 30] * 64, 8) == 1 and workers([100, 1 << 27], 1) == 1
+    assert workers([1000] * 3, 1) == 3 and workers([1000] * 8, 8) == 1 and workers([1000] * 9, 8) == 2
+    assert workers([], 4) == 1 and workers([5], 0) == 1
+    monkeypatch.setenv("STRALG_AMD_FARM_WORKERS", "8")
+    assert workers([1 << 30] * 64, 1) == 8 and workers([1000] * 3, 1) == 3
+    monkeypatch.setenv("STRALG_AMD_FARM_WORKERS", "0")
+    assert workers([1000] * 64, 1) == 1
+
+
 def _worker(rank, world, port, emu_lib, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

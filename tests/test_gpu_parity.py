@@ -597,6 +597,55 @@ def test_c_batch_farm_unequal_records(gpu_ctx):
         assert got[0][1] == want_set & os.sched_getaffinity(0) or got[0][1] <= want_set
 
 
+def test_c_batch_farm_many_short_records(gpu_ctx):
+    """40 records of 3 k ... 300 k symbols on one listed device: the farm runs four workers (contexts, streams, host
+    threads) on it; every record against the oracle, with one worker ($STRALG_AMD_FARM_WORKERS=1) and with the default"""
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.c_void_p), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.c_void_p),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.c_void_p)]
+
+    lib = gpu_ctx.lib
+    rng = np.random.default_rng(77)
+    lengths = [int(v) for v in rng.integers(3000, 300000, size=40)]
+    letters = np.frombuffer(b"\0ACGT", dtype=np.uint8)
+    syms = [synth(n, 5, 900 + i) for i, n in enumerate(lengths)]
+    raws = [letters[x].tobytes() for x in syms]
+    want = [oracle.sa_is(x, 5) for x in syms]
+    arr = (C.c_char_p * len(raws))(*raws)
+    devs = (C.c_int * 1)(0)
+    lib.stralg_amd_build_tables_batch.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_bool, C.POINTER(C.c_int), C.c_int,
+                                                  C.POINTER(C.POINTER(BT))]
+    lib.stralg_amd_build_tables_batch.restype = C.c_int
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    lib.stralg_amd_farm_workers_per_device.argtypes = [C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
+    la = (C.c_size_t * len(lengths))(*lengths)
+    old = os.environ.pop("STRALG_AMD_FARM_WORKERS", None)
+    try:
+        assert lib.stralg_amd_farm_workers_per_device(la, len(lengths), 1) == 4
+        for setting in (None, "1"):
+            if setting:
+                os.environ["STRALG_AMD_FARM_WORKERS"] = setting
+            out = (C.POINTER(BT) * len(raws))()
+            assert lib.stralg_amd_build_tables_batch(arr, len(raws), False, devs, 1, out) == 0
+            for x, w, t in zip(syms, want, out):
+                N = t.contents.sa.contents.length
+                assert N == x.size + 1
+                assert (np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)) == w).all(), (setting, N)
+                o = np.ctypeslib.as_array(t.contents.o_table, shape=(N + 1, 5))
+                assert (o == oracle.o_table(x, w, 5)).all(), (setting, N)
+                lib.completely_free_bwt_table(t)
+    finally:
+        os.environ.pop("STRALG_AMD_FARM_WORKERS", None)
+        if old is not None:
+            os.environ["STRALG_AMD_FARM_WORKERS"] = old
+
+
 def test_c_harness_runs(tmp_path):
     """a plain C caller of the reference-named API (restated performance/suffix_array_construction.c)"""
     import subprocess
