@@ -979,6 +979,21 @@ int sx_prefix_ties_sampled(sx_ctx *ctx, const sx_text_info &ti, sx_arena am, boo
     const uint64_t m = all_suffixes ? ti.N : ti.m;
     const uint64_t look_from = ctx->sample_min >= 0 ? (uint64_t)ctx->sample_min : (1ull << 20);
     if (ti.maxc < 8 || m < look_from || ctx->prefix_symbols > 0) return 0; // (a forced prefix length: a test of that sort)
+    // Symbols that are all equally frequent are not what words, phrases or mark-up look like: the chance that two
+    // positions hold the same symbol, times the symbols in use, is 1 for uniform symbols (1 GiB of random bytes: 1.000,
+    // which then keeps the millisecond the look costs), 1.7 for English text, 1.3 for proteins
+    if (ctx->sample_min < 0) {
+        double sum_p2 = 0.0;
+        uint32_t used = 0;
+        const double n_sym = (double)ti.N - 1.0;
+        for (int c = 1; c < 256 && n_sym > 0; ++c) {
+            if (!ti.h_all[c]) continue;
+            const double pc = (double)ti.h_all[c] / n_sym;
+            sum_p2 += pc * pc;
+            ++used;
+        }
+        if (sum_p2 * (double)used < 1.1) return 0;
+    }
     const uint32_t base = ti.maxc + 1;
     uint32_t Cmax = 0;
     for (double cap63 = 9.2e18, v = 1.0; v * base <= cap63 && Cmax < 63; v *= base) ++Cmax;
