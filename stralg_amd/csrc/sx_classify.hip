@@ -225,12 +225,38 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     // A workgroup walks over many tiles and adds its histograms to the global ones once at the end: a global
     // atomic per tile and symbol (262 144 tiles on 15 addresses at 1 GiB of DNA) serialises at the memory side
     // and was most of this kernel's time.
+    // (the next tile's 17 bytes are asked for before this tile's barriers: SX_CLS_PREFETCH)
+    uint4 v_next = {0u, 0u, 0u, 0u};
+    uint32_t b_next = 0;
+#ifndef SX_CLS_PREFETCH
+#define SX_CLS_PREFETCH 1
+#endif
+    if (SX_CLS_PREFETCH && blockIdx.x < ntiles) {
+        const uint64_t q0 = (uint64_t)blockIdx.x * kClsTile + (uint64_t)t * kClsPerThread;
+        const uint8_t *__restrict__ S0 = blockIdx.x < src_tiles ? src : T;
+        v_next = *reinterpret_cast<const uint4 *>(S0 + q0);
+        b_next = (uint32_t)S0[q0 + 16];
+    }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform
         const uint64_t tile0 = (uint64_t)tile * kClsTile;
         const uint64_t p0 = tile0 + (uint64_t)t * kClsPerThread;
         const uint8_t *__restrict__ S = tile < src_tiles ? src : T; // (uniform per workgroup and tile)
-        const uint4 v = *reinterpret_cast<const uint4 *>(S + p0);
-        const uint32_t w[5] = {v.x, v.y, v.z, v.w, (uint32_t)S[p0 + 16]};
+        uint4 v;
+        uint32_t b16;
+        if (SX_CLS_PREFETCH) {
+            v = v_next, b16 = b_next;
+            const uint32_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint64_t q0 = (uint64_t)nt * kClsTile + (uint64_t)t * kClsPerThread;
+                const uint8_t *__restrict__ Sn = nt < src_tiles ? src : T;
+                v_next = *reinterpret_cast<const uint4 *>(Sn + q0);
+                b_next = (uint32_t)Sn[q0 + 16];
+            }
+        } else {
+            v = *reinterpret_cast<const uint4 *>(S + p0);
+            b16 = (uint32_t)S[p0 + 16];
+        }
+        const uint32_t w[5] = {v.x, v.y, v.z, v.w, b16};
         if (tile < src_tiles) *reinterpret_cast<uint4 *>(T + p0) = v; // the copy the rest of the build reads
         const bool inside = p0 + 16 <= n; // everywhere but at the very end of the text
         uint32_t dmask, vmask;
@@ -363,6 +389,9 @@ __global__ __launch_bounds__(kBlock) void cls_types_kernel(
     }
 }
 
+#ifndef SX_CLS_GRID
+#define SX_CLS_GRID 4096u // workgroups of cls_types_kernel (1 GiB of DNA: 1024 0.79 ms, 2048 0.75, 4096 0.655, 16384 0.66)
+#endif
 // ---- pass 4: sample flags ---------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void samp_flags_kernel(const uint16_t *__restrict__ lmsbits, uint64_t n,
                                                             const uint32_t *__restrict__ tile_prev, uint32_t W,
@@ -529,7 +558,7 @@ int sx_classify(sx_ctx *ctx, uint8_t *T, uint64_t n, sx_arena &arena, sx_text_in
     sx_launch(ctx, SX_KC_CLASSIFY, ti.ntiles, cls_resolve_kernel, dim3(sx_div_up(ti.ntiles, kBlock * 16)), block, ti.tile_first,
               ti.ntiles);
     sx_launch(ctx, SX_KC_CLASSIFY, ti.N + ti.N / 8 + (src ? (uint64_t)src_tiles * kClsTile : 0), cls_types_kernel,
-              dim3(ti.ntiles < 2048 ? ti.ntiles : 2048), block, T, n, (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms,
+              dim3(ti.ntiles < SX_CLS_GRID ? ti.ntiles : SX_CLS_GRID), block, T, n, (const uint8_t *)ti.tile_first, ti.ntiles, ti.lmsbits, tile_lms,
               tile_last, ti.d_hist, src, src_tiles);
     // read the three histograms back: the host drives the bucket loop
     uint32_t h[3 * 256 + 1];
