@@ -621,6 +621,65 @@ __global__ __launch_bounds__(kBlock) void refine_small_groups_kernel(
     }
 }
 
+// The same with a lane a member.  Above, only the lanes of group heads work (every other one on random text) and walk
+// their members one after the other: 0.87 ms for 5.6 M tied suffixes, a twentieth of the random-read rate.  Here a wave
+// takes a window of 64 list slots, windows start every kRsStride = 56 slots: a group of at most eight members whose head
+// lies in the window's first 56 slots ends inside the window, so every such group is owned by exactly one wave.  Every
+// owned member reads its own next key and window (all reads of the wave in flight together), finds its place among its
+// mates through lane shifts (at most seven either way), and the member that belongs at slot j of the group writes there.
+// Larger groups are only reported, as above.
+constexpr int kRsStride = kWave - kSmallGroup;
+__global__ __launch_bounds__(kBlock) void refine_small_groups_wave_kernel(
+    const uint8_t *__restrict__ T, uint64_t n, const uint32_t *__restrict__ ap, const uint32_t *__restrict__ apos,
+    const uint8_t *__restrict__ head, uint64_t A, uint64_t skip, pkey_cfg kc, uint32_t *__restrict__ vals_sorted,
+    uint32_t *__restrict__ ap_new, uint8_t *__restrict__ head_new, uint32_t *__restrict__ seedw, wnd_cfg wcfg,
+    uint32_t *__restrict__ large)
+{
+    const uint64_t base = ((uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)wave_id()) * kRsStride;
+    if (base >= A) return; // (the whole wave)
+    const int l = lane_id();
+    const uint64_t t = base + (uint64_t)l;
+    const bool valid = t < A;
+    // a slot opens a group when its head flag is set; the slot after the last one closes the list
+    const uint64_t heads = __ballot(((valid && head[t]) || t == A) ? 1 : 0);
+    const uint64_t upto = heads & lanemask_le();
+    const int first = upto ? 63 - __clzll((unsigned long long)upto) : -1; // lane of the group's head (-1: before the window)
+    const uint64_t later = heads & ~lanemask_le();
+    const int my_end = later ? __ffsll((unsigned long long)later) - 1 : kWave + kSmallGroup; // lane after the group's last member (unknown: too far)
+    const bool mine = valid && first >= 0 && first < kRsStride; // the group's head lies in this wave's stride
+    const bool small = mine && my_end - first <= kSmallGroup;
+    if (__any((mine && !small && l == first) ? 1 : 0) && l == 0) atomicAdd(large, 1u);
+    const uint32_t p = small ? ap[t] : 0u;
+    const uint32_t slot_here = small ? apos[t] : 0u;
+    uint64_t key = 0;
+    if (small) {
+        const uint64_t q = (uint64_t)p + skip;
+        key = q <= n ? prefix_key(T, q, kc) : 0ull;
+    }
+    const uint32_t wnd = (small && seedw && p) ? wnd_fill<uint32_t>(T, p, wcfg) : 0u;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    const int fl = small ? first : -1 - l; // (lanes outside owned groups: a group of their own, never a mate)
+    uint32_t less = 0, same_left = 0;
+#pragma unroll
+    for (int o = 1; o < kSmallGroup; ++o) {
+        const int fu = __shfl_up(fl, o, kWave), fd = __shfl_down(fl, o, kWave);
+        const uint64_t ku = pack64(__shfl_up(klo, o, kWave), __shfl_up(khi, o, kWave));
+        const uint64_t kd = pack64(__shfl_down(klo, o, kWave), __shfl_down(khi, o, kWave));
+        const bool mate_u = l >= o && fu == fl, mate_d = l + o < kWave && fd == fl;
+        less += (mate_u && ku < key) ? 1u : 0u;
+        same_left += (mate_u && ku == key) ? 1u : 0u;
+        less += (mate_d && kd < key) ? 1u : 0u;
+    }
+    const int at = small ? first + (int)(less + same_left) : l; // the lane whose slot this member moves to
+    const uint32_t slot_at = __shfl(slot_here, at, kWave);
+    if (small) {
+        vals_sorted[slot_at] = p;
+        if (seedw) seedw[slot_at] = wnd;
+        ap_new[base + (uint64_t)at] = p;
+        head_new[base + (uint64_t)at] = same_left == 0 ? 1 : 0; // first of its run of equal keys (the group's first member included)
+    }
+}
+
 // Groups of kSmallGroup + 1 .. kMidGroup members (a family of diverged repeats leaves tens of millions of suffixes in
 // groups of some hundred to some thousand: through the radix passes every one of them crossed HBM 12 times a round).
 // A workgroup takes the groups whose head lies in its span of the active list -- such a group ends inside the
@@ -1375,6 +1434,15 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             continue;
         }
         // groups of up to eight members: settled by their head's thread
+#ifndef SX_RS_WAVES
+#define SX_RS_WAVES 1
+#endif
+        if (SX_RS_WAVES && ctx->sort_mode != 1)
+            sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_small_groups_wave_kernel,
+                      dim3(sx_div_up(sx_div_up(A, kRsStride), kWavesPerBlock)), block, ti.T, ti.n, (const uint32_t *)ap,
+                      (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip, pkey_make(base, Cmax), vs, ap_new, head_new,
+                      embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
+        else
         sx_launch(ctx, SX_KC_DOUBLING, (uint64_t)A * 60, refine_small_groups_kernel, dim3(sx_div_up(A, kBlock)), block, ti.T,
                   ti.n, (const uint32_t *)ap, (const uint32_t *)apos, (const uint8_t *)head, (uint64_t)A, skip,
                   pkey_make(base, Cmax), vs, ap_new, head_new, embed ? seedw : nullptr, full_wcfg, d_scalar + 1);
