@@ -193,6 +193,25 @@ __device__ __forceinline__ uint64_t key_and_window_dna(const uint8_t *img, uint3
     return acc | (uint64_t)wnd << kbits;
 }
 
+// ---- dense keys for texts of four symbols (A C G T: the symbols 1 .. 4, the sentinel 0) ------------------------------
+// The base-5 key leaves a fifth of the key space per symbol unused (no symbol is 0 before the end of the text), and
+// inside a sub-bucket of the hybrid sort -- a range of 2^16 key values -- the keys that do occur sit in clumps: the
+// local sort's bins fill unevenly, and a wave's ranking inside the bins takes as many steps as its fullest bin
+// (8 - 10 on random DNA; 3.36 ms at 1 GiB, 2.83 with the steps capped at 5).  Two bits a symbol use every key value:
+//     key = (sum over the C symbols of (symbol - 1) * 4^(C - 1 - i)) << lenbits | (symbols before the text's end)
+// A suffix that runs into the sentinel counts it and the padding behind it as the smallest symbol, and the length
+// field puts it in front of every suffix that has real symbols there: the order of the base-5 keys, and two suffixes
+// have equal keys exactly when they did (same C symbols, none at the end of the text).  The sum comes from the same
+// dot products with base 4 (symbols as they are: sum(symbol * 4^k), a constant too large), minus the constant, plus
+// what the z = C - len zeros at the end took too much.
+__device__ __forceinline__ uint64_t dense4_finish(uint64_t raw, uint32_t C, uint32_t z, uint32_t lenbits)
+{
+    const uint64_t ones = 0x5555555555555555ull; // 4^k summed: 0b...010101
+    const uint64_t k0 = ones & ((1ull << (2u * C)) - 1ull), corr = z ? ones & ((1ull << (2u * z)) - 1ull) : 0ull;
+    return ((raw - k0 + corr) << lenbits) | (uint64_t)(C - z);
+}
+__device__ __forceinline__ uint32_t dense4_zeros(uint64_t p, uint32_t C, uint64_t n) { return p + C > n ? (uint32_t)(p + C - n) : 0u; }
+
 // One workgroup per classification tile (4096 text positions): the tile's LMS positions are
 // listed in LDS from the LMS bit array, then every thread turns listed positions into
 // (key, position) pairs at the tile's offset in the global LMS order.  This is the compaction of
@@ -205,7 +224,8 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
                                                                uint32_t kbits, wnd_cfg wcfg,
                                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                                uint8_t *__restrict__ dig0, uint32_t dig_shift,
-                                                               uint32_t dig_mask)
+                                                               uint32_t dig_mask, uint64_t dense_n /* dense keys: n + 1, else 0 */,
+                                                               uint32_t lenbits)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     __shared__ uint32_t spos[kClsTile / 2 + 1]; // LMS positions are at least two apart
@@ -237,6 +257,15 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
         uint64_t key;
         if (CS > 0 && p >= (uint32_t)WS) { // (everywhere but at the very start of the text)
             key = key_and_window_dna<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1), (CS > 0 ? BS : 2)>(img, (uint32_t)((uint64_t)(p - (uint32_t)WS) - origin), kc, kbits);
+            if (dense_n) { // (uniform) the key bits again, dense; the window above them stays
+                const uint64_t kmask = (1ull << kbits) - 1ull;
+                key = (key & ~kmask) | dense4_finish(key & kmask /* the sum is below 4^C * 4/3 < 2^(2C+1) <= 2^kbits */, kc.C, dense4_zeros(p, kc.C, dense_n - 1), lenbits);
+            }
+        } else if (CS > 0 && dense_n) {
+            uint64_t raw = 0;
+            for (uint32_t s2 = 0; s2 < kc.C; ++s2) raw = raw * 4u + (uint64_t)T[(uint64_t)p + s2];
+            key = dense4_finish(raw, kc.C, dense4_zeros(p, kc.C, dense_n - 1), lenbits);
+            if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
         } else if (CS > 0) {
             // the first few positions of the text, in the static forms: symbol by symbol from memory.  (With the general
             // form below compiled in here, the compiler evaluated its 64 uniform tests once per workgroup and parked them
@@ -252,6 +281,7 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
             } else {
                 key = prefix_key(T, p, kc);
             }
+            if (dense_n) key = dense4_finish(key, kc.C, dense4_zeros(p, kc.C, dense_n - 1), lenbits); // (uniform)
             // The key bits above kbits are not sorted on, they just ride along: put the suffix's
             // symbol window (text[p-1], text[p-2], ... for the induction, sx_window.hpp) there while
             // this part of the text is at hand, instead of gathering it again after the sort.
@@ -1173,18 +1203,28 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     int kbits = 64;
     bool embed = false;
     uint64_t kmask = ~0ull;
+#ifndef SX_DENSE4
+#define SX_DENSE4 1
+#endif
     for (int attempt = 0;; ++attempt) {
+        // four symbols and the sentinel: dense keys of two bits a symbol and a length field (dense4_finish); the plain-passes
+        // mode keeps the base-5 keys (tests run both)
+        const uint32_t lenbits = (uint32_t)sx_bitlen(C);
+        int kbits_wnd = 64, kbits_base = 64;
+        const bool dense4 = SX_DENSE4 && !all_suffixes && base == 5 && ctx->sort_mode != 1 && 2 * C + lenbits <= 60;
         {
             uint64_t top = 1; // base^C - 1 is the largest key
             for (uint32_t i = 0; i < C; ++i) top *= base;
-            kbits = sx_bitlen(top - 1);
+            kbits = dense4 ? (int)(2 * C + lenbits) : sx_bitlen(top - 1);
             if (kbits < 1) kbits = 1;
+            kbits_base = sx_bitlen(top - 1) > 0 ? sx_bitlen(top - 1) : 1;
+            kbits_wnd = kbits > kbits_base ? kbits : kbits_base; // (dense keys: the windows of the base-5 keys, for which the static kernels are built)
         }
         // symbol windows in the unsorted key bits, when at least four symbols fit (32-bit windows only)
         wnd_cfg wcfg;
         const bool wide = sx_window_cfg(ti.maxc, wcfg);
         uint32_t wchars = 0;
-        if (!wide && 64 - kbits > kCntBits) wchars = (uint32_t)(64 - kbits - kCntBits) / wcfg.B;
+        if (!wide && 64 - kbits_wnd > kCntBits) wchars = (uint32_t)(64 - kbits_wnd - kCntBits) / wcfg.B;
         if (wchars > wcfg.CW) wchars = wcfg.CW;
         embed = wchars >= 4;
         if (all_suffixes) {
@@ -1221,16 +1261,23 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 sum_p2 += pc * pc;
             }
             const double eff = sum_p2 > 0.0 ? 1.0 / sum_p2 : 1.0;
-            for (int cand = 24; cand <= 32 && top_bits == 0; cand += 8) {
+#ifndef SX_DENSE4_TOP
+#define SX_DENSE4_TOP 22 // (1 GiB of DNA, whole step: base-5 keys 23.30 ms; dense keys with 24 top bits 22.79, 22: 22.71, 21: 22.73, 20: 22.79)
+#endif
+            const int cand0 = dense4 ? SX_DENSE4_TOP : 24;
+            for (int ci = 0; ci < 2 && top_bits == 0; ++ci) {
+                const int cand = ci == 0 ? cand0 : 32;
                 if (!sx_local_sort_applies(m, kbits, cand)) continue;
                 if (ctx->sort_mode >= 2) { // forced (tests): 2 three passes, 3 four
-                    if ((ctx->sort_mode == 2) == (cand == 24)) top_bits = cand;
+                    if ((ctx->sort_mode == 2) == (ci == 0)) top_bits = cand;
                     continue;
                 }
-                const double syms = (double)C - (double)(kbits - cand) / log2((double)base);
+                // (dense keys: judged as the base-5 keys were -- a text that fails this test has repeat families that overflow a
+                //  workgroup with 12-symbol sub-buckets as they did with 10-symbol ones: the genome-like text 49 instead of 40 ms)
+                const double syms = (double)C - (double)(kbits_base - (ci == 0 ? 24 : 32)) / log2((double)base);
                 const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
                 const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
-                if (cand == 24 && m >= (1u << 22) && mean_bucket <= 300.0 && top_bucket <= 400.0) top_bits = cand; // (a workgroup owns the sub-buckets that start in its span and end within its reach: one that starts
+                if (ci == 0 && m >= (1u << 22) && mean_bucket <= 300.0 && top_bucket <= 400.0) top_bits = cand; // (a workgroup owns the sub-buckets that start in its span and end within its reach: one that starts
                                                                                                        //  at the span's last pair may hold kLsCap - kLsSpan = 1024 pairs, one that starts earlier more)
             }
         }
@@ -1253,13 +1300,14 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                       (uint32_t)kbits, wcfg, ka, dig0, dig_shift, dig_mask);
         else
         {
-            const pkey_cfg kc = pkey_make(base, C);
+            const pkey_cfg kc = pkey_make(dense4 ? 4u : base, C);
             // DNA-like texts: everything static for the usual prefix lengths (base 5: the window takes what
             // 64 - kbits - 4 bits hold)
             const bool dna = kc.dot && (wcfg.B == 2 || wcfg.B == 3) && kbits >= 8;
 #define SX_TILE_KEYS(CS, WS, BS)                                                                                       \
     sx_launch(ctx, SX_KC_KEYS, m * 12 + ti.N + ti.N / 8, lms_tile_keys_kernel<CS, WS, BS>, dim3(ti.ntiles), block,     \
-              ti.T, (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0, dig_shift, dig_mask)
+              ti.T, (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, kc, (uint32_t)kbits, wcfg, ka, va, dig0, dig_shift, dig_mask, \
+              (uint64_t)(dense4 ? ti.n + 1 : 0), lenbits)
             const uint32_t shape = dna ? (C * 16 + wcfg.CW) * 4 + wcfg.B : 0u;
             switch (shape) {
             // base 5 (A C G T): 64 Mi ... 4 Gi symbols
