@@ -205,11 +205,9 @@ def test_hybrid_prefix_sort(gpu_ctx):
                     bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
                     gpu_ctx.sa_bwt_build_dev(xd, n, sigma, sa, bw)
                     st = gpu_ctx.last_stats()
-                    # (four-letter texts: dense keys of 2 C + 4 ... 5 bits outside the plain-passes mode -- 32 bits for
-                    #  14 symbols, which four passes on the top 32 leave nothing of for the LDS step)
-                    expect = (0, 1, 5)[mode - 1] if not (sigma == 5 and C == 14 and mode == 3) else 0
-                    assert (st["sort_local"] & 5) == expect and st["key_slots"] == C, (sigma, n, C, mode, st)
-                    assert st["key_bits"] == ((2 * C + (4 if C < 16 else 5)) if sigma == 5 and mode != 1 else st["key_bits"]), st
+                    assert (st["sort_local"] & 5) == (0, 1, 5)[mode - 1] and st["key_slots"] == C, (sigma, n, C, mode, st)
+                    if sigma == 5 and mode < 3:  # four-letter texts: dense keys with the hybrid sort, base-5 keys with plain passes
+                        assert st["key_bits"] == (2 * C + (4 if C < 16 else 5) if mode == 2 else int(np.ceil(C * np.log2(5)))), st
                     assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n, C, mode)
                     assert (bw.cpu().numpy() == bw_want).all(), (sigma, n, C, mode)
         # 40 copies of a 60-symbol piece: equal keys crowd a bin of the counting pass, that workgroup takes stable passes
