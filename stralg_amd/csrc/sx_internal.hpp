@@ -100,7 +100,7 @@ uint32_t sx_local_sort_tiles(uint64_t m);
 int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t *vout,
                   uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
-                  uint32_t *d_total_and_fail);
+                  uint32_t *d_total_and_fail, uint32_t longest_expected = 0 /* the longest sub-bucket the caller expects; 0: not known */);
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);

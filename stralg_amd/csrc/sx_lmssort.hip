@@ -1270,7 +1270,21 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
 #ifndef SX_DENSE4_TOP
 #define SX_DENSE4_TOP 22 // (1 GiB of DNA, whole step: base-5 keys 23.30 ms; dense keys with 24 top bits 22.79, 22: 22.71, 21: 22.73, 20: 22.79)
 #endif
-            const int cand0 = dense4 ? SX_DENSE4_TOP : 24;
+            // Dense keys: a sub-bucket is a prefix of top_bits / 2 symbols, so its mean length (m / eff^symbols) and that of
+            // the most frequent symbol's run (m * pmax^symbols) are known better than for base-b keys; LMS suffixes favour
+            // some prefixes (the fullest sub-bucket of uniform text holds 3.6 times the mean, measured), so 4.5 times the
+            // larger of the two, with half as much again for safety, has to fit the 1024 pairs between a span's end and the
+            // reach.  Skewed symbol counts (a genome: 30 % A) give the run of the most frequent symbol many times the mean:
+            // such texts have repeat families too, and are left to plain passes as before.  22 top bits where they do
+            // (1 GiB ... 2 GiB of uniform DNA), else 24 (up to 8 GiB).
+            int cand0 = dense4 ? SX_DENSE4_TOP : 24;
+            bool dense_fits = false;
+            if (dense4 && ctx->sort_mode == 0) {
+                for (int tb = SX_DENSE4_TOP; tb <= 24 && !dense_fits; tb += 2) {
+                    const double sy = (double)tb / 2.0, mean_d = (double)m / pow(eff, sy), top_d = (double)m * pow(pmax, sy);
+                    if (top_d <= 1.5 * mean_d && 4.5 * top_d * 1.5 <= 1024.0 && sx_local_sort_applies(m, kbits, tb)) cand0 = tb, dense_fits = true;
+                }
+            }
             for (int ci = 0; ci < 2 && top_bits == 0; ++ci) {
                 const int cand = ci == 0 ? cand0 : 32;
                 if (!sx_local_sort_applies(m, kbits, cand)) continue;
@@ -1278,12 +1292,10 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                     if ((ctx->sort_mode == 2) == (ci == 0)) top_bits = cand;
                     continue;
                 }
-                // (dense keys: judged as the base-5 keys were -- a text that fails this test has repeat families that overflow a
-                //  workgroup with 12-symbol sub-buckets as they did with 10-symbol ones: the genome-like text 49 instead of 40 ms)
                 const double syms = (double)C - (double)(kbits_base - (ci == 0 ? 24 : 32)) / log2((double)base);
                 const double mean_bucket = syms > 0.0 ? (double)m / pow(eff, syms) : (double)m;
                 const double top_bucket = syms > 0.0 ? (double)m * pow(pmax, syms) : (double)m;
-                if (ci == 0 && m >= (1u << 22) && mean_bucket <= 300.0 && top_bucket <= 400.0) top_bits = cand; // (a workgroup owns the sub-buckets that start in its span and end within its reach: one that starts
+                if (ci == 0 && m >= (1u << 22) && (dense4 ? dense_fits : (mean_bucket <= 300.0 && top_bucket <= 400.0))) top_bits = cand; // (a workgroup owns the sub-buckets that start in its span and end within its reach: one that starts
                                                                                                        //  at the span's last pair may hold kLsCap - kLsSpan = 1024 pairs, one that starts earlier more)
             }
         }
@@ -1343,8 +1355,18 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             const uint64_t *kin = in_b ? kb : ka;
             const uint32_t *vin = in_b ? vb : va;
             uint32_t *vo = in_b ? va : vb;
+            // (dense keys: a sub-bucket is a prefix of top_bits / 2 symbols; LMS suffixes favour some prefixes -- two thirds of
+            //  them begin with the smallest symbol -- so the fullest sub-bucket of uniform text holds 3.6 times the mean: 4.5 times
+            //  the most frequent symbol's share to that power, for the local sort's choice of its span)
+            uint32_t longest = 0;
+            if (dense4 && ctx->sort_mode == 0) {
+                double pm = 0.0;
+                for (int c = 1; c < 256; ++c) pm = (double)ti.h_all[c] > pm ? (double)ti.h_all[c] : pm;
+                const double est = 4.5 * (double)m * pow(pm / ((double)ti.N - 1.0), (double)top_bits / 2.0);
+                longest = est < 1.0 ? 1u : (est > 1e9 ? 1000000000u : (uint32_t)est);
+            }
             SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, top_bits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
-                                 tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar));
+                                 tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar, longest));
             uint32_t res[2] = {0, 0};
             SX_TRY(sx_readback(ctx, d_scalar, 2, res));
             if (!(res[1] & 1u)) {

@@ -45,14 +45,14 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
     uint32_t *__restrict__ tile_cnt, uint2 *__restrict__ stage, uint8_t *__restrict__ stage_head,
-    uint32_t *__restrict__ fail)
+    uint32_t *__restrict__ fail, uint32_t span /* kLsSpan, or more where the sub-buckets are known to be short */)
 {
     __shared__ uint64_t K[kLsCap]; // keys; then (payload << 32 | sub-bucket rank << L | low bits); per-wave counters during a ranking
     __shared__ uint32_t V[kLsCap]; // positions
     __shared__ uint32_t bnd[kLsWords], bpre[kLsWords]; // sub-bucket starts as bits; starts before each word
     __shared__ uint32_t s_first, s_end, s_scan[kLsWaves], s_kprev[2], s_max;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint64_t g0 = (uint64_t)blockIdx.x * kLsSpan;
+    const uint64_t g0 = (uint64_t)blockIdx.x * span;
     const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
     const uint32_t avail = m - g0 < (uint64_t)kLsCap ? (uint32_t)(m - g0) : (uint32_t)kLsCap; // pairs in reach
     const bool end_in_reach = g0 + avail == m;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         const bool start = i == 0 ? (g0 == 0 || ((kprev & kmask) >> L) != idc) : ((K[i - 1] & kmask) >> L) != idc;
         if (start) {
             atomicOr(&bnd[i >> 5], 1u << (i & 31u));
-            if (i < (uint32_t)kLsSpan) atomicMin(&s_first, i);
+            if (i < span) atomicMin(&s_first, i);
             else atomicMin(&s_end, i);
         }
     }
@@ -413,13 +413,23 @@ bool sx_local_sort_applies(uint64_t m, int kbits, int top_bits)
 int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t *vout,
                   uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
-                  uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used */)
+                  uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used */,
+                  uint32_t longest_expected)
 {
-    const uint32_t tiles = sx_local_sort_tiles(m);
+    // The span: a workgroup's costs that do not depend on its pairs (zeroing and scanning 8192 counters, the barriers) are
+    // spread over more pairs the longer it is (1 GiB of DNA, dense keys: span 5120 2.79 ms, 5632 2.60, 5888 2.52), but a
+    // sub-bucket that starts at the span's last pair must end within the reach of kLsCap pairs, or the whole sort falls back
+    // to plain passes.  So the span grows only where the caller knows how long sub-buckets get (four-letter texts with
+    // dense keys: uniform symbols at a known rate; longest_expected = 0: not known), with a factor of safety.
+    uint32_t span = (uint32_t)kLsSpan;
+    if (longest_expected > 0 && 3 * (uint64_t)longest_expected <= 2 * ((uint64_t)kLsCap - 5632u)) span = 5632u;
+    else if (longest_expected > 0 && 3 * (uint64_t)longest_expected <= 2 * ((uint64_t)kLsCap - 5376u)) span = 5376u;
+    if (span < (uint32_t)kLsSpan) span = (uint32_t)kLsSpan;
+    const uint32_t tiles = sx_div_up(m, span);
     const uint32_t L = (uint32_t)(kbits - top_bits);
     SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, sizeof(uint32_t), ctx->stream));
     sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
-              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1);
+              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span);
     SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_cnt}, OutExclusive{tile_off}, d_total_and_fail, SX_KC_NAMES, 0)));
     sx_launch(ctx, SX_KC_NAMES, 0, local_tied_gather_kernel, dim3(tiles), dim3(kBlock), (const uint32_t *)tile_start,
               (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, (const uint2 *)stage, (const uint8_t *)stage_head, apos, ap,
