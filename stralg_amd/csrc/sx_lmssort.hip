@@ -1359,10 +1359,15 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             //  them begin with the smallest symbol -- so the fullest sub-bucket of uniform text holds 3.6 times the mean: 4.5 times
             //  the most frequent symbol's share to that power, for the local sort's choice of its span)
             uint32_t longest = 0;
-            if (dense4 && ctx->sort_mode == 0) {
+            if ((dense4 || all_suffixes) && ctx->sort_mode == 0) {
                 double pm = 0.0;
                 for (int c = 1; c < 256; ++c) pm = (double)ti.h_all[c] > pm ? (double)ti.h_all[c] : pm;
-                const double est = 4.5 * (double)m * pow(pm / ((double)ti.N - 1.0), (double)top_bits / 2.0);
+                pm /= (double)ti.N - 1.0;
+                // (all suffixes of a wide alphabet, the direct sort: no favoured prefixes, a sub-bucket is a prefix of
+                //  top_bits / log2(base) symbols -- three bytes at 256 symbols --: the most frequent symbol's run and what
+                //  chance adds to the fullest of 2^24 sub-buckets)
+                const double run = (double)m * pow(pm, dense4 ? (double)top_bits / 2.0 : (double)top_bits / log2((double)base));
+                const double est = dense4 ? 4.5 * run : 1.2 * run + 8.0 * sqrt(run) + 16.0;
                 longest = est < 1.0 ? 1u : (est > 1e9 ? 1000000000u : (uint32_t)est);
             }
             SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, top_bits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
