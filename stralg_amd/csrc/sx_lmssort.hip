@@ -1258,7 +1258,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             // with skewed frequencies too (2 GiB of uniform DNA: 40.3 against 43.2 ms for six plain passes), but are only
             // taken when asked for (SX_FLAG_SORT_MODE 3): texts that long are genomes, their repeat families overflow a
             // workgroup whatever the symbol counts promise, and a failed attempt costs more than a good one saves
-            // (the genome-like 1 GiB text: 58 instead of 44 ms).
+            // (the genome-like 1 GiB text: 58 instead of 44 ms).  (Four-letter texts with dense keys: see cand0 below -- their
+            // sub-buckets' lengths are known, and 2 GiB ... 8 GiB of uniform DNA take the hybrid sort with 22 / 24 top bits.)
             double pmax = 0.0, sum_p2 = 0.0;
             const double n_sym = (double)ti.N - 1.0;
             for (int c = 1; c < 256 && n_sym > 0; ++c) {
