@@ -389,7 +389,7 @@ def run_rank(args):
     # rank then uses cuda:0 and the scalars travel on the CPU.  STRALG_BENCH_EMU=1 (tests, no GPU) runs the same
     # code over the CPU execution harness of the kernels (tests/emu): torch CPU tensors, gloo.
     emu = os.environ.get("STRALG_BENCH_EMU") == "1"
-    backend = "gloo" if emu else os.environ.get("STRALG_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("STRALG_BENCH_BACKEND", "gloo" if emu else "nccl")
     if os.environ.get("STRALG_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     if world != args.gpus and rank == 0:
@@ -415,13 +415,22 @@ def run_rank(args):
         ctx.set_induce_attended(1)
     # host work of a rank (staging copies, page faults of pinned and malloc'd buffers) next to its GPU's PCIe root
     numa_node = ctx.bind_to_numa_node()
+    cuda = dev.type == "cuda"
+    coll = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    cuda = dev.type == "cuda"
+        # gloo is the control plane and always comes up; RCCL ("nccl") is tried beside it and carries the timing barrier
+        # and the scalar reductions when the attempt succeeds on EVERY rank (farm.init_collectives) -- a first RCCL run
+        # that fails (no such run has been possible on the builder's one-GPU boxes) costs the line a label, not the run
+        coll = farm.init_collectives(rank, world, dev if cuda else None, prefer=backend)
+        ident = {"rank": rank, "local_rank": local_rank, "device": str(dev)}
+        if cuda:
+            pr = torch.cuda.get_device_properties(dev)
+            ident["device_name"] = pr.name
+            ident["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                                      getattr(pr, "pci_device_id", 0))
+            ident["hbm_GiB"] = round(pr.total_memory / 2**30, 1)
+        coll["ranks"] = farm.gather_objects(ident)
 
     def sync():
         if cuda:
@@ -491,7 +500,7 @@ def run_rank(args):
     ctx.profile_only(None)
     stats = ctx.last_stats()
     # max time over ranks, total suffixes over ranks (the only collectives; none on the data path)
-    red_dev = dev if backend == "nccl" else None
+    red_dev = None  # (farm.reduce_scalars uses the group and device farm.init_collectives chose)
     elapsed, total_units = farm.reduce_scalars(elapsed_own, args.steps * N, device=red_dev)
 
     # ---- after the timed region: check the last step's results on the device ------------------------------
@@ -569,6 +578,7 @@ def run_rank(args):
             "value": round(value, 3),
             "unit": "Msuffixes/s",
             "n_gpus": world,
+            **({"collective_backend": coll["collective_backend"], "n_ranks_seen": coll["n_ranks_seen"]} if coll else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -610,6 +620,13 @@ def run_rank(args):
                              "frac_of_peak": round(alg_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
         if fasta is not None:
             out["fasta_record"] = fasta
+        if coll is not None:
+            # who took part: the driver can check "RCCL saw N ranks" and that N distinct GPUs did the work
+            out["collectives"] = {"backend": coll["collective_backend"], "n_ranks_seen": coll["n_ranks_seen"],
+                                  "nccl_error": coll["nccl_error"], "control_plane": "gloo", "ranks": coll["ranks"],
+                                  "distinct_devices": len({(r.get("pci_bus_id"), r.get("device")) for r in coll["ranks"]}),
+                                  "note": "no collective on the data path; this group carries the timing barrier and the "
+                                          "max / sum of the bookkeeping scalars only"}
         if world == 1 and not args.no_e2e and not emu and workload in ("dna", "fasta"):
             del text, sa, bwt, c_tab, o_tab
             job = None
@@ -632,7 +649,7 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(cpu_sample, sigma, f"the first {cpu_n} symbols of the record rank 0 built")
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        farm.fence(cuda)
         dist.destroy_process_group()
     ctx.close()
     return 1 if bad_ranks else 0

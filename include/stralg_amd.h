@@ -97,6 +97,8 @@ int sx_device_count(void);
 int sx_device_numa_node(int device);
 int sx_ctx_create(int device, sx_ctx **out);
 void sx_ctx_destroy(sx_ctx *ctx);
+/* contexts alive in this process (created minus destroyed) */
+int sx_ctx_live_count(void);
 const char *sx_last_error(const sx_ctx *ctx);
 /* drop cached workspace (it is otherwise kept between calls) */
 void sx_ctx_trim(sx_ctx *ctx);
@@ -118,13 +120,13 @@ enum {
                                        whose rounds the tail kernel could not finish leaves word, the launches behind it do nothing,
                                        and the host carries that bucket on before it queues the rest; 1 = attended: the host reads
                                        every bucket's last range back before it queues the next bucket (rounds 1 and 2) */
+    ,SX_FLAG_COPY_TEXT_FIRST = 10   /* 1 = the build's padded copy of the text is made by a device copy before the classification
+                                       (rounds 1 and 2); 0 = the classification writes it while it reads the caller's text */
     ,SX_FLAG_RECURSE_MIN = 11      /* a reduced string of at most 255 names and at least this many symbols is sorted by the whole
                                        pipeline again (in a child context) instead of by prefix doubling; negative: the default
                                        (2^20); tests set small values */
     ,SX_FLAG_SAMPLE_MIN = 12       /* texts of more than 8 symbols and at least this many suffixes get a look at a sample before a
                                        prefix-key sort (negative: the default, 2^20; tests set small values) */
-    ,SX_FLAG_COPY_TEXT_FIRST = 10   /* 1 = the build's padded copy of the text is made by a device copy before the classification
-                                       (rounds 1 and 2); 0 = the classification writes it while it reads the caller's text */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

@@ -174,12 +174,17 @@ void dealloc_fasta_iter(struct fasta_iter *iter);
  * One context per host thread, so N threads can farm records over N GPUs
  * (tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62 is the per-record loop). */
 int stralg_amd_set_device(int device);
-/* release the calling thread's context and its cached device memory */
+/* release the calling thread's context and its cached device memory (a thread that exits without this call releases
+ * them too: the context hangs on a pthread key whose destructor runs at thread exit) */
 void stralg_amd_release(void);
+/* device contexts alive in this process */
+int stralg_amd_live_contexts(void);
 /* Build tables for `count` independent strings over the listed devices by host threads pinned to their GPU's NUMA
  * node -- one a device for long records, up to four for records too short to fill a GPU
  * (stralg_amd_farm_workers_per_device); strings are dealt longest first to the least loaded worker (LPT by length).
- * out[k] receives build_complete_table(strings[k], ...). */
+ * out[k] receives build_complete_table(strings[k], ...).  Returns 0, the number of records that could not be built
+ * (more letters than a remap table holds, no memory on the host or the device: out[k] == NULL for each, a line on
+ * stderr, the other records are built all the same), or a negative value when the farm itself could not be set up. */
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out);
 /* workers (contexts, host threads) the farm runs on each device for records of these lengths; $STRALG_AMD_FARM_WORKERS

@@ -108,6 +108,27 @@ static void *big_alloc(size_t bytes)
     return p;
 }
 
+/* A thread that exits without calling stralg_amd_release() -- every caller written against the reference's API: it has
+ * no such call -- must not take its device workspace (GiBs of HBM) with it: a pthread key whose destructor destroys the
+ * thread's context runs at thread exit.  (The main thread's context goes with the process.) */
+static pthread_key_t ctx_key;
+static pthread_once_t ctx_key_once = PTHREAD_ONCE_INIT;
+static int ctx_key_ok = 0;
+
+static void ctx_key_destroy(void *p)
+{
+    /* the __thread variables of the exiting thread may be gone already: only the key's value is used */
+    if (p) sx_ctx_destroy((sx_ctx *)p);
+}
+
+static void ctx_key_make(void) { ctx_key_ok = pthread_key_create(&ctx_key, ctx_key_destroy) == 0; }
+
+static void ctx_key_set(sx_ctx *ctx)
+{
+    pthread_once(&ctx_key_once, ctx_key_make);
+    if (ctx_key_ok) (void)pthread_setspecific(ctx_key, ctx);
+}
+
 static sx_ctx *thread_ctx(void)
 {
     if (tls_ctx) return tls_ctx;
@@ -117,6 +138,7 @@ static sx_ctx *thread_ctx(void)
     }
     int rc = sx_ctx_create(tls_device, &tls_ctx);
     if (rc != 0) die("sx_ctx_create", rc, NULL);
+    ctx_key_set(tls_ctx);
     return tls_ctx;
 }
 
@@ -126,6 +148,7 @@ int stralg_amd_set_device(int device)
     if (tls_ctx && tls_device != device) {
         sx_ctx_destroy(tls_ctx);
         tls_ctx = NULL;
+        ctx_key_set(NULL);
     }
     tls_device = device;
     return 0;
@@ -135,7 +158,11 @@ void stralg_amd_release(void)
 {
     if (tls_ctx) sx_ctx_destroy(tls_ctx);
     tls_ctx = NULL;
+    ctx_key_set(NULL);
 }
+
+/* contexts alive in this process (created minus destroyed): what the thread-exit test looks at */
+int stralg_amd_live_contexts(void) { return sx_ctx_live_count(); }
 
 /* ---- suffix arrays (stralg/suffix_array_internal.c:7-19, suffix_array.c:12-24) ---- */
 
@@ -445,17 +472,42 @@ static double now_ms(void)
  * context beside the forward one -- 1480 - 1530 ms either way.  The host side is bound by first-touch page faults and
  * the memory bandwidth of the GPU's NUMA node (zeroing + DMA + pointer fill: 64 GiB of writes a record), not by idle
  * time, so the phases stay one after the other.  $STRALG_AMD_TIMING=1 prints them.) */
-struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse)
+/* build_complete_table with an error channel: 0 and *out, or a code (SX_E_ARG: more letters than a remap table holds;
+ * SX_E_NOMEM; a device error) with everything released and a line on stderr.  The reference-named entry point below
+ * aborts on a code (the reference's constructors cannot fail); the farm keeps going with the
+ * other records. */
+static void free_partial_table(struct bwt_table *table)
 {
+    if (!table) return;
+    if (table->sa) {
+        free(table->sa->string);
+        free(table->sa->array);
+        free(table->sa);
+    }
+    free(table->remap_table);
+    free(table->c_table);
+    free(table->o_table);
+    free(table->o_indices);
+    free(table->ro_table);
+    free(table->ro_indices);
+    free(table);
+}
+
+static int build_complete_table_try(const uint8_t *string, bool include_reverse, struct bwt_table **out)
+{
+    *out = NULL;
     const bool timing = getenv("STRALG_AMD_TIMING") != NULL;
     const double t0 = timing ? now_ms() : 0.0;
     const size_t n = strlen((const char *)string);
     uint8_t *remapped = malloc(n + 1);
+    if (!remapped) return SX_E_NOMEM;
     struct remap_table *remap_table = remap_record(string, n, remapped);
     if (remap_table->alphabet_size > 128) {
         fprintf(stderr, "stralg_amd: build_complete_table: %u distinct letters; stralg's remap table holds "
                         "at most 127 (stralg/remap.h:14-18)\n", remap_table->alphabet_size - 1);
-        abort();
+        free(remapped);
+        free(remap_table);
+        return SX_E_ARG;
     }
     const uint32_t sigma = remap_table->alphabet_size;
     const size_t N = n + 1;
@@ -465,20 +517,31 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
     /* One device pass per direction (sx_build_tables): the induced sort hands the BWT over with
      * the suffix array, so init_bwt_table's gather of text[SA[i]-1] is not repeated.  The
      * results are what sa_is_construction + init_bwt_table produce (bwt.c:143-154). */
-    struct suffix_array *sa = malloc(sizeof *sa); /* allocate_sa_ without its strlen; `remapped` moves into sa->string */
+    struct suffix_array *sa = calloc(1, sizeof *sa); /* allocate_sa_ without its strlen; `remapped` moves into sa->string */
+    struct bwt_table *table = calloc(1, sizeof *table);
+    if (!sa || !table) {
+        free(sa), free(table), free(remapped), free(remap_table);
+        return SX_E_NOMEM;
+    }
     sa->string = remapped;
     sa->length = (uint32_t)N;
     sa->array = big_alloc(N * sizeof *sa->array);
-    sa->inverse = NULL;
-    sa->lcp = NULL;
-    struct bwt_table *table = malloc(sizeof *table);
     table->remap_table = remap_table;
     table->sa = sa;
     table->c_table = calloc(sigma, sizeof *table->c_table);
     table->o_table = big_alloc(o_words * sizeof *table->o_table);
+    if (!sa->array || !table->c_table || !table->o_table) {
+        fprintf(stderr, "stralg_amd: build_complete_table: no host memory for the tables of %zu symbols\n", n);
+        free_partial_table(table);
+        return SX_E_NOMEM;
+    }
     const double t1 = timing ? now_ms() : 0.0;
     int rc = sx_build_tables(ctx, remapped, n, sigma, sa->array, table->c_table, table->o_table);
-    if (rc != 0) die("build_complete_table", rc, ctx);
+    if (rc != 0) {
+        fprintf(stderr, "stralg_amd: build_complete_table failed (code %d): %s\n", rc, sx_last_error(ctx));
+        free_partial_table(table);
+        return rc;
+    }
     const double t2 = timing ? now_ms() : 0.0;
     table->o_indices = row_pointers(table->o_table, N + 1, sigma);
     if (timing)
@@ -491,18 +554,37 @@ struct bwt_table *build_complete_table(const uint8_t *string, bool include_rever
         /* the reverse suffix array and the reversed copy are temporary (bwt.c:147-158) */
         const double t3 = timing ? now_ms() : 0.0;
         uint8_t *rev = malloc(n + 1);
+        uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
+        table->ro_table = big_alloc(o_words * sizeof *table->ro_table);
+        if (!rev || !c_tmp || !table->ro_table) {
+            fprintf(stderr, "stralg_amd: build_complete_table: no host memory for the reverse table of %zu symbols\n", n);
+            free(rev), free(c_tmp);
+            free_partial_table(table);
+            return SX_E_NOMEM;
+        }
         struct lut_job lj = {remapped, rev, NULL, n, true};
         parallel_ranges(n, lut_slice, &lj);
         rev[n] = 0;
-        uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
-        table->ro_table = big_alloc(o_words * sizeof *table->ro_table);
         rc = sx_build_tables(ctx, rev, n, sigma, NULL, c_tmp, table->ro_table);
-        if (rc != 0) die("build_complete_table (reverse)", rc, ctx);
         free(c_tmp);
         free(rev);
+        if (rc != 0) {
+            fprintf(stderr, "stralg_amd: build_complete_table (reverse) failed (code %d): %s\n", rc, sx_last_error(ctx));
+            free_partial_table(table);
+            return rc;
+        }
         table->ro_indices = row_pointers(table->ro_table, N + 1, sigma);
         if (timing) fprintf(stderr, "stralg_amd timing: reverse direction %.1f ms\n", now_ms() - t3);
     }
+    *out = table;
+    return 0;
+}
+
+struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse)
+{
+    struct bwt_table *table = NULL;
+    const int rc = build_complete_table_try(string, include_reverse, &table);
+    if (rc != 0) die("build_complete_table", rc, tls_ctx);
     return table;
 }
 
@@ -891,6 +973,9 @@ struct farm_job {
     size_t n_mine;
     bool include_reverse;
     int device;
+    bool on_caller;  /* the lane runs on the thread that called the farm */
+    size_t failed;   /* records of this lane that could not be built (their out[] is NULL) */
+    int first_error; /* the first such record's code */
 };
 
 /* "0-63,128-191" -> cpu set; returns the number of CPUs */
@@ -931,14 +1016,39 @@ int stralg_amd_bind_thread_to_device(int device)
     return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0 ? node : -1;
 }
 
+/* One lane of the farm.  A record that cannot be built (more letters than a remap table holds, no memory on the host or
+ * the device) gets out[k] = NULL and counts as a failure; the lane goes on with its other records.  on_caller: the lane
+ * runs on the thread that called the farm (its thread could not be created): that thread's CPU affinity, device and
+ * context are the caller's and are put back as they were. */
 static void *farm_worker(void *arg)
 {
     struct farm_job *job = arg;
+    cpu_set_t saved_set;
+    const bool have_set = job->on_caller && pthread_getaffinity_np(pthread_self(), sizeof saved_set, &saved_set) == 0;
+    const int saved_device = tls_device;
+    sx_ctx *saved_ctx = NULL;
+    if (job->on_caller) { /* park the caller's context: stralg_amd_set_device must not destroy it */
+        saved_ctx = tls_ctx;
+        tls_ctx = NULL;
+    }
     (void)stralg_amd_bind_thread_to_device(job->device);
     stralg_amd_set_device(job->device);
-    for (size_t k = 0; k < job->n_mine; ++k)
-        job->out[job->mine[k]] = build_complete_table(job->strings[job->mine[k]], job->include_reverse);
+    for (size_t k = 0; k < job->n_mine; ++k) {
+        struct bwt_table *t = NULL;
+        const int rc = build_complete_table_try(job->strings[job->mine[k]], job->include_reverse, &t);
+        job->out[job->mine[k]] = rc == 0 ? t : NULL;
+        if (rc != 0) {
+            job->failed++;
+            if (!job->first_error) job->first_error = rc;
+        }
+    }
     stralg_amd_release();
+    if (job->on_caller) {
+        tls_ctx = saved_ctx;
+        tls_device = saved_device;
+        ctx_key_set(saved_ctx);
+        if (have_set) (void)pthread_setaffinity_np(pthread_self(), sizeof saved_set, &saved_set);
+    }
     return NULL;
 }
 
@@ -1015,7 +1125,8 @@ int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, b
     size_t *lengths = malloc((count ? count : 1) * sizeof *lengths);
     if (!lengths) return -2;
     for (size_t k = 0; k < count; ++k) lengths[k] = strlen((const char *)strings[k]);
-    /* every device `workers` times in the list of lanes, device-major: LPT deals the records over all of them */
+    /* every device `workers` times in the list of lanes, worker-major (lane w * n_devices + d is worker w of device d):
+     * LPT deals the records over all of them */
     const int workers = stralg_amd_farm_workers_per_device(lengths, count, n_devices);
     int *lanes = malloc((size_t)n_devices * (size_t)workers * sizeof *lanes);
     if (!lanes) {
@@ -1056,7 +1167,7 @@ static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count,
                     const size_t t = order[j];
                     order[j] = order[j - 1], order[j - 1] = t;
                 }
-            jobs[d] = (struct farm_job){strings, out, order + first, at - first, include_reverse, devices[d]};
+            jobs[d] = (struct farm_job){strings, out, order + first, at - first, include_reverse, devices[d], false, 0, 0};
         }
         /* a lane whose thread cannot be created (EAGAIN under a thread limit) is run by the caller after the
          * others have been started: every record is built either way, and only created threads are joined */
@@ -1066,10 +1177,15 @@ static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count,
         } else {
             for (int d = 0; d < n_devices; ++d) created[d] = pthread_create(&threads[d], NULL, farm_worker, &jobs[d]) == 0;
             for (int d = 0; d < n_devices; ++d)
-                if (!created[d]) (void)farm_worker(&jobs[d]);
+                if (!created[d]) {
+                    jobs[d].on_caller = true;
+                    (void)farm_worker(&jobs[d]);
+                }
             for (int d = 0; d < n_devices; ++d)
                 if (created[d]) pthread_join(threads[d], NULL);
             free(created);
+            /* records that could not be built: out[k] == NULL for each, their number is the (positive) return value */
+            for (int d = 0; d < n_devices; ++d) rc += (int)jobs[d].failed;
         }
     }
     free(threads), free(jobs), free(lengths), free(lane), free(order);
@@ -1087,5 +1203,5 @@ int stralg_amd_fasta_tables_batch(struct fasta_records *records, bool include_re
     for (struct fasta_record_impl *rec = records->recs; rec; rec = rec->next) strings[k++] = rec->seq;
     const int rc = stralg_amd_build_tables_batch(strings, n, include_reverse, devices, n_devices, out);
     free(strings);
-    return rc < 0 ? rc : (int)n;
+    return rc < 0 ? rc : (int)n; /* (records that could not be built have out[k] == NULL) */
 }

@@ -106,19 +106,25 @@ __global__ void readback_kernel(const uint32_t *__restrict__ src, uint32_t count
 }
 } // namespace sx
 
+constexpr int kReadbackSpinUs = 150;
 int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst)
 {
     if (count > 1024) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
     const uint32_t seq = ++ctx->readback_seq ? ctx->readback_seq : ++ctx->readback_seq; // (never 0: the page starts zeroed)
     hipLaunchKernelGGL(sx::readback_kernel, dim3(1), dim3(256), 0, ctx->stream, d_src, (uint32_t)count, ctx->h_pin, seq);
     if (hipGetLastError() != hipSuccess) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback launch refused");
+    // The word usually arrives within tens of microseconds (the device is a launch or two behind the host), which is
+    // what the poll is for: hipStreamSynchronize sleeps through that.  A wait that lasts longer -- milliseconds of queued
+    // work in front of the read-back -- is left to the runtime: a farm runs several workers a device, all pinned to the
+    // CPUs of one NUMA node beside the pager and remap helpers, and a spinning worker takes a core from those.
     volatile uint32_t *flag = ctx->h_pin + 1024;
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t spins = 0;
     while (*flag != seq) {
-        if ((++spins & 0x3FFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kReadbackSpinUs)) break;
     }
-    if (*flag != seq) SX_CHECK(hipStreamSynchronize(ctx->stream)); // (slow device, or a fault: let the runtime say)
+    if (*flag != seq) SX_CHECK(hipStreamSynchronize(ctx->stream)); // (a long wait, or a fault: let the runtime say)
     std::atomic_thread_fence(std::memory_order_acquire);
     if (*flag != seq) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback: the sequence word did not arrive");
     if (ctx->launch_err != hipSuccess) return launch_error(ctx);
@@ -223,6 +229,9 @@ int sx_device_numa_node(int device)
     return node;
 }
 
+static std::atomic<int> g_live_contexts{0};
+extern "C" int sx_ctx_live_count(void) { return g_live_contexts.load(); }
+
 int sx_ctx_create(int device, sx_ctx **out)
 {
     if (!out) return SX_E_ARG;
@@ -247,6 +256,7 @@ int sx_ctx_create(int device, sx_ctx **out)
         return SX_E_INTERNAL;
     }
     memset(ctx->h_pin, 0, 8192); // (the read-back sequence word starts at 0)
+    g_live_contexts.fetch_add(1);
     *out = ctx;
     return 0;
 }
@@ -279,6 +289,7 @@ void sx_ctx_destroy(sx_ctx *ctx)
     for (char *b : ctx->h_stage)
         if (b) (void)hipHostFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    g_live_contexts.fetch_sub(1);
     delete ctx;
 }
 

@@ -102,9 +102,14 @@ __global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const ui
 }
 
 // pairs in partition order -> inv; workgroup b of XCD x = b % 8 takes the x-th eighth of the pairs, in order
-__global__ __launch_bounds__(kBlock) void inverse_apply_kernel(const uint2 *__restrict__ pairs, uint64_t N, uint32_t *__restrict__ inv, int by_xcd)
+// A target array that is not a permutation leaves slots of `pairs` unwritten (the partition pass drops what overflows a
+// window and counts it in `bad`): such a slot holds whatever the slab held before, so nothing is stored once `bad` is
+// set, and no store leaves [0, N) whatever a slot holds.
+__global__ __launch_bounds__(kBlock) void inverse_apply_kernel(const uint2 *__restrict__ pairs, uint64_t N, uint32_t *__restrict__ inv, int by_xcd,
+                                                               const uint32_t *__restrict__ bad)
 {
     constexpr int kPer = 8;
+    if (bad && *bad) return; // (uniform: the partition pass has ended)
     const uint64_t chunks = (N + (uint64_t)kBlock * kPer - 1) / ((uint64_t)kBlock * kPer);
     const uint64_t per_xcd = (chunks + 7) / 8;
     const uint64_t chunk = by_xcd ? (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (uint64_t)blockIdx.x;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void inverse_apply_kernel(const uint2 *__re
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const uint64_t j = j0 + (uint64_t)k * kBlock + threadIdx.x;
-        if (j < N) inv[e[k].x] = e[k].y;
+        if (j < N && (uint64_t)e[k].x < N) inv[e[k].x] = e[k].y;
     }
 }
 
@@ -269,7 +274,7 @@ int sx_scatter_permutation(sx_ctx *ctx, const uint32_t *targets, const uint32_t 
               cursor, pairs, bad);
     const uint64_t chunks = (N + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
     sx_launch(ctx, kclass, N * 12, inverse_apply_kernel, dim3((uint32_t)(((chunks + 7) / 8) * 8)), dim3(kBlock), (const uint2 *)pairs, N, out,
-              by_xcd);
+              by_xcd, (const uint32_t *)bad);
     return 0;
 }
 

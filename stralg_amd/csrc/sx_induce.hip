@@ -1897,9 +1897,12 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
 }
 
 // steps of the tail kernel per launch: a run that outlasts them goes to the device-wide jump (run_fill).  In a pass
-// queued as a whole nobody is there to start that jump, so the tail kernel gets the steps of any run that the
-// classification did not report (shorter than two tiles, 8191 symbols: a step of its loop takes a few microseconds).
-constexpr uint32_t kTailIters = 64, kTailItersUnattended = 16384;
+// queued as a whole nobody is there to start that jump, so the tail kernel gets more steps -- but not the 16 384 that
+// would see any run the classification did not report (shorter than two tiles, 8191 symbols) to its end: runs of
+// differing lengths just under that never meet the jump's condition (every entry of the round continued), and one
+// workgroup then ground through thousands of dependent steps of a few microseconds each while the chip idled.  A
+// bucket that outlasts these steps is reported (tail_report) and carried on attended, with the device-wide jump.
+constexpr uint32_t kTailIters = 64, kTailItersUnattended = 1024;
 template <class WT>
 void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, int mode, uint32_t c, int dir)
 {

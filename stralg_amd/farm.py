@@ -30,40 +30,108 @@ def _dist():
     return None
 
 
+# The group that carries the timing barrier and the scalar reductions, and the device its tensors live on: RCCL
+# ("nccl") with tensors on the rank's GPU, or gloo with CPU tensors (init_collectives decides, every rank alike).
+_COLL = {"group": None, "device": None, "backend": None}
+
+
+def init_collectives(rank, world, dev=None, prefer="nccl", attempt_timeout_s=180):
+    """Process groups of an N > 1 run.  The default group is gloo (CPU, TCP on 127.0.0.1 / MASTER_ADDR): it always comes
+    up and is the control plane.  With prefer == "nccl" and a GPU, an RCCL group is created beside it and tried once (an
+    all-reduce of ones that must sum to `world`); whether EVERY rank's attempt succeeded is agreed over gloo, and only
+    then do the barrier and the reductions of the timed region go over RCCL -- otherwise all ranks stay on gloo and the
+    reason is reported.  Nothing on the data path is collective either way.  Returns a dict for the bench line:
+    collective_backend, nccl_error, n_ranks_seen."""
+    import datetime
+    import os
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
+    info = {"collective_backend": "gloo", "nccl_error": None}
+    _COLL.update(group=None, device=None, backend="gloo")
+    forced = os.environ.get("STRALG_BENCH_FORCE_NCCL_ATTEMPT") == "1"  # (tests: the fall-back branch on a box without GPUs)
+    if prefer == "nccl" and ((dev is not None and dev.type == "cuda") or forced):
+        ok, err, g = 1, None, None
+        try:
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=attempt_timeout_s))
+            t = torch.ones(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=g)
+            if dev is not None and dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            if int(round(float(t.item()))) != world:
+                raise RuntimeError(f"RCCL all-reduce of ones gave {float(t.item())}, expected {world}")
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL or the runtime raises here: the run goes on over gloo
+            ok, err = 0, f"{type(e).__name__}: {e}".replace("\n", " ")[:400]
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # (default group: gloo)
+        if int(flag.item()) == 1:
+            _COLL.update(group=g, device=dev, backend="nccl")
+            info["collective_backend"] = "nccl"
+        else:
+            info["nccl_error"] = err or "the RCCL attempt failed on another rank"
+    elif prefer == "nccl":
+        info["nccl_error"] = "not attempted: no GPU device on this rank"
+    ones = torch.ones(1, dtype=torch.float64, device=_COLL["device"])
+    dist.all_reduce(ones, group=_COLL["group"])
+    info["n_ranks_seen"] = int(round(float(ones.item())))
+    return info
+
+
+def collective_backend():
+    return _COLL["backend"]
+
+
+def gather_objects(obj):
+    """[rank 0's object, rank 1's, ...] over the gloo control plane (bookkeeping only)"""
+    dist = _dist()
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def _barrier():
+    dist = _dist()
+    if dist is None:
+        return
+    import torch
+    t = torch.zeros(1, dtype=torch.int32, device=_COLL["device"])
+    dist.all_reduce(t, group=_COLL["group"])
+    if _COLL["device"] is not None and _COLL["device"].type == "cuda":
+        torch.cuda.synchronize(_COLL["device"])
+
+
 def fence(cuda=True):
     """barrier + device sync on both sides, as bench.py's timing contract requires."""
-    dist = _dist()
     if cuda:
         import torch
         torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier()
     if cuda:
         import torch
         torch.cuda.synchronize()
 
 
 def reduce_scalars(elapsed, units, device=None):
-    """(max elapsed over ranks, sum of units over ranks)."""
+    """(max elapsed over ranks, sum of units over ranks), over the group init_collectives chose (`device` is kept for
+    callers that set up torch.distributed themselves: the tests' plain gloo groups)."""
     dist = _dist()
     if dist is None:
         return elapsed, units
     import torch
+    if _COLL["backend"] is not None:
+        device = _COLL["device"]
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_COLL["group"])
+    dist.all_reduce(u, op=dist.ReduceOp.SUM, group=_COLL["group"])
     return float(t.item()), int(round(u.item()))
 
 
 def gather_ints(value):
     """[value of rank 0, value of rank 1, ...] (bookkeeping only)"""
-    dist = _dist()
-    if dist is None:
-        return [int(value)]
-    out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, int(value))
-    return [int(v) for v in out]
+    return [int(v) for v in gather_objects(int(value))]
 
 
 def timed(step, steps, warmup, cuda=True):

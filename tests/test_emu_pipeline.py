@@ -306,6 +306,31 @@ def test_fused_build_tables(emu_ctx, golden):
         assert (ot == oracle.o_table(x, want, sigma)).all(), (sigma, n)
 
 
+def test_inverse_of_a_non_permutation_stays_inside(emu_ctx):
+    """sx_sa_inverse_lcp on an array that is not a permutation (a duplicated value, hence a missing one, in windows of
+    the two-pass form that differ): SX_E_ARG, and no store outside the arrays.  The window that misses a value has an
+    unwritten slot in the pair buffer, which holds whatever the SORT slab held before -- so the slab is dirtied by a
+    build first (the harness's fresh slab would be zeros); under tests/test_emu_asan.py an out-of-range store is a report."""
+    from stralg_amd import StralgAmdError
+    x = synth(9000, 5, 77)
+    emu_ctx.sa_build(x, 5)  # leaves sort keys (large words) in the slab the pairs are staged in
+    sa = oracle.sa_is(x, 5)
+    for src, dst in ((10, 8000), (8000, 10)):  # (windows of 256 targets in the harness)
+        bad = sa.copy()
+        bad[np.flatnonzero(sa == dst)[0]] = src  # value `src` twice, `dst` never: one window overflows, one has a slot left
+        with pytest.raises(StralgAmdError):
+            emu_ctx.inverse_lcp(x, bad, want_lcp=False)
+    bad = sa.copy()
+    bad[np.flatnonzero(sa == 301)[0]] = 300  # both in one window: its count is right, nothing to notice (compute_inverse,
+    emu_ctx.inverse_lcp(x, bad, want_lcp=False)  # suffix_array.c:55-62, checks nothing either) -- but every store stays inside
+    bad = sa.copy()
+    bad[5] = 0xFFFFFFF0  # a value beyond N
+    with pytest.raises(StralgAmdError):
+        emu_ctx.inverse_lcp(x, bad, want_lcp=False)
+    inv, _ = emu_ctx.inverse_lcp(x, sa, want_lcp=False)  # the context is as usable as before
+    assert (inv == oracle.inverse(sa)).all()
+
+
 def test_next_rows(emu_ctx, golden):
     """inverse, LCP and batched exact search kernels against the reference's vectors"""
     import os
@@ -646,3 +671,84 @@ def test_threaded_host_layer(emu_ctx, golden, monkeypatch):
             for i in (0, 1, N // 2, N):
                 assert C.addressof(t.contents.o_indices[i].contents) == base + 4 * sigma * i
             lib.completely_free_bwt_table(t)
+
+
+def _c_structs():
+    """stralg/suffix_array.h:10-20, remap.h:9-19, bwt.h:36-44 as ctypes structures"""
+    import ctypes as C
+
+    class SA(C.Structure):
+        _fields_ = [("string", C.POINTER(C.c_uint8)), ("length", C.c_uint32), ("array", C.POINTER(C.c_uint32)),
+                    ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+
+    class RT(C.Structure):
+        _fields_ = [("alphabet_size", C.c_uint32), ("table", C.c_byte * 256), ("rev_table", C.c_byte * 128)]
+
+    class BT(C.Structure):
+        _fields_ = [("remap_table", C.POINTER(RT)), ("sa", C.POINTER(SA)), ("c_table", C.POINTER(C.c_uint32)),
+                    ("o_table", C.POINTER(C.c_uint32)), ("o_indices", C.POINTER(C.POINTER(C.c_uint32))),
+                    ("ro_table", C.POINTER(C.c_uint32)), ("ro_indices", C.POINTER(C.POINTER(C.c_uint32)))]
+
+    return SA, RT, BT
+
+
+def test_thread_exit_releases_its_context(emu_ctx, golden):
+    """A caller written against the reference's API never calls stralg_amd_release(): a worker thread that builds tables
+    and exits must not keep its device context (GiBs of workspace on a GPU).  The context hangs on a pthread key whose
+    destructor runs at thread exit (stralg_host.c)."""
+    import ctypes as C
+    import threading
+    SuffixArray, _, _ = _c_structs()
+    lib = emu_ctx.lib
+    lib.stralg_amd_live_contexts.restype = C.c_int
+    lib.sa_is_construction.argtypes = [C.c_char_p, C.c_uint32]
+    lib.sa_is_construction.restype = C.POINTER(SuffixArray)
+    lib.free_suffix_array.argtypes = [C.POINTER(SuffixArray)]
+    lib.free_suffix_array.restype = None
+    c = golden["ref/mississippi"]
+    text = bytes(c["sym"]) + b"\0"
+    before = lib.stralg_amd_live_contexts()
+    seen = []
+
+    def work(release):
+        sa = lib.sa_is_construction(text, int(c["sigma"]))
+        seen.append((lib.stralg_amd_live_contexts(), np.ctypeslib.as_array(sa.contents.array, shape=(sa.contents.length,)).copy()))
+        lib.free_suffix_array(sa)
+        if release:
+            lib.stralg_amd_release()
+
+    for release in (False, True, False):
+        th = threading.Thread(target=work, args=(release,))
+        th.start()
+        th.join()
+        assert lib.stralg_amd_live_contexts() == before, "the exited thread's context is still alive"
+    assert all(live == before + 1 and (arr == c["sa"]).all() for live, arr in seen)
+
+
+def test_farm_goes_on_past_a_record_it_cannot_build(emu_ctx, golden):
+    """stralg_amd_build_tables_batch: a record with more letters than a remap table holds (stralg/remap.h:14-18) gets
+    out[k] = NULL and is counted in the return value; the other records -- also the ones of the same lane -- are built."""
+    import ctypes as C
+    _, _, BT = _c_structs()
+    lib = emu_ctx.lib
+    lib.stralg_amd_build_tables_batch.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_bool, C.POINTER(C.c_int), C.c_int,
+                                                  C.POINTER(C.POINTER(BT))]
+    lib.stralg_amd_build_tables_batch.restype = C.c_int
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    too_many = bytes(range(1, 200)) * 3  # 199 distinct letters
+    names = ["ref/mississippi", None, "ref/repetitive", "ref/fasta3", None]
+    raws = [bytes(golden[k]["raw"]) if k else too_many for k in names]
+    arr = (C.c_char_p * len(raws))(*raws)
+    out = (C.POINTER(BT) * len(raws))()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.stralg_amd_build_tables_batch(arr, len(raws), True, devs, 2, out) == 2
+    for k, name in enumerate(names):
+        if name is None:
+            assert not out[k]
+            continue
+        c, t = golden[name], out[k]
+        N = t.contents.sa.contents.length
+        assert (np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)) == c["sa"]).all(), name
+        assert (np.ctypeslib.as_array(t.contents.ro_table, shape=(N + 1, c["sigma"])) == c["ro"]).all(), name
+        lib.completely_free_bwt_table(t)

@@ -131,6 +131,7 @@ def test_bench_launches_its_own_ranks_on_fasta_records(emu_ctx):
     assert len(lines) == 1, out.stdout[-2000:]
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["scaling"] == "weak" and doc["unit"] == "Msuffixes/s"
+    assert doc["collective_backend"] == "gloo" and doc["n_ranks_seen"] == 2 and doc["collectives"]["nccl_error"] is None
     assert doc["verified"] is True and len(doc["verified_checks"]) == 4
     assert doc["config"]["n"] == 5003 and "FASTA" in doc["config"]["workload"]
     fr = doc["fasta_record"]
@@ -143,6 +144,25 @@ def test_bench_launches_its_own_ranks_on_fasta_records(emu_ctx):
                 "host_tables_ms_per_record", "host_tables_Msuffixes_per_s"):
         assert key in fr and fr[key] >= 0, key
     assert fr["stream_ms_per_record"] > 0 and fr["egress_inclusive_Msuffixes_per_s"] > 0
+
+
+def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up(emu_ctx):
+    """farm.init_collectives: gloo is the control plane; an RCCL group is tried beside it and used only when the attempt
+    succeeds on every rank.  Here (no GPU: the attempt is forced and must fail) both ranks agree on gloo, the run goes
+    on, and the line says which backend carried the barrier, why, how many ranks it saw and who they were."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(STRALG_BENCH_EMU="1", STRALG_BENCH_BACKEND="nccl", STRALG_BENCH_FORCE_NCCL_ATTEMPT="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "1500", "--steps", "1",
+                          "--warmup", "0", "--no-egress"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert doc["n_gpus"] == 2 and doc["verified"] is True
+    assert doc["collective_backend"] == "gloo" and doc["n_ranks_seen"] == 2
+    co = doc["collectives"]
+    assert co["backend"] == "gloo" and co["nccl_error"] and co["control_plane"] == "gloo"
+    assert [r["rank"] for r in co["ranks"]] == [0, 1]
 
 
 def test_bench_default_run_carries_the_other_configs(emu_ctx):

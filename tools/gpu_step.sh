@@ -3,6 +3,7 @@
 #   tests[:K_EXPR]   pytest -m gpu (optionally -k K_EXPR)
 #   bench[:ARGS]     python bench.py ARGS > bench[_<n>].json
 #   bench2           two ranks sharing the one GPU (gloo carries the scalars): the N > 1 path of bench.py
+#   bench2n          the same with RCCL tried first (refused for two ranks on one GPU: the fall-back to gloo, on hardware)
 #   prof             rocprofv3 --kernel-trace --stats of bench.py (summary via tools/profile_summary.py)
 set -o pipefail
 tag=$1; shift
@@ -25,6 +26,11 @@ for step in "$@"; do
     bench2)
       STRALG_BENCH_BACKEND=gloo STRALG_BENCH_SHARE_GPU=1 timeout -k 10 900 python bench.py --gpus 2 $arg > "$out/bench2_$k.json" 2> "$out/bench2_$k.err"
       rc=$?; tail -c 600 "$out/bench2_$k.err"; head -c 300 "$out/bench2_$k.json"; echo;;
+    bench2n)
+      # the same with the default backend: RCCL is tried first; two ranks on ONE GPU are refused by RCCL ("duplicate GPU"),
+      # which is the fall-back branch of farm.init_collectives on real hardware (the line then says collective_backend gloo)
+      STRALG_BENCH_SHARE_GPU=1 timeout -k 10 900 python bench.py --gpus 2 $arg > "$out/bench2n_$k.json" 2> "$out/bench2n_$k.err"
+      rc=$?; tail -c 600 "$out/bench2n_$k.err"; head -c 300 "$out/bench2n_$k.json"; echo;;
     trace)
       # rocprofv3 kernel trace of bench.py ARGS (python3 directly after --), per-kernel stats and the last step's timeline
       rm -rf "$out/trace_$k"; mkdir -p "$out/trace_$k"

@@ -9,10 +9,14 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 first = sys.argv[2] if len(sys.argv) > 2 else "cls_first"
 last = sys.argv[3] if len(sys.argv) > 3 else "otable"
+if not rows:
+    sys.exit(f"step_timeline: no kernel trace under {sys.argv[1]}")
 ends = [i for i, r in enumerate(rows) if last in r[2]]
-i1 = ends[-1]
+i1 = ends[-1] if ends else len(rows) - 1  # (--no-tables, byte workloads: no such kernel -- up to the trace's end)
 starts = [i for i, r in enumerate(rows[:i1]) if first in r[2]]
-i0 = starts[-1]
+if not starts:  # (the direct sort has no cls_first: the whole trace)
+    print(f"step_timeline: no kernel matching '{first}' before the last '{last}': showing the whole trace", file=sys.stderr)
+i0 = starts[-1] if starts else 0
 while i0 > 0 and rows[i0][0] - rows[i0 - 1][1] < 20000 and first not in rows[i0 - 1][2]:  # the step's leading copies
     i0 -= 1
 prev = rows[i0][0]
