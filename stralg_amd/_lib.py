@@ -52,6 +52,7 @@ def load(path=None):
         "sx_device_numa_node": (C.c_int, [C.c_int]),
         "sx_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "sx_ctx_destroy": (None, [vp]),
+        "sx_ctx_live_count": (C.c_int, []),
         "sx_last_error": (C.c_char_p, [vp]),
         "sx_ctx_trim": (None, [vp]),
         "sx_ctx_set_flag": (C.c_int, [vp, C.c_int, C.c_int]),
@@ -98,7 +99,7 @@ def load(path=None):
     return lib
 
 
-EXPORTS = ["sx_device_count", "sx_device_numa_node", "sx_ctx_create", "sx_ctx_destroy", "sx_last_error", "sx_ctx_trim", "sx_ctx_set_flag",
+EXPORTS = ["sx_device_count", "sx_device_numa_node", "sx_ctx_create", "sx_ctx_destroy", "sx_ctx_live_count", "sx_last_error", "sx_ctx_trim", "sx_ctx_set_flag",
            "sx_sa_build", "sx_sa_build_dev", "sx_sa_bwt_build_dev", "sx_bwt_tables", "sx_bwt_tables_dev",
            "sx_bwt_tables_from_bwt_dev", "sx_build_tables", "sx_sa_inverse_dev", "sx_sa_lcp_dev", "sx_sa_inverse_lcp",
            "sx_bwt_exact_search_dev", "sx_build_tables_stream", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_profile_enable", "sx_profile_only",
