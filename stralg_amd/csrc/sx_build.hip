@@ -190,6 +190,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
 
     const uint32_t *sorted_lms = nullptr;
     const void *seed_windows = nullptr; // windows of the sorted LMS suffixes, when the sort carried them
+    bool seed_windows_u32 = false;      // ... as 32-bit words (the prefix-key sort's), whatever the text's window width
     if (ti.m <= 1) {
         // only the sentinel is LMS: it alone seeds the induction
         uint32_t *one = an.take<uint32_t>(1);
@@ -213,6 +214,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         if (resolved) {
             ctx->stats.lms_path = 1;
             ctx->stats.n_samples = ti.m;
+            seed_windows_u32 = seed_windows != nullptr;
         } else {
             sorted_lms = nullptr;
             seed_windows = nullptr;
@@ -313,7 +315,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         sorted_lms = slms;
     }
 
-    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, seed_windows, d_sa, d_bwt, an));
+    SX_TRY(sx_induce(ctx, ti, sigma, sorted_lms, seed_windows, seed_windows_u32, d_sa, d_bwt, an));
     SX_TRY(sx_sync(ctx));
     ctx->stats.ms_total =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -1744,6 +1744,23 @@ __global__ __launch_bounds__(kBlock) void bwt_from_windows_kernel(const WT *__re
     }
 }
 
+// the sort's 32-bit seed windows (fewer symbols, same layout) as the 64-bit words the passes of a wide alphabet read
+__global__ __launch_bounds__(kBlock) void widen_windows_kernel(const uint32_t *__restrict__ in, uint64_t count, uint64_t *__restrict__ out)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4u;
+    if (i0 >= count) return;
+    if (i0 + 4u <= count && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i0);
+        uint4 a, b;
+        a.x = v.x, a.y = 0, a.z = v.y, a.w = 0;
+        b.x = v.z, b.y = 0, b.z = v.w, b.w = 0;
+        *reinterpret_cast<uint4 *>(out + i0) = a;
+        *reinterpret_cast<uint4 *>(out + i0 + 2) = b;
+    } else {
+        for (uint64_t i = i0; i < count && i < i0 + 4u; ++i) out[i] = in[i];
+    }
+}
+
 template <class WT>
 __global__ void set_entry_kernel(uint32_t *SA, WT *WN, uint8_t *BW, uint32_t p, const uint8_t *T, wnd_cfg cfg)
 {
@@ -2085,7 +2102,7 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
 
 template <class WT>
 int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
-                 const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena, wnd_cfg cfg)
+                 const void *seed_windows, bool seed_windows_u32, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena, wnd_cfg cfg)
 {
     const uint64_t N = ti.N;
     // buckets that hold anything: 0 .. maxc
@@ -2102,7 +2119,9 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.BW = bwt_out ? bwt_out : arena.take<uint8_t>(N);
     st.N = N;
     st.m = ti.m;
-    WT *seedW = seed_windows ? (WT *)seed_windows : arena.take<WT>(ti.m ? ti.m : 1);
+    // (seed_windows_u32: the prefix-key sort's 32-bit words for a text whose windows are 64-bit: widened below)
+    const bool widen = seed_windows && seed_windows_u32 && sizeof(WT) == 8;
+    WT *seedW = seed_windows && !widen ? (WT *)seed_windows : arena.take<WT>(ti.m ? ti.m : 1);
     st.cursor[0] = arena.take<uint32_t>(256);
     st.cursor[1] = arena.take<uint32_t>(256);
     st.ranges = arena.take<uint32_t>(2 * (kMaxSpec + 3));
@@ -2151,7 +2170,10 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
 
     // windows of the sorted LMS suffixes: the only systematic text access of both passes, unless
     // they already came along with the sort keys (sx_lmssort.hip)
-    if (!seed_windows)
+    if (widen)
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.m * 12, widen_windows_kernel, dim3(sx_div_up(ti.m, kBlock * 4)), dim3(kBlock),
+                  (const uint32_t *)seed_windows, (uint64_t)ti.m, (uint64_t *)seedW);
+    else if (!seed_windows)
         sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.m * (4 + sizeof(WT) + 16), fill_windows_kernel<WT>,
                   dim3(sx_div_up(ti.m, kBlock)), dim3(kBlock), ti.T, sorted_lms, ti.m, cfg, seedW);
     // the sentinel suffix (sa_is.c:463: SA[0] = n)
@@ -2300,11 +2322,11 @@ int sx_bwt_from_seed_windows(sx_ctx *ctx, const uint32_t *seedw, uint64_t N, uin
 }
 
 int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
-              const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena)
+              const void *seed_windows, bool seed_windows_u32, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena)
 {
     if (ti.N > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "induce: n exceeds 32-bit positions");
     wnd_cfg cfg;
     const bool wide = sx_window_cfg(ti.maxc, cfg);
-    if (!wide) return induce_typed<uint32_t>(ctx, ti, sigma, sorted_lms, seed_windows, SA, bwt_out, arena, cfg);
-    return induce_typed<uint64_t>(ctx, ti, sigma, sorted_lms, seed_windows, SA, bwt_out, arena, cfg);
+    if (!wide) return induce_typed<uint32_t>(ctx, ti, sigma, sorted_lms, seed_windows, false, SA, bwt_out, arena, cfg);
+    return induce_typed<uint64_t>(ctx, ti, sigma, sorted_lms, seed_windows, seed_windows_u32, SA, bwt_out, arena, cfg);
 }

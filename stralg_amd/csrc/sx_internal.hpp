@@ -104,9 +104,10 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
 
 // ---- sx_induce.hip
 size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma);
-// seed_windows: optional device array (one window per sorted LMS suffix, layout of sx_window.hpp)
+// seed_windows: optional device array (one window per sorted LMS suffix, layout of sx_window.hpp); seed_windows_u32: they
+// are 32-bit words although the text's windows are 64-bit (the prefix-key sort's: fewer symbols, same layout)
 int sx_induce(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint32_t *sorted_lms,
-              const void *seed_windows, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena);
+              const void *seed_windows, bool seed_windows_u32, uint32_t *SA, uint8_t *bwt_out, sx_arena &arena);
 
 // ---- sx_extras.hip: out[targets[i]] = values[i] (null: i) for a permutation of [0, N), in two passes that keep the stores
 // inside windows the L2 holds (half the time of the plain scatter from 2^23 entries on)

@@ -1202,6 +1202,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t A = 0;
     int kbits = 64;
     bool embed = false;
+    uint32_t embed_chars = 0; // symbols of the windows the keys carry (embed)
     uint64_t kmask = ~0ull;
 #ifndef SX_DENSE4
 #define SX_DENSE4 1
@@ -1227,12 +1228,20 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             kbits_base = sx_bitlen(top - 1) > 0 ? sx_bitlen(top - 1) : 1;
             kbits_wnd = kbits > kbits_base ? kbits : kbits_base; // (dense keys: the windows of the base-5 keys, for which the static kernels are built)
         }
-        // symbol windows in the unsorted key bits, when at least four symbols fit (32-bit windows only)
+        // Symbol windows in the unsorted key bits, when at least four symbols fit.  Texts of more than 16 symbols, whose
+        // induction windows are 64-bit words, take part since round 4: the sort hands the windows on as 32-bit words (the
+        // same layout with fewer symbols: code fields of B bits above a 4-bit count), so up to 28 / B symbols, and from
+        // two on they are worth it -- an LMS seed's first symbol is its entry's bucket, its second the symbol byte of
+        // the entry it induces, and the text is read again where that entry is scanned.  (Without them every seed's
+        // window was gathered from the text in suffix order before the L pass: 3.6 * 10^8 random 16-byte reads, 8.3 of
+        // the 94 ms of 1 GiB of bytes through the induced-sort passes.)
         const bool wide = sx_window_cfg(ti.maxc, wcfg);
         uint32_t wchars = 0;
-        if (!wide && 64 - kbits_wnd > kCntBits) wchars = (uint32_t)(64 - kbits_wnd - kCntBits) / wcfg.B;
+        if (64 - kbits_wnd > kCntBits) wchars = (uint32_t)(64 - kbits_wnd - kCntBits) / wcfg.B;
         if (wchars > wcfg.CW) wchars = wcfg.CW;
-        embed = wchars >= 4;
+        if (wide && wchars > (32u - (uint32_t)kCntBits) / wcfg.B) wchars = (32u - (uint32_t)kCntBits) / wcfg.B;
+        embed = wide ? wchars >= 2 : wchars >= 4;
+        embed_chars = embed ? wchars : 0;
         if (all_suffixes) {
             // no induction follows a direct sort; one symbol of window is the BWT symbol of the suffix, for free
             wchars = 64 - kbits >= (int)(kCntBits + wcfg.B) ? 1u : 0u;
@@ -1433,8 +1442,9 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     }
 
     wnd_cfg full_wcfg; // refined slots get their windows straight from the text
-    (void)sx_window_cfg(ti.maxc, full_wcfg);
+    const bool wide_windows = sx_window_cfg(ti.maxc, full_wcfg);
     if (all_suffixes) full_wcfg.CW = 1; // (the seed windows are 32-bit words: one wide symbol fits, seven do not)
+    else if (wide_windows && embed) full_wcfg.CW = embed_chars; // (32-bit words here too: as many symbols as the keys carried)
     // ties are refined with the longest key that fits (Cmax symbols a round)
     uint64_t top_r = 1;
     for (uint32_t i = 0; i < Cmax; ++i) top_r *= base;

@@ -69,6 +69,11 @@ def init_collectives(rank, world, dev=None, prefer="nccl", attempt_timeout_s=180
             info["collective_backend"] = "nccl"
         else:
             info["nccl_error"] = err or "the RCCL attempt failed on another rank"
+            if g is not None:  # its watchdog and proxy threads would go on polling beside the timed steps
+                try:
+                    dist.destroy_process_group(g)
+                except Exception:  # noqa: BLE001
+                    pass
     elif prefer == "nccl":
         info["nccl_error"] = "not attempted: no GPU device on this rank"
     ones = torch.ones(1, dtype=torch.float64, device=_COLL["device"])

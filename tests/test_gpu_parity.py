@@ -717,6 +717,38 @@ def test_induced_passes_of_wide_alphabets_at_size(gpu_ctx):
         gpu_ctx.set_no_direct_sort(False)
 
 
+def _reference_pins(log2n, sigma, sa, bw=None, c=None, o=None):
+    """BASELINE.json configs[1]-[3] against the UNMODIFIED reference's own output at size
+    (tests/golden/golden_big.npz, written by tests/golden/make_golden_big.py from oracle/_ref's sa_is_mem_construction,
+    sa_is_mem.c:471-494, on the same splitmix64 text): SHA-256 of the whole suffix array (and of every 2^26-entry chunk,
+    so that a mismatch is located), every 2^20-th entry, the BWT's SHA-256, and the symbol counts = C table and last O row."""
+    import hashlib
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_big.npz"))
+    key = f"n{log2n}/s{sigma}"
+    N = (1 << log2n) + 1
+    assert int(z[key + "/seed"][0]) == 42 and sa.numel() == N
+    want_sampled = z[key + "/sa_sampled"]
+    got_sampled = torch.cat([sa[:: 1 << 20], sa[-1:]]).cpu().numpy().view(np.uint32)
+    assert (got_sampled == want_sampled).all(), f"{key}: sampled suffix-array entries differ from the reference's"
+    h, chunk = hashlib.sha256(), 1 << 26
+    for k, s0 in enumerate(range(0, N, chunk)):
+        b = sa[s0:s0 + chunk].cpu().numpy().tobytes()  # (int32 storage: the same little-endian bytes as the reference's u32)
+        assert hashlib.sha256(b).digest() == bytes(z[key + "/sa_chunk_sha256"][k]), f"{key}: suffix-array chunk {k} differs"
+        h.update(b)
+    assert h.digest() == bytes(z[key + "/sa_sha256"]), f"{key}: SHA-256 of the suffix array differs from the reference's"
+    if bw is not None:
+        hb = hashlib.sha256()
+        for s0 in range(0, N, 1 << 28):
+            hb.update(bw[s0:s0 + (1 << 28)].cpu().numpy().tobytes())
+        assert hb.digest() == bytes(z[key + "/bwt_sha256"]), f"{key}: SHA-256 of the BWT differs from the reference's"
+    if c is not None:
+        counts = z[key + "/counts"].astype(np.int64)
+        assert (c.cpu().numpy().astype(np.int64) == np.concatenate([[0], np.cumsum(counts)[:-1]])).all()  # bwt.c:22-31
+        assert (o[N * sigma:(N + 1) * sigma].cpu().numpy().astype(np.int64) == counts).all()  # the row behind the last position
+    return key
+
+
 @pytest.mark.parametrize("log2n,sigma", [(28, 5), (30, 5), (28, 256), (30, 256)])
 def test_full_size_properties(gpu_ctx, log2n, sigma):
     import torch
@@ -744,6 +776,7 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
         finally:
             gpu_ctx.set_no_direct_sort(False)
         assert bool((sa2 == sa).all())
+        _reference_pins(log2n, sigma, sa)  # ... and it is the reference's own array (SHA-256, sampled entries)
         return
     # the fused calls bench.py times: suffix array + BWT from the induced-sort passes, then C and O from that BWT
     c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
@@ -754,6 +787,7 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
     gpu_ctx.trim()  # the checks need the memory more than the library's cached workspace does
     done = verify.verify_build_on_device(text, n, sigma, sa, bw, c, o)
     assert len(done) == 3
+    _reference_pins(log2n, sigma, sa, bw, c, o)  # the reference's own SA / BWT / counts at this size, by SHA-256
     if log2n <= 28:
         # the unfused entry points (sa_is_construction, then init_bwt_table's gather) must hand over the same
         sa2, bw2 = torch.empty_like(sa), torch.empty_like(bw)

