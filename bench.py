@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--copy-text-first", action="store_true", help="the build copies the text before the classification (A/B)")
     ap.add_argument("--cpu-log2n", type=int, default=int(os.environ.get("STRALG_BENCH_CPU_LOG2N", "25")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-cpu-whole-record", action="store_true",
+                    help="skip the reference's sa_is_mem_construction on the whole 2^28 record of configs[1] (~1-2 minutes of one core)")
     ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last step's results")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
     ap.add_argument("--e2e-log2n", default="28,30", help="sizes of the host-buffer measurements")
@@ -146,17 +148,65 @@ def cpu_baseline(x, sigma, what):
     return out
 
 
-def pmc_traffic(log2n, sigma, tables, klass):
-    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
-    same command (profiles/pmc_traffic.json, made by tools/profile.sh + tools/pmc_to_json.py).  PMC counters
-    cannot be read from inside the process: the figure is replayed from that file, not measured in this run
-    (roofline.traffic_source says so); null for workloads that were not profiled."""
-    try:
-        doc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
-        c = doc[f"log2n={log2n} sigma={sigma} tables={int(tables)}"]["classes"][klass]
-        return round(c["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+def reference_pin(sa, n, sigma, seed):
+    """Bit-exactness against the UNMODIFIED reference at this size, where tests/golden/golden_big.npz holds it (the
+    reference's sa_is_mem_construction on the same splitmix64 text, seed 42; tests/golden/make_golden_big.py): SHA-256 of
+    the device's suffix array, downloaded in chunks, against the reference's.  None when no such fixture exists."""
+    import hashlib
+    import numpy as np
+    log2n = n.bit_length() - 1
+    path = os.path.join(ROOT, "tests", "golden", "golden_big.npz")
+    if n != 1 << log2n or seed != 42 or not os.path.exists(path):
         return None
+    z = np.load(path)
+    key = f"n{log2n}/s{sigma}/sa_sha256"
+    if key not in z.files:
+        return None
+    h = hashlib.sha256()
+    for s0 in range(0, n + 1, 1 << 26):
+        h.update(sa[s0:s0 + (1 << 26)].cpu().numpy().tobytes())
+    return {"fixture": f"tests/golden/golden_big.npz:{key}", "sha256": h.hexdigest()[:16] + "...",
+            "match": h.digest() == bytes(z[key]),
+            "what": "SHA-256 of the whole suffix array vs the reference's sa_is_mem_construction (sa_is_mem.c:471-494) on the same text"}
+
+
+def cpu_baseline_at_size(log2n, sigma, seed, sa_device=None):
+    """The unmodified reference's sa_is_mem_construction (oracle/_ref) on the WHOLE record of BASELINE.json configs[1]
+    (2^28 symbols; ~60-100 s on one core), next to the bounded sample above: the reference's rate falls with n
+    (BASELINE.md section 2).  Its array is compared entry by entry with the device's (sa_device) when that is given."""
+    import numpy as np
+    from oracle import pyoracle
+    from stralg_amd.synth import synth
+    if not pyoracle.have_ref():
+        return {"skipped": "oracle/_ref has not been built"}
+    n = 1 << log2n
+    x = synth(n, sigma, seed)
+    ref = pyoracle._Ref()
+    t0 = time.perf_counter()
+    sa = ref.sa_is_mem(x, sigma)
+    dt = time.perf_counter() - t0
+    out = {"n": n, "alphabet_size": sigma, "fn": "sa_is_mem_construction (sa_is_mem.c:471-494)", "kind": "reference", "cores": 1,
+           "seconds": round(dt, 1), "value": round((n + 1) / dt / 1e6, 3), "unit": "Msuffixes/s"}
+    if sa_device is not None:
+        out["device_array_identical"] = bool((sa_device.cpu().numpy().view(np.uint32) == sa).all())
+    return out
+
+
+def pmc_traffic(workload, log2n, sigma, tables, klass):
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
+    same command (profiles/pmc_traffic.json, made by tools/gpu_step.sh's prof step + tools/pmc_to_json.py).  PMC counters
+    cannot be read from inside the process: the figure is replayed from that file, not measured in this run
+    (roofline.traffic_source says so); None for workloads that were not profiled.  Returns (bytes, stale): stale when the
+    kernel sources have changed since the passes were collected (the file is stamped with their SHA-256)."""
+    try:
+        from stralg_amd._lib import kernel_sources_sha16
+        doc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
+        key = f"log2n={log2n} sigma={sigma} tables={int(tables)}"
+        entry = doc[key if workload == "dna" else f"workload={workload} " + key]
+        c = entry["classes"][klass]
+        return round(c["hbm_bytes_per_launch"]), entry.get("kernel_sources_sha16") != kernel_sources_sha16()
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 # ---- host-buffer (PCIe-inclusive) measurements, outside the timed region --------------------------------------
@@ -223,7 +273,7 @@ LMS_PATHS = {0: "none", 1: "prefix-key LMS sort + induced-sort passes", 2: "gene
              "induced-sort passes", 3: "direct prefix sort of all suffixes"}
 
 
-def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_direct=False, cuda=True):
+def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_direct=False, cuda=True, cpu_at_size=False):
     """`steps` timed steps of the hot path on one more text (generated on the device), one warm-up that doubles as the
     per-class profile, results verified on the device afterwards.  Outside bench.py's timed region."""
     import torch
@@ -270,6 +320,10 @@ def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_dir
            "dominant_class": dom, "dominant_ms_per_step": round(d["ms"], 3),
            "roofline_frac": round(d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d["ms"] > 0 else 0.0,
            "whole_step_frac_of_peak": round(alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if n == 1 << (n.bit_length() - 1):
+        # the dominant class's HBM bytes per launch from the committed rocprofv3 PMC passes of `bench.py --workload ...`
+        tr, stale = pmc_traffic(gen + ("_induced" if no_direct else ""), n.bit_length() - 1, sigma, tables, dom)
+        out["traffic"], out["traffic_stale"] = tr, stale
     ctx.trim()
     try:
         verify.verify_build_on_device(text, n, sigma, sa, bwt, c_tab if tables else None, o_tab)
@@ -277,13 +331,19 @@ def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_dir
     except AssertionError as e:
         out["verified"] = False
         out["error"] = str(e)
+    if gen in ("dna", "bytes") and cuda:
+        pin = reference_pin(sa, n, sigma, seed)
+        if pin is not None:
+            out["reference_pin"] = pin
+    if cpu_at_size:
+        out["cpu_reference_whole_record"] = cpu_baseline_at_size(n.bit_length() - 1, sigma, seed, sa)
     del text, sa, bwt, c_tab, o_tab
     if cuda:
         torch.cuda.empty_cache()
     return out
 
 
-def other_configs(ctx, dev, steps, cuda=True, log2n=30):
+def other_configs(ctx, dev, steps, cuda=True, log2n=30, cpu_whole_record=False):
     """BASELINE.json configs[1] and [3] and one hard text, so that the driver's line carries them too:
     256 MiB DNA; 1 GiB of random bytes by the default path (direct prefix sort) and through the LMS sort + induced-sort
     passes (the "wide-alphabet LDS-histogram path" configs[3] names); a genome-like 1 GiB text; a Fibonacci string
@@ -301,7 +361,8 @@ def other_configs(ctx, dev, steps, cuda=True, log2n=30):
             (f"genome_like_{size(big)}", "genome_like", big, 5, True, False),
             (f"fibonacci_{size(big)}", "periodic", big, 3, True, False)):
         try:
-            out[name] = measure_config(ctx, dev, gen, n, sig, 42, steps, tables, no_direct, cuda)
+            out[name] = measure_config(ctx, dev, gen, n, sig, 42, steps, tables, no_direct, cuda,
+                                       cpu_at_size=cpu_whole_record and gen == "dna" and n == 1 << 28)
         except Exception as e:  # noqa: BLE001 -- an extra must not take the headline line down with it
             out[name] = {"error": f"{type(e).__name__}: {e}"}
     return out
@@ -523,6 +584,12 @@ def run_rank(args):
             verified = False
             checks = [f"FAILED on rank {rank}: {e}"]
             print(f"bench.py: verification failed on rank {rank}: {e}", file=sys.stderr)
+    ref_pin = None
+    if rank == 0 and cuda and workload in ("dna", "bytes") and sa is not None and not args.no_verify:
+        ref_pin = reference_pin(sa, n, sigma, seed)  # (a fixture exists for 2^28 and 2^30 symbols, sigma 5 and 256, seed 42)
+        if ref_pin is not None and not ref_pin["match"]:
+            verified = False
+            checks.append("FAILED: the suffix array's SHA-256 differs from the reference's")
     bad_ranks, _ = farm.reduce_scalars(1.0 if verified is False else 0.0, 0, device=red_dev)
 
     # ---- the FASTA record with its ingest, every rank at once (what limits config 5: PCIe / host) --------
@@ -572,7 +639,7 @@ def run_rank(args):
                   f"one independent record per GPU")
         else:
             wl = f"sa_is_construction on {n} symbols ({workload}), alphabet_size={sigma}"
-        traffic = pmc_traffic(args.log2n, sigma, tables, dom) if workload == "dna" and args.n == 0 else None
+        traffic, traffic_stale = pmc_traffic(workload, args.log2n, sigma, tables, dom) if args.n == 0 else (None, None)
         out = {
             "metric": f"Msuffixes/s ({what}, {size_label} {alpha_label})",
             "value": round(value, 3),
@@ -600,6 +667,7 @@ def run_rank(args):
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_stale": traffic_stale,  # the kernel sources have changed since the PMC passes (None: no figure)
                 "traffic_source": (f"{PMC_TRAFFIC}: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, committed by the "
                                    "builder; not measured in this run") if traffic is not None else None,
                 "launches": d["launches"],
@@ -607,6 +675,7 @@ def run_rank(args):
             },
             "verified": verified if bad_ranks == 0.0 else False,
             "verified_checks": checks,
+            **({"reference_pin": ref_pin} if ref_pin is not None else {}),
             # per-class times of ONE untimed step with events around every launch (run between warm-up and timing)
             "kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches_per_step": v["launches"],
                             "GBps": round(v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
@@ -644,9 +713,14 @@ def run_rank(args):
             ctx.trim()
             if cuda:
                 torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(ctx, dev, max(1, args.other_steps), cuda, args.log2n)
+            out["other_configs"] = other_configs(ctx, dev, max(1, args.other_steps), cuda, args.log2n,
+                                                 cpu_whole_record=not args.no_cpu and not args.no_cpu_whole_record and not emu)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cpu_sample, sigma, f"the first {cpu_n} symbols of the record rank 0 built")
+            whole = next((c["cpu_reference_whole_record"] for c in out.get("other_configs", {}).values()
+                          if isinstance(c, dict) and "cpu_reference_whole_record" in c), None)
+            if whole is not None:  # the same baseline at a benchmark size: configs[1]'s whole 2^28-symbol record
+                out["cpu_baseline"]["whole_record"] = whole
         print(json.dumps(out), flush=True)
     if world > 1:
         farm.fence(cuda)

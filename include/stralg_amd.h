@@ -127,6 +127,9 @@ enum {
                                        (2^20); tests set small values */
     ,SX_FLAG_SAMPLE_MIN = 12       /* texts of more than 8 symbols and at least this many suffixes get a look at a sample before a
                                        prefix-key sort (negative: the default, 2^20; tests set small values) */
+    ,SX_FLAG_INDUCE_NO_HOIST = 13  /* texts of more than 8 symbols: 1 = every bucket's LMS seeds (L pass) and L-type entries (S pass)
+                                       are scanned by launches of the bucket's own, as in rounds 1 - 3; 0 (default) = all buckets'
+                                       at once, up front, placed by the text's bigram counts */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

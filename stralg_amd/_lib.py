@@ -105,3 +105,17 @@ EXPORTS = ["sx_device_count", "sx_device_numa_node", "sx_ctx_create", "sx_ctx_de
            "sx_bwt_exact_search_dev", "sx_build_tables_stream", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_profile_enable", "sx_profile_only",
            "sx_profile_reset", "sx_profile_read", "sx_kernel_class_name", "sx_last_stats",
            "sx_synth_dev", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]
+
+
+def kernel_sources_sha16():
+    """SHA-256 (first 16 hex digits) over the kernel sources the product library is built from (stralg_amd/csrc/*.hip,
+    *.hpp, in name order): what a rocprofv3 PMC pass is stamped with (tools/pmc_to_json.py) so that bench.py can tell when
+    the kernels have changed since the committed traffic figures were measured (there is no .git on the GPU box)."""
+    import glob
+    import hashlib
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "*.hip")) + glob.glob(os.path.join(here, "*.hpp"))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

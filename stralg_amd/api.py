@@ -240,6 +240,11 @@ class Context:
         finish is carried on by the host), 1 the host looks at every bucket's last range"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 9, int(mode)), "sx_ctx_set_flag")
 
+    def set_induce_hoist(self, on=True):
+        """SX_FLAG_INDUCE_NO_HOIST: texts of more than 8 symbols -- all buckets' LMS seeds / L-type entries scanned at once, up
+        front, placed by the text's bigram counts (default), or by launches of each bucket's own (rounds 1 - 3)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 13, 0 if on else 1), "sx_ctx_set_flag")
+
     def set_recurse_min(self, symbols):
         """SX_FLAG_RECURSE_MIN: reduced strings of at most 255 names recurse from this length on (negative: default)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 11, int(symbols)), "sx_ctx_set_flag")

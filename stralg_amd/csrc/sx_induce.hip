@@ -417,6 +417,51 @@ constexpr int kWideThreads = 512, kWideWaves = kWideThreads / kWave, kWideItems 
 constexpr int kWideTile = kWideThreads * kWideItems;
 constexpr uint32_t kWideChunk = 256;                  // tiles per chunk of the column sums (long rounds)
 
+// the entries [a, b) of the source arrays counted by destination bucket into the LDS row h (zeroed by the caller; a
+// barrier on either side is the caller's): symbol bytes where the source has them, windows otherwise
+template <class WT>
+__device__ __forceinline__ void wide_count_range(const WT *__restrict__ srcW, const uint8_t *__restrict__ srcB, uint32_t a, uint32_t b,
+                                                 int mode, uint32_t c, const wnd_cfg &cfg, uint32_t *h, bool aligned)
+{
+    if (srcB) {
+        for (uint64_t q = (uint64_t)(a >> 4) + threadIdx.x; q * 16u < b; q += kWideThreads) {
+            const uint64_t e0 = q * 16u;
+            uint32_t S[4] = {0, 0, 0, 0};
+            if (aligned && e0 >= a && e0 + 16u <= b) {
+                load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (e0 + e >= a && e0 + e < b) S[e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t ch = (S[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                if (ch != 0 && induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+            }
+        }
+    } else {
+        for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kWideThreads) {
+            const uint64_t e0 = q * 4u;
+            WT W[4] = {0, 0, 0, 0};
+            if (aligned && e0 >= a && e0 + 4u <= b) {
+                load_quad(srcW + e0, W);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
+                    const uint32_t ch = wnd_first<WT>(W[e], cfg);
+                    if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
+                }
+            }
+        }
+    }
+}
+
 template <class WT>
 __global__ __launch_bounds__(kWideThreads) void induce_wide_count_kernel(const WT *__restrict__ srcW,
                                                                       const uint8_t *__restrict__ srcB,
@@ -436,43 +481,7 @@ __global__ __launch_bounds__(kWideThreads) void induce_wide_count_kernel(const W
         const uint32_t tile0 = tile * (uint32_t)kWideTile;
         const uint32_t cnt = len - tile0 < (uint32_t)kWideTile ? len - tile0 : (uint32_t)kWideTile;
         const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt; // the tile's entries: [a, b), any order
-        if (srcB) {
-            for (uint64_t q = (uint64_t)(a >> 4) + threadIdx.x; q * 16u < b; q += kWideThreads) {
-                const uint64_t e0 = q * 16u;
-                uint32_t S[4] = {0, 0, 0, 0};
-                if (aligned && e0 >= a && e0 + 16u <= b) {
-                    load_quad(reinterpret_cast<const uint32_t *>(srcB + e0), S);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (e0 + e >= a && e0 + e < b) S[e >> 2] |= (uint32_t)srcB[e0 + e] << (8 * (e & 3));
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t ch = (S[e >> 2] >> (8 * (e & 3))) & 0xFFu;
-                    if (ch != 0 && induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
-                }
-            }
-        } else {
-            for (uint64_t q = (uint64_t)(a >> 2) + threadIdx.x; q * 4u < b; q += kWideThreads) {
-                const uint64_t e0 = q * 4u;
-                WT W[4] = {0, 0, 0, 0};
-                if (aligned && e0 >= a && e0 + 4u <= b) {
-                    load_quad(srcW + e0, W);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (e0 + e >= a && e0 + e < b) W[e] = srcW[e0 + e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (wnd_count<WT>(W[e]) != 0) { // the entry for position 0 is the only one stored with an empty window
-                        const uint32_t ch = wnd_first<WT>(W[e], cfg);
-                        if (induce_accept(ch, c, mode)) atomicAdd(&h[ch], 1u);
-                    }
-                }
-            }
-        }
+        wide_count_range<WT>(srcW, srcB, a, b, mode, c, cfg, h, aligned);
         __syncthreads();
         if (threadIdx.x < 256) hist[(uint64_t)tile * 256 + threadIdx.x] = h[threadIdx.x];
         __syncthreads();
@@ -626,6 +635,140 @@ __global__ __launch_bounds__(kBlock) void induce_wide_apply_kernel(uint32_t *__r
 // A tile of 8192 entries is taken in kWideTile / (512 * ITEMS) steps of ITEMS entries a thread: 16 for 32-bit windows; 8 for
 // 64-bit windows (alphabets of 17 symbols and more), whose 16 entries a thread did not fit 128 registers -- 76 of them
 // were spilled, and a byte text's round of a single tile took 45 us.  A later step's entries go behind the earlier ones'.
+// LDS of one scatter workgroup (the kernels below declare it and hand it to wide_scatter_tile)
+template <int ITEMS> struct wide_scatter_lds {
+    static constexpr int kSub = kWideThreads * ITEMS;
+    uint64_t swnd[kSub]; // the step's output in bucket order: windows first, then reused for the positions;
+                         // the per-wave counters live here while the entries are still in registers
+    uint8_t sdig[kSub];  // bucket of every staged slot
+    uint32_t goff[256];  // destination of the bucket's first staged slot, minus (plus) that slot
+    uint32_t scan_lds[kWideWaves];
+};
+
+// One tile (`tile`-th of the range [lo, lo + len) in scan order) of a round: stable split of its entries by the first
+// symbol of their windows.  pre: entries of earlier tiles for bucket t (threads t < 256); base_d: bucket t's cursor at the
+// start of the round.  Ends with a barrier (the LDS may be reused at once).
+template <class WT, int ITEMS>
+__device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW,
+                                                  uint32_t lo, uint32_t len, uint32_t tile, int rev, int mode, uint32_t c, const wnd_cfg &cfg,
+                                                  const uint8_t *__restrict__ T, uint32_t pre, uint32_t base_d, int dir,
+                                                  uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW)
+{
+    constexpr int kSub = kWideThreads * ITEMS, kSteps = kWideTile / kSub;
+    static_assert(kWideTile % kSub == 0 && kSub * 8 >= kWideWaves * 256 * 4, "steps tile the tile; the counters fit the staging image");
+    uint64_t *swnd = L.swnd;
+    uint8_t *sdig = L.sdig;
+    uint32_t *goff = L.goff, *scan_lds = L.scan_lds;
+    uint32_t *wcount = reinterpret_cast<uint32_t *>(swnd);
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    for (int step = 0; step < kSteps; ++step) {
+        const uint32_t step0 = tile * (uint32_t)kWideTile + (uint32_t)step * kSub;
+        if (step0 >= len) break; // uniform
+        for (int i = t; i < kWideWaves * 256; i += kWideThreads) wcount[i] = 0;
+        __syncthreads();
+        const uint32_t wave0 = step0 + (uint32_t)w * (kWave * ITEMS);
+        uint32_t val[ITEMS], lpos[ITEMS]; // position - 1; [12:0] rank, then staged slot, [31:16] bucket, bit 15: taken
+        WT wnd[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            val[k] = 0;
+            wnd[k] = 0;
+            bool ok = false;
+            uint32_t dig = 0;
+            if (i < len) {
+                const uint32_t idx = lo + (rev ? len - 1u - i : i);
+                const uint32_t p = srcP[idx];
+                const WT ww = srcW[idx];
+                if (p != 0) {
+                    dig = wnd_first<WT>(ww, cfg);
+                    ok = induce_accept(dig, c, mode);
+                    val[k] = p - 1u;
+                    wnd[k] = wnd_pop<WT>(ww, cfg);
+                }
+            }
+            lpos[k] = ok ? (dig & 0xFFu) << 16 | 0x8000u : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const bool ok = (lpos[k] & 0x8000u) != 0;
+            lpos[k] |= wave_rank_inorder<8, false>(lpos[k] >> 16, ok, wcount + w * 256);
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        {
+            if (t < 256) {
+#pragma unroll
+                for (int ww = 0; ww < kWideWaves; ++ww) {
+                    const uint32_t x = wcount[ww * 256 + t];
+                    wcount[ww * 256 + t] = tot;
+                    tot += x;
+                }
+            }
+            const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
+            if (lane == kWave - 1) scan_lds[w] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
+            const uint32_t ex = base + inc - tot; // the bucket's first staged slot
+            if (t < 256) {
+#pragma unroll
+                for (int ww = 0; ww < kWideWaves; ++ww) wcount[ww * 256 + t] += ex;
+                // staged slot i of bucket t lands at goff + i (L pass) / goff - i (S pass)
+                goff[t] = dir > 0 ? base_d + pre - ex : base_d - 1u - pre + ex;
+            }
+        }
+        pre += tot;
+        __syncthreads();
+        uint32_t produced = 0;
+        for (int ww = 0; ww < kWideWaves; ++ww) produced += scan_lds[ww];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)
+            if (lpos[k] & 0x8000u) lpos[k] = (lpos[k] & 0xFFFF0000u) | 0x8000u | ((lpos[k] & 0x1FFFu) + wcount[w * 256 + (lpos[k] >> 16)]);
+        __syncthreads(); // the counters are part of the staging image
+        // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
+        // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
+        // a seventh of the entries of a byte alphabet).
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)
+            if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, val[k], cfg);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            if (lpos[k] & 0x8000u) {
+                const uint32_t slot = lpos[k] & 0x1FFFu;
+                swnd[slot] = (uint64_t)wnd[k];
+                sdig[slot] = (uint8_t)(lpos[k] >> 16);
+            }
+        }
+        __syncthreads();
+        uint32_t dstv[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
+            dstv[k] = 0;
+            if (i < produced) {
+                const WT nw = (WT)swnd[i];
+                const uint32_t g = goff[sdig[i]];
+                dstv[k] = dir > 0 ? g + i : g - i;
+                WN[dstv[k]] = nw;
+                BW[dstv[k]] = wnd_symbol<WT>(nw, cfg);
+            }
+        }
+        __syncthreads();
+        uint32_t *sval = reinterpret_cast<uint32_t *>(swnd);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)
+            if (lpos[k] & 0x8000u) sval[lpos[k] & 0x1FFFu] = val[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
+            if (i < produced) SA[dstv[k]] = sval[i];
+        }
+        __syncthreads(); // LDS is reused by the next step
+    }
+}
+
 template <class WT, int ITEMS>
 __global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ range_in, int rev, int mode,
@@ -633,127 +776,223 @@ __global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
     const uint32_t *__restrict__ cursor_cur, int dir, uint32_t *__restrict__ SA, WT *__restrict__ WN,
     uint8_t *__restrict__ BW, uint32_t min_len)
 {
-    constexpr int kSub = kWideThreads * ITEMS, kSteps = kWideTile / kSub;
-    static_assert(kWideTile % kSub == 0 && kSub * 8 >= kWideWaves * 256 * 4, "steps tile the tile; the counters fit the staging image");
-    __shared__ uint64_t swnd[kSub]; // the step's output in bucket order: windows first, then reused for the positions;
-                                    // the per-wave counters live here while the entries are still in registers
-    __shared__ uint8_t sdig[kSub];  // bucket of every staged slot
-    __shared__ uint32_t goff[256];  // destination of the bucket's first staged slot, minus (plus) that slot
-    __shared__ uint32_t scan_lds[kWideWaves];
-    uint32_t *wcount = reinterpret_cast<uint32_t *>(swnd);
-    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    __shared__ wide_scatter_lds<ITEMS> lds;
+    const int t = (int)threadIdx.x;
     const uint32_t lo = range_in[0], len = range_in[1] - lo;
     if (len <= min_len) return;
     const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
     const uint32_t base_d = t < 256 ? cursor_cur[t] : 0u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
-        uint32_t pre = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // entries of earlier tiles (and steps) for bucket t
-        for (int step = 0; step < kSteps; ++step) {
-            const uint32_t step0 = tile * (uint32_t)kWideTile + (uint32_t)step * kSub;
-            if (step0 >= len) break; // uniform
-            for (int i = t; i < kWideWaves * 256; i += kWideThreads) wcount[i] = 0;
-            __syncthreads();
-            const uint32_t wave0 = step0 + (uint32_t)w * (kWave * ITEMS);
-            uint32_t val[ITEMS], lpos[ITEMS]; // position - 1; [12:0] rank, then staged slot, [31:16] bucket, bit 15: taken
-            WT wnd[ITEMS];
+        const uint32_t pre = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // entries of earlier tiles (and steps) for bucket t
+        wide_scatter_tile<WT, ITEMS>(lds, srcP, srcW, lo, len, tile, rev, mode, c, cfg, T, pre, base_d, dir, SA, WN, BW);
+    }
+}
+
+// ---- more than 8 buckets: every bucket's "other region" round at once, up front ------------------------------------
+// Bucket c's pass is two scans: the entries the pass itself puts into c (L from L, S from S: rounds whose input is made
+// as the pass goes) and a region that is complete before the pass begins -- c's LMS seeds in the L pass, c's L-type
+// entries in the S pass.  Rounds 1 - 3 scanned that second region bucket by bucket: a count, an offsets and a scatter
+// launch each, 2 x 255 times for a byte text, every one bound by its own latency (1 GiB of bytes: 30 of the 94 ms
+// of the two passes), because its outputs land behind whatever the bucket's own rounds have appended so far.  But where
+// they land is a property of the text.  Bucket d's L region is, in suffix-array order, for c = 0 .. d - 1 the entries
+// p (text[p] = d, text[p + 1] = c) whose successor p + 1 is an L-type entry of c, then those whose successor is one
+// of c's LMS suffixes, and last the entries with text[p + 1] = d; the first two groups together are the occurrences
+// of the bigram (d, c) in the text, BG[d][c].  So with the bigram counts (one pass over the text, bigram_kernel) and
+// the number of c's seeds that go to d (the counting launch's column totals) the place of every group is known
+// before the pass starts: all buckets' seeds are split and written by ONE count / offsets / scatter (full bandwidth
+// instead of 255 latencies), a bucket's pass is its own rounds alone, and bucket_begin_kernel sets the cursors to
+// the group starts (and checks that the pass left them where the bigram counts say).  The S pass mirrors it: bucket
+// d's S region from its end downwards is, for c = 255 .. d + 1, the entries whose successor is an S-type entry of
+// c, then those whose successor is an L-type entry of c -- all L-type entries are final after the L pass.
+#ifndef SX_HOIST_GRID_X
+#define SX_HOIST_GRID_X 64u // workgroups a bucket in the up-front launches (they loop over the bucket's tiles); the CPU test harness: 2
+#endif
+#ifndef SX_BIGRAM_GRID
+#define SX_BIGRAM_GRID 256u // (the CPU test harness: 2)
+#endif
+constexpr uint32_t kHoistGridX = SX_HOIST_GRID_X, kBigramGrid = SX_BIGRAM_GRID;
+constexpr uint32_t kBigramWords = 32768; // LDS counters of bigram_kernel: rows of nk counters, as many rows a pass as fit
+constexpr int kBigramThreads = 1024;
+__global__ __launch_bounds__(kBigramThreads) void bigram_kernel(const uint8_t *__restrict__ T, uint64_t n, uint32_t nk,
+                                                                uint32_t *__restrict__ BG /* [256][256], zeroed */)
+{
+    __shared__ uint32_t cnt[kBigramWords];
+    const uint32_t R = kBigramWords / nk; // rows of the matrix a pass holds (nk <= 256: at least 128)
+    const uint64_t pieces = (n + 15) / 16, per = (pieces + gridDim.x - 1) / gridDim.x;
+    const uint64_t q0 = (uint64_t)blockIdx.x * per, q1 = q0 + per < pieces ? q0 + per : pieces;
+    for (uint32_t r0 = 0; r0 < nk; r0 += R) { // uniform
+        const uint32_t rows = nk - r0 < R ? nk - r0 : R;
+        for (uint32_t i = threadIdx.x; i < rows * nk; i += kBigramThreads) cnt[i] = 0;
+        __syncthreads();
+        for (uint64_t q = q0 + threadIdx.x; q < q1; q += kBigramThreads) {
+            const uint64_t p0 = q * 16u;
+            uint64_t w0, w1;
+            load_bytes16(T, p0, w0, w1); // (the build's copy of the text is padded beyond text[n] = 0)
+            uint32_t d = (uint32_t)(w0 & 0xFFu);
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
-                val[k] = 0;
-                wnd[k] = 0;
-                bool ok = false;
-                uint32_t dig = 0;
-                if (i < len) {
-                    const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                    const uint32_t p = srcP[idx];
-                    const WT ww = srcW[idx];
-                    if (p != 0) {
-                        dig = wnd_first<WT>(ww, cfg);
-                        ok = induce_accept(dig, c, mode);
-                        val[k] = p - 1u;
-                        wnd[k] = wnd_pop<WT>(ww, cfg);
-                    }
-                }
-                lpos[k] = ok ? (dig & 0xFFu) << 16 | 0x8000u : 0u;
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t nxt = e < 7 ? (uint32_t)(w0 >> (8 * (e + 1))) & 0xFFu
+                                           : (e < 15 ? (uint32_t)(w1 >> (8 * (e - 7))) & 0xFFu : (uint32_t)T[p0 + 16u]);
+                // the diagonal is never asked for (a symbol's run stays inside its bucket's own rounds), and it is
+                // where the lanes of a wave would queue on one counter
+                if (p0 + (uint32_t)e < n && d != nxt && d - r0 < rows) atomicAdd(&cnt[(d - r0) * nk + nxt], 1u);
+                d = nxt;
             }
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const bool ok = (lpos[k] & 0x8000u) != 0;
-                lpos[k] |= wave_rank_inorder<8, false>(lpos[k] >> 16, ok, wcount + w * 256);
-            }
-            __syncthreads();
-            uint32_t tot = 0;
-            {
-                if (t < 256) {
-#pragma unroll
-                    for (int ww = 0; ww < kWideWaves; ++ww) {
-                        const uint32_t x = wcount[ww * 256 + t];
-                        wcount[ww * 256 + t] = tot;
-                        tot += x;
-                    }
-                }
-                const uint32_t inc = wave_inclusive_scan<OpAdd>(tot);
-                if (lane == kWave - 1) scan_lds[w] = inc;
-                __syncthreads();
-                uint32_t base = 0;
-                for (int ww = 0; ww < w; ++ww) base += scan_lds[ww];
-                const uint32_t ex = base + inc - tot; // the bucket's first staged slot
-                if (t < 256) {
-#pragma unroll
-                    for (int ww = 0; ww < kWideWaves; ++ww) wcount[ww * 256 + t] += ex;
-                    // staged slot i of bucket t lands at goff + i (L pass) / goff - i (S pass)
-                    goff[t] = dir > 0 ? base_d + pre - ex : base_d - 1u - pre + ex;
-                }
-            }
-            pre += tot;
-            __syncthreads();
-            uint32_t produced = 0;
-            for (int ww = 0; ww < kWideWaves; ++ww) produced += scan_lds[ww];
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k)
-                if (lpos[k] & 0x8000u) lpos[k] = (lpos[k] & 0xFFFF0000u) | 0x8000u | ((lpos[k] & 0x1FFFu) + wcount[w * 256 + (lpos[k] >> 16)]);
-            __syncthreads(); // the counters are part of the staging image
-            // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
-            // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
-            // a seventh of the entries of a byte alphabet).
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k)
-                if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, val[k], cfg);
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                if (lpos[k] & 0x8000u) {
-                    const uint32_t slot = lpos[k] & 0x1FFFu;
-                    swnd[slot] = (uint64_t)wnd[k];
-                    sdig[slot] = (uint8_t)(lpos[k] >> 16);
-                }
-            }
-            __syncthreads();
-            uint32_t dstv[ITEMS];
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
-                dstv[k] = 0;
-                if (i < produced) {
-                    const WT nw = (WT)swnd[i];
-                    const uint32_t g = goff[sdig[i]];
-                    dstv[k] = dir > 0 ? g + i : g - i;
-                    WN[dstv[k]] = nw;
-                    BW[dstv[k]] = wnd_symbol<WT>(nw, cfg);
-                }
-            }
-            __syncthreads();
-            uint32_t *sval = reinterpret_cast<uint32_t *>(swnd);
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k)
-                if (lpos[k] & 0x8000u) sval[lpos[k] & 0x1FFFu] = val[k];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const uint32_t i = (uint32_t)t + (uint32_t)k * kWideThreads;
-                if (i < produced) SA[dstv[k]] = sval[i];
-            }
-            __syncthreads(); // LDS is reused by the next step
         }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < rows * nk; i += kBigramThreads) {
+            const uint32_t v = cnt[i];
+            if (v) atomicAdd(&BG[(uint64_t)(r0 + i / nk) * 256u + i % nk], v);
+        }
+        __syncthreads();
+    }
+}
+
+// EL[c][d] = begin[d] + sum of BG[d][c'] over c' <= c, c' < d: where bucket d's groups (d, 0 .. c) end;
+// ES[c][d] = begin[d + 1] - sum of BG[d][c'] over c' >= c, c' > d: where its groups (d, 255 .. c) end, counted from the bucket's end
+__global__ __launch_bounds__(256) void hoist_tables_kernel(const uint32_t *__restrict__ BG, const uint32_t *__restrict__ begin /* 257 */,
+                                                         uint32_t nk, uint32_t *__restrict__ EL, uint32_t *__restrict__ ES)
+{
+    const uint32_t d = threadIdx.x;
+    if (d >= nk) return;
+    uint32_t acc = begin[d];
+    for (uint32_t c = 0; c < nk; ++c) {
+        if (c < d) acc += BG[(uint64_t)d * 256u + c];
+        EL[(uint64_t)c * 256u + d] = acc;
+    }
+    acc = begin[d + 1];
+    for (uint32_t c = nk; c-- > 0;) {
+        if (c > d) acc -= BG[(uint64_t)d * 256u + c];
+        ES[(uint64_t)c * 256u + d] = acc;
+    }
+}
+
+// the region of every bucket c = blockIdx.y -- entries [lo[c], lo[c] + len[c]) of the source arrays -- counted tile by
+// tile (hist rows row0[c] ...); desc: lo[256], len[256], row0[256]
+template <class WT>
+__global__ __launch_bounds__(kWideThreads) void hoist_count_kernel(const WT *__restrict__ srcW, const uint8_t *__restrict__ srcB,
+                                                                const uint32_t *__restrict__ desc, int rev, int mode, wnd_cfg cfg,
+                                                                uint32_t *__restrict__ hist /* [row][256] */)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t c = blockIdx.y, lo = desc[c], len = desc[256 + c], row0 = desc[512 + c];
+    if (len == 0) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const bool aligned = srcB ? ((uintptr_t)srcB & 15u) == 0 : ((uintptr_t)srcW & 15u) == 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        if (threadIdx.x < 256) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t tile0 = tile * (uint32_t)kWideTile;
+        const uint32_t cnt = len - tile0 < (uint32_t)kWideTile ? len - tile0 : (uint32_t)kWideTile;
+        const uint32_t a = rev ? lo + len - tile0 - cnt : lo + tile0, b = a + cnt;
+        wide_count_range<WT>(srcW, srcB, a, b, mode, c, cfg, h, aligned);
+        __syncthreads();
+        if (threadIdx.x < 256) hist[(uint64_t)(row0 + tile) * 256 + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// workgroup c: the tile counts of bucket c's region -> entries of earlier tiles, per destination bucket (in place); the
+// column totals tot[c][d] = entries of c's region that go to bucket d; dbase[c][d] = where the first of them lands
+// (L pass: the group (d, c) ends at EL[c][d] and these are its last tot entries; S pass: the group ends, downwards, at
+// ES[c][d] and these are the last ones before that end -- as the cursor the scatter counts down from)
+__global__ __launch_bounds__(kBlock * kWideOffGroups) void hoist_offsets_kernel(uint32_t *__restrict__ hist, const uint32_t *__restrict__ desc,
+                                                                              const uint32_t *__restrict__ E, int dir,
+                                                                              uint32_t *__restrict__ tot, uint32_t *__restrict__ dbase)
+{
+    __shared__ uint32_t gsum[kWideOffGroups][256];
+    const uint32_t c = blockIdx.x, len = desc[256 + c], row0 = desc[512 + c];
+    const uint32_t d = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    uint32_t *rows = hist + (uint64_t)row0 * 256;
+    const uint32_t per = (ntiles + kWideOffGroups - 1) / kWideOffGroups;
+    const uint32_t t0 = g * per < ntiles ? g * per : ntiles, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    constexpr int kBatch = 16;
+    uint32_t sum = 0;
+    for (uint32_t tb = t0; tb < t1; tb += kBatch) {
+        uint32_t x[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < t1 ? rows[(uint64_t)(tb + i) * 256 + d] : 0u;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) sum += x[i];
+    }
+    gsum[g][d] = sum;
+    __syncthreads();
+    uint32_t run = 0, all = 0;
+#pragma unroll
+    for (int gg = 0; gg < kWideOffGroups; ++gg) {
+        const uint32_t x = gsum[gg][d];
+        if ((uint32_t)gg < g) run += x;
+        all += x;
+    }
+    for (uint32_t tb = t0; tb < t1; tb += kBatch) {
+        uint32_t x[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) x[i] = tb + i < t1 ? rows[(uint64_t)(tb + i) * 256 + d] : 0u;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            if (tb + i < t1) rows[(uint64_t)(tb + i) * 256 + d] = run;
+            run += x[i];
+        }
+    }
+    if (g == 0) {
+        tot[(uint64_t)c * 256 + d] = all;
+        const uint32_t e = E[(uint64_t)c * 256 + d];
+        dbase[(uint64_t)c * 256 + d] = dir > 0 ? e - all : e + all;
+    }
+}
+
+template <class WT, int ITEMS>
+__global__ __launch_bounds__(kWideThreads, 4) void hoist_scatter_kernel(
+    const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ desc, int rev, int mode, wnd_cfg cfg,
+    const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs /* [row][256] */, const uint32_t *__restrict__ dbase, int dir,
+    uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW)
+{
+    __shared__ wide_scatter_lds<ITEMS> lds;
+    const int t = (int)threadIdx.x;
+    const uint32_t c = blockIdx.y, lo = desc[c], len = desc[256 + c], row0 = desc[512 + c];
+    if (len == 0) return;
+    const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
+    const uint32_t base_d = t < 256 ? dbase[(uint64_t)c * 256 + t] : 0u;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
+        const uint32_t pre = t < 256 ? offs[(uint64_t)(row0 + tile) * 256 + t] : 0u;
+        wide_scatter_tile<WT, ITEMS>(lds, srcP, srcW, lo, len, tile, rev, mode, c, cfg, T, pre, base_d, dir, SA, WN, BW);
+    }
+}
+
+// Start of bucket c's own rounds in a pass whose other-region rounds were done up front: every bucket the rounds can
+// write to gets its cursor set to the start of its group (d, c) -- where the cursor must already be, give or take the
+// up-front entries of the buckets since the last one that had rounds of its own (c_from .. c - 1 in the L pass,
+// c + 1 .. c_from in the S pass): anything else means the pass and the bigram counts disagree (err) --, the first range
+// is what lies in front of bucket c's own group.  A pass stopped by an unfinished bucket (poison) is left as it is.
+__global__ __launch_bounds__(256) void bucket_begin_kernel(uint32_t *__restrict__ range, uint32_t *__restrict__ cursor,
+                                                         const uint32_t *__restrict__ begin, const uint32_t *__restrict__ E,
+                                                         const uint32_t *__restrict__ tot, uint32_t nk, uint32_t c, uint32_t c_from,
+                                                         int dir, uint32_t *__restrict__ tickets, uint32_t ntickets,
+                                                         const uint32_t *__restrict__ poison, uint32_t *__restrict__ err)
+{
+    const uint32_t d = threadIdx.x;
+    if (d == 0)
+        for (uint32_t i = 0; i < ntickets; ++i) tickets[i] = 0;
+    if (poison && poison[0]) {
+        if (d == 0) range[0] = range[1] = 0;
+        return;
+    }
+    if (d >= nk) return;
+    if (dir > 0 && d >= c) {
+        const uint32_t want = c == 0 ? begin[d] : E[(uint64_t)(c - 1) * 256 + d];
+        uint32_t have = cursor[d];
+        for (uint32_t k = c_from; k < c; ++k) have += tot[(uint64_t)k * 256 + d];
+        if (have != want) atomicOr(err, 1u);
+        cursor[d] = want;
+        if (d == c) range[0] = begin[c], range[1] = want;
+    } else if (dir < 0 && d <= c) {
+        const uint32_t want = c + 1 >= nk ? begin[d + 1] : E[(uint64_t)(c + 1) * 256 + d];
+        uint32_t have = cursor[d];
+        for (uint32_t k = c_from; k > c; --k) have -= tot[(uint64_t)k * 256 + d];
+        if (have != want) atomicOr(err, 2u);
+        cursor[d] = want;
+        if (d == c) range[0] = want, range[1] = begin[c + 1];
     }
 }
 
@@ -1782,7 +2021,9 @@ size_t sx_induce_scratch_bytes(uint64_t N, uint32_t sigma)
     // (at most 8 buckets: (round, bucket) count rows of the eight-rounds-at-a-time form, over the largest bucket's tiles)
     return (size_t)N * 8 + 256 + (size_t)(N / 2 + 2) * 8 + 256 + (size_t)N + 256 + (size_t)sigma * ntiles * 4 + 256 +
            (size_t)kBatchRows * (ntiles + 1) * 4 + 1024 +
-           (sigma > 8 ? (size_t)(wtiles + wtiles / 256 + 4) * 1024 + 512 : 0) + 16384;
+           (sigma > 8 ? (size_t)(wtiles + wtiles / 256 + 4) * 1024 + 512 : 0) + 16384 +
+           // the up-front rounds of more than 8 buckets: tile counts of all buckets' regions, the bigram matrix and its tables
+           (sigma > 8 ? ((size_t)N / kWideTile + 520) * 1024 + 5 * 65536 * 4 + 16384 : 0);
 }
 
 namespace {
@@ -1821,6 +2062,13 @@ template <class WT> struct induce_state {
     int small_alphabet;
     int par; // which cursor buffer is current
     wnd_cfg cfg;
+    // more than 8 buckets: the other-region rounds of all buckets are done up front (hoist_*_kernel, bucket_begin_kernel)
+    int hoist;
+    uint32_t *d_begin;       // bucket boundaries on the device (257)
+    uint32_t *hoist_E;       // the current pass's group ends: EL or ES, [c][d]
+    uint32_t *hoist_tot;     // the current pass's up-front entries from bucket c to bucket d, [c][d]
+    uint32_t *hoist_err;     // set by bucket_begin_kernel when a cursor is not where the bigram counts put it
+    uint32_t hoist_from;     // the last bucket of the pass that had rounds of its own (L pass: 0, S pass: nk - 1 before the first)
 };
 
 template <class WT>
@@ -2010,7 +2258,12 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
     for (uint64_t batch = 0;; ++batch) {
         if (batch > max_batches) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: the rounds of a bucket did not come to an end");
         if (!resuming) {
-        if (first)
+        if (first && st.hoist) {
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, bucket_begin_kernel, dim3(1), dim3(256), st.ranges, st.cursor[st.par],
+                      (const uint32_t *)st.d_begin, (const uint32_t *)st.hoist_E, (const uint32_t *)st.hoist_tot, st.nk, c, st.hoist_from,
+                      dir, st.tickets, (uint32_t)(kMaxSpec + 2), (const uint32_t *)(st.unattended ? st.poison : nullptr), st.hoist_err);
+            st.hoist_from = c;
+        } else if (first)
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
                       (const uint32_t *)st.cursor[st.par], (int)c, which, st.tickets, (uint32_t)(kMaxSpec + 2),
                       (const uint32_t *)(st.unattended ? st.poison : nullptr));
@@ -2192,6 +2445,73 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.poison = arena.take<uint32_t>(4);
     if (!st.poison) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small");
     st.host_poison = ctx->h_pin + 1040;
+    // More than 8 buckets: every bucket's other-region round (its LMS seeds in the L pass, its L-type entries in the S
+    // pass) up front, all buckets in one count / offsets / scatter, placed by the text's bigram counts (hoist_*_kernel)
+    st.hoist = (!st.small_alphabet && !ctx->induce_no_hoist) ? 1 : 0;
+    st.d_begin = st.hoist_E = st.hoist_tot = st.hoist_err = nullptr;
+    st.hoist_from = 0;
+    uint32_t *hz_BG = nullptr, *hz_EL = nullptr, *hz_ES = nullptr, *hz_tot = nullptr, *hz_dbase = nullptr, *hz_hist = nullptr,
+             *hz_desc = nullptr;
+    uint32_t h_desc[2][768]; // per pass: lo[256], len[256], first hist row[256] of every bucket's region (uploaded; alive to the end)
+    uint32_t hz_rows[2] = {0, 0}, hz_most[2] = {1, 1};
+    if (st.hoist) {
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t row = 0;
+            for (uint32_t c = 0; c < 256; ++c) {
+                const uint32_t len = c < nk ? (pass == 0 ? ti.h_lms[c] : ti.h_l[c]) : 0u;
+                h_desc[pass][c] = pass == 0 ? lms_off[c] : begin[c];
+                h_desc[pass][256 + c] = len;
+                h_desc[pass][512 + c] = row;
+                const uint32_t tiles = sx_div_up(len, kWideTile);
+                row += tiles;
+                if (tiles > hz_most[pass]) hz_most[pass] = tiles;
+            }
+            hz_rows[pass] = row;
+        }
+        st.d_begin = arena.take<uint32_t>(260);
+        hz_BG = arena.take<uint32_t>(65536);
+        hz_EL = arena.take<uint32_t>(65536);
+        hz_ES = arena.take<uint32_t>(65536);
+        hz_tot = arena.take<uint32_t>(65536);
+        hz_dbase = arena.take<uint32_t>(65536);
+        hz_desc = arena.take<uint32_t>(2 * 768);
+        st.hoist_err = arena.take<uint32_t>(4);
+        hz_hist = arena.take<uint32_t>(((size_t)(hz_rows[0] > hz_rows[1] ? hz_rows[0] : hz_rows[1]) + 2) * 256);
+        if (!st.d_begin || !hz_BG || !hz_EL || !hz_ES || !hz_tot || !hz_dbase || !hz_desc || !st.hoist_err || !hz_hist)
+            return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: arena too small (up-front rounds)");
+        SX_CHECK(hipMemcpyAsync(st.d_begin, begin, 257 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        SX_CHECK(hipMemcpyAsync(hz_desc, h_desc, sizeof h_desc, hipMemcpyHostToDevice, ctx->stream));
+        SX_CHECK(hipMemsetAsync(hz_BG, 0, 65536 * sizeof(uint32_t), ctx->stream));
+        SX_CHECK(hipMemsetAsync(st.hoist_err, 0, 4 * sizeof(uint32_t), ctx->stream));
+        // the text's bigram counts (one pass per 32768 / nk rows of the matrix), then where every bucket's groups end
+        uint32_t bg_grid = (uint32_t)sx_div_up(sx_div_up(ti.n ? ti.n : 1, 16), (uint64_t)kBigramThreads * 16);
+        if (bg_grid > kBigramGrid) bg_grid = kBigramGrid;
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, ti.n * (uint64_t)sx_div_up(nk, kBigramWords / nk), bigram_kernel, dim3(bg_grid),
+                  dim3(kBigramThreads), ti.T, (uint64_t)ti.n, nk, hz_BG);
+        sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, hoist_tables_kernel, dim3(1), dim3(256), (const uint32_t *)hz_BG, (const uint32_t *)st.d_begin, nk,
+                  hz_EL, hz_ES);
+    }
+    // all buckets' other-region rounds of a pass: one count, one offsets, one scatter (queued at the start of the pass)
+    auto hoisted_rounds = [&](int pass) -> int {
+        const uint32_t *desc = hz_desc + pass * 768;
+        const int rev = pass, mode = pass == 0 ? MODE_L_FROM_LMS : MODE_S_FROM_L, dir = pass == 0 ? +1 : -1;
+        const uint32_t *srcP = pass == 0 ? sorted_lms : (const uint32_t *)SA;
+        const WT *srcW = pass == 0 ? (const WT *)seedW : (const WT *)st.WN;
+        const uint8_t *srcB = pass == 0 ? (const uint8_t *)nullptr : (const uint8_t *)st.BW;
+        st.hoist_E = pass == 0 ? hz_EL : hz_ES;
+        st.hoist_tot = hz_tot;
+        st.hoist_from = pass == 0 ? 0u : nk - 1u;
+        uint32_t gx = hz_most[pass];
+        if (gx > kHoistGridX) gx = kHoistGridX;
+        sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, hoist_count_kernel<WT>, dim3(gx, nk), dim3(kWideThreads), srcW, srcB, desc, rev, mode, st.cfg,
+                  hz_hist);
+        sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)hz_rows[pass] * 2048, hoist_offsets_kernel, dim3(nk), dim3(kBlock * kWideOffGroups),
+                  hz_hist, desc, (const uint32_t *)st.hoist_E, dir, hz_tot, hz_dbase);
+        sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, hoist_scatter_kernel<WT, 8>, dim3(gx, nk), dim3(kWideThreads), srcP, srcW, desc, rev,
+                  mode, st.cfg, st.T, (const uint32_t *)hz_hist, (const uint32_t *)hz_dbase, dir, st.SA, st.WN, st.BW);
+        ctx->stats.induce_rounds++;
+        return 0;
+    };
     auto cursors_as_counted = [&](bool &ok) -> int {
         uint32_t cur[256];
         SX_TRY(sx_readback(ctx, (const uint32_t *)st.cursor[st.par], nk, cur));
@@ -2211,6 +2531,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             if (ti.h_all[c] == 0) continue;
             if (stopped()) return 0;
             const bool carry_on = resume && c == from;
+            if (carry_on) st.hoist_from = c; // (its rounds are carried on from where they stopped: no bucket_begin_kernel)
             if (ti.h_l[c]) {
                 uint32_t head_end = 0;
                 st.unattended = (unattended_ok && !carry_on) ? 1 : 0;
@@ -2220,7 +2541,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
                     return sx_fail_msg(ctx, SX_E_INTERNAL, "induce L: bucket did not receive its L-type count");
                 st.unattended = unattended_ok ? 1 : 0;
             }
-            if (ti.h_lms[c]) {
+            if (ti.h_lms[c] && !st.hoist) {
                 sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, lms_off[c], lms_off[c + 1],
                           (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u, (const uint32_t *)(st.unattended ? st.poison : nullptr));
                 // (the round's size is known: the one form that takes it, and no launch that finds nothing to do)
@@ -2237,6 +2558,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             if (ti.h_all[c] == 0) continue;
             if (stopped()) return 0;
             const bool carry_on = resume && c == from;
+            if (carry_on) st.hoist_from = c;
             const uint32_t n_s = ti.h_all[c] - ti.h_l[c];
             if (c > 0 && n_s) {
                 uint32_t tail_end = 0;
@@ -2247,7 +2569,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
                     return sx_fail_msg(ctx, SX_E_INTERNAL, "induce S: bucket did not receive its S-type count");
                 st.unattended = unattended_ok ? 1 : 0;
             }
-            if (ti.h_l[c]) {
+            if (ti.h_l[c] && !st.hoist) {
                 sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, begin[c],
                           begin[c] + ti.h_l[c], (const uint32_t *)st.cursor[st.par], (int)c, 0, st.tickets, 1u,
                           (const uint32_t *)(st.unattended ? st.poison : nullptr));
@@ -2262,6 +2584,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         st.unattended = unattended_ok ? 1 : 0;
         if (pass == 1) SX_CHECK(hipStreamSynchronize(ctx->stream)); // (`begin`, the L pass's upload source, may still be in use)
         SX_CHECK(hipMemcpyAsync(st.cursor[st.par], pass == 0 ? begin : begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (st.hoist) SX_TRY(hoisted_rounds(pass));
         uint32_t from = pass == 0 ? 0u : nk - 1u, rec[4] = {0, 0, 0, 0};
         const uint32_t *resume = nullptr;
         for (uint32_t attempt = 0;; ++attempt) {
@@ -2289,6 +2612,11 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         uint32_t timed_out[2] = {0, 0};
         SX_TRY(sx_readback(ctx, (const uint32_t *)st.status, 2, timed_out));
         if (timed_out[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a look-back wait timed out");
+    }
+    if (st.hoist) {
+        uint32_t err = 0;
+        SX_TRY(sx_readback(ctx, (const uint32_t *)st.hoist_err, 1, &err));
+        if (err) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a bucket's cursor is not where the text's bigram counts put it");
     }
     if (ctx->prof_on) {
         // Algorithmic bytes of the two passes (the launches themselves were queued with bounds, not

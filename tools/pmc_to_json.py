@@ -58,8 +58,12 @@ def main():
                   "write_bytes_per_launch": write[c][1] / launches,
                   "hbm_bytes_per_launch": (2.0 * fetch[c][1] + write[c][1]) / launches}
     doc = json.load(open(dest)) if os.path.exists(dest) else {}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stralg_amd._lib import kernel_sources_sha16
     doc[workload] = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, "
-                               "FETCH_SIZE doubled (gfx950 wide streaming reads), per class", "classes": res}
+                               "FETCH_SIZE doubled (gfx950 wide streaming reads), per class", "classes": res,
+                     # what the figures were measured on: bench.py reports traffic_stale when the kernels have changed since
+                     "kernel_sources_sha16": kernel_sources_sha16()}
     json.dump(doc, open(dest, "w"), indent=1, sort_keys=True)
     print(json.dumps(res.get("radix_scatter"), indent=1))
 
