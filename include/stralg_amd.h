@@ -212,6 +212,9 @@ int sx_fasta_pack(sx_ctx *ctx, const uint8_t *file, uint64_t file_len, uint8_t *
  * *alphabet_size_out = k + 1.  Fails when more than 127 distinct symbols occur (remap.h:14-18). */
 int sx_remap_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out, int16_t *table_out,
                  uint32_t *alphabet_size_out);
+/* stralg/bwt.c:147-151: the reversed copy of a remapped string that build_complete_table sorts for the RO table:
+ * d_out[i] = d_in[n - 1 - i], d_out[n] = 0 (n + 1 bytes; the buffers must not overlap) */
+int sx_reverse_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out);
 
 /* ---- measurement ------------------------------------------------------------ */
 int sx_profile_enable(sx_ctx *ctx, int on);       /* bracket every launch with HIP events */

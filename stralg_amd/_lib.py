@@ -73,6 +73,7 @@ def load(path=None):
         "sx_fasta_pack": (C.c_int, [vp, u8p, C.c_uint64, u8p, C.POINTER(C.c_uint64), u32p, C.c_uint64,
                                     C.POINTER(C.c_uint32)]),
         "sx_remap_dev": (C.c_int, [vp, u8p, C.c_uint64, u8p, C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]),
+        "sx_reverse_dev": (C.c_int, [vp, u8p, C.c_uint64, u8p]),
         "sx_profile_enable": (C.c_int, [vp, C.c_int]),
         "sx_profile_only": (C.c_int, [vp, C.c_int]),
         "sx_profile_reset": (C.c_int, [vp]),
@@ -102,7 +103,7 @@ def load(path=None):
 EXPORTS = ["sx_device_count", "sx_device_numa_node", "sx_ctx_create", "sx_ctx_destroy", "sx_ctx_live_count", "sx_last_error", "sx_ctx_trim", "sx_ctx_set_flag",
            "sx_sa_build", "sx_sa_build_dev", "sx_sa_bwt_build_dev", "sx_bwt_tables", "sx_bwt_tables_dev",
            "sx_bwt_tables_from_bwt_dev", "sx_build_tables", "sx_sa_inverse_dev", "sx_sa_lcp_dev", "sx_sa_inverse_lcp",
-           "sx_bwt_exact_search_dev", "sx_build_tables_stream", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_profile_enable", "sx_profile_only",
+           "sx_bwt_exact_search_dev", "sx_build_tables_stream", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_reverse_dev", "sx_profile_enable", "sx_profile_only",
            "sx_profile_reset", "sx_profile_read", "sx_kernel_class_name", "sx_last_stats",
            "sx_synth_dev", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]
 

@@ -149,6 +149,10 @@ class Context:
                                           C.byref(sigma)), "sx_remap_dev")
         return int(sigma.value), table
 
+    def reverse_dev(self, d_in, n, d_out):
+        """sx_reverse_dev: d_out[0..n) = d_in reversed, d_out[n] = 0 (the string build_complete_table sorts for RO, bwt.c:147-151)"""
+        self._check(self.lib.sx_reverse_dev(self.h, _ptr(d_in), n, _ptr(d_out)), "sx_reverse_dev")
+
     def fasta_records(self, data):
         """sx_fasta_pack (host buffers): [(name, sequence), ...] in file order from the bytes of a FASTA file"""
         buf = np.frombuffer(bytes(data), dtype=np.uint8)

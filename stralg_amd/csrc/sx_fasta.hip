@@ -235,6 +235,28 @@ __global__ __launch_bounds__(kBlock) void remap_apply_kernel(const uint8_t *__re
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = 0; // the terminator remap() appends (remap.c:113)
 }
 
+
+// out[i] = in[n - 1 - i] (i < n), out[n] = 0: the reversed copy build_complete_table sorts for the RO table
+// (stralg/bwt.c:147-151).  A thread turns 16 bytes around: one unaligned 16-byte load, two byte swaps, one 16-byte store.
+__global__ __launch_bounds__(kBlock) void reverse_kernel(const uint8_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ out)
+{
+    const uint64_t pieces = (n + 15) / 16;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < pieces; q += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t o0 = q * 16u; // out[o0 .. o0 + 16) = in[n - 16 - o0 .. n - o0) backwards
+        if (o0 + 16u <= n && (((uintptr_t)out) & 15u) == 0) {
+            uint64_t lo, hi;
+            load_bytes16(in, n - 16u - o0, lo, hi);
+            uint4 v;
+            const uint64_t a = __builtin_bswap64(hi), b = __builtin_bswap64(lo);
+            v.x = (uint32_t)a, v.y = (uint32_t)(a >> 32), v.z = (uint32_t)b, v.w = (uint32_t)(b >> 32);
+            *reinterpret_cast<uint4 *>(out + o0) = v;
+        } else {
+            for (uint64_t i = o0; i < n && i < o0 + 16u; ++i) out[i] = in[n - 1u - i];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = 0;
+}
+
 } // namespace sx
 
 using namespace sx;
@@ -348,6 +370,19 @@ int sx_remap_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out, i
     if (next > 128) return sx_fail_msg(ctx, SX_E_ARG, "remap: more than 127 distinct symbols (stralg/remap.h:14-18)");
     SX_CHECK(hipMemcpyAsync(lut, table, 256, hipMemcpyHostToDevice, ctx->stream));
     sx_launch(ctx, SX_KC_REMAP, 2 * n, remap_apply_kernel, dim3(grid), dim3(kBlock), d_in, n, (const uint8_t *)lut, d_out);
+    return sx_sync(ctx);
+}
+
+
+int sx_reverse_dev(sx_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out)
+{
+    if (!ctx || !d_out || (n && !d_in)) return SX_E_ARG;
+    // (the two buffers must not overlap: every byte moves)
+    if (n && d_in < d_out + n + 1 && d_out < d_in + n) return sx_fail_msg(ctx, SX_E_ARG, "reverse: the buffers overlap");
+    SX_CHECK(hipSetDevice(ctx->device));
+    uint32_t grid = sx_div_up(sx_div_up(n ? n : 1, 16), kBlock);
+    if (grid > 16384) grid = 16384;
+    sx_launch(ctx, SX_KC_REMAP, 2 * n, reverse_kernel, dim3(grid), dim3(kBlock), d_in, n, d_out);
     return sx_sync(ctx);
 }
 
