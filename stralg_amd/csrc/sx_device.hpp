@@ -169,6 +169,11 @@ template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v,
 #ifndef SX_OPAQUE_VGPR // the CPU test harness defines it away
 #define SX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
+// nothing is scheduled across this point (keeps the compiler from interleaving the unrolled copies of a register-hungry
+// step -- eight window decodes at once spilled a thousand registers)
+#ifndef SX_SCHED_FENCE // (the CPU test harness defines it away as well)
+#define SX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int BITS, bool ALL>
 __device__ __forceinline__ uint32_t wave_rank_inorder(uint32_t digit, bool valid, uint32_t *counter)
 {

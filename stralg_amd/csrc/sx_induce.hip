@@ -635,6 +635,41 @@ __global__ __launch_bounds__(kBlock) void induce_wide_apply_kernel(uint32_t *__r
 // A tile of 8192 entries is taken in kWideTile / (512 * ITEMS) steps of ITEMS entries a thread: 16 for 32-bit windows; 8 for
 // 64-bit windows (alphabets of 17 symbols and more), whose 16 entries a thread did not fit 128 registers -- 76 of them
 // were spilled, and a byte text's round of a single tile took 45 us.  A later step's entries go behind the earlier ones'.
+// Windows that ran dry, refilled from the text with every load in flight before the first is used: need[k] says which
+// of a thread's entries (positions val[k] >= 1) want one.  (wnd_fill under a branch per entry made a thread wait for
+// each of its random reads in turn: 8 trips to memory of ~1 us each, half the time of a wide alphabet's round --
+// measured with clock64 around the phases, tools/wide_probe.py.)
+template <class WT, int ITEMS>
+__device__ __forceinline__ void refill_windows(const uint8_t *__restrict__ T, const uint32_t (&val)[ITEMS], const bool (&need)[ITEMS],
+                                               const wnd_cfg &cfg, WT (&wnd)[ITEMS])
+{
+    uint64_t lo[ITEMS], hi[ITEMS];
+    uint32_t cnt[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        lo[k] = hi[k] = 0;
+        cnt[k] = val[k] < cfg.CW ? val[k] : cfg.CW;
+        if (need[k]) load_bytes16(T, (uint64_t)(val[k] - cnt[k]), lo[k], hi[k]);
+    }
+    // (decoded by a rolled loop, one entry after the other: eight inlined copies of wnd_from_bytes' unrolled forms, which
+    //  the compiler interleaves, spilled a thousand registers)
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        SX_SCHED_FENCE();
+        if (need[k]) {
+            WT acc = 0;
+            uint64_t w = lo[k];
+#pragma unroll 1
+            for (uint32_t i = 0; i < cnt[k]; ++i) { // text[p - cnt] first: it ends with text[p - 1] in the lowest field
+                acc = (acc << cfg.B) | (WT)((w & 0xFFull) - 1ull);
+                w = i == 7u ? hi[k] : w >> 8;
+            }
+            wnd[k] = (acc << kCntBits) | (WT)cnt[k];
+        }
+    }
+    SX_SCHED_FENCE();
+}
+
 // LDS of one scatter workgroup (the kernels below declare it and hand it to wide_scatter_tile)
 template <int ITEMS> struct wide_scatter_lds {
     static constexpr int kSub = kWideThreads * ITEMS;
@@ -661,40 +696,56 @@ __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, co
     uint32_t *goff = L.goff, *scan_lds = L.scan_lds;
     uint32_t *wcount = reinterpret_cast<uint32_t *>(swnd);
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+#ifdef SX_WIDE_PROBE
+    long long pr[10];
+    int pi = 0;
+#define SX_PROBE() do { if (pi < 10) pr[pi++] = clock64(); } while (0)
+#else
+#define SX_PROBE() do { } while (0)
+#endif
     for (int step = 0; step < kSteps; ++step) {
         const uint32_t step0 = tile * (uint32_t)kWideTile + (uint32_t)step * kSub;
         if (step0 >= len) break; // uniform
+        SX_PROBE();
         for (int i = t; i < kWideWaves * 256; i += kWideThreads) wcount[i] = 0;
         __syncthreads();
         const uint32_t wave0 = step0 + (uint32_t)w * (kWave * ITEMS);
         uint32_t val[ITEMS], lpos[ITEMS]; // position - 1; [12:0] rank, then staged slot, [31:16] bucket, bit 15: taken
         WT wnd[ITEMS];
+        // (every load of the step is issued before the first is looked at: with the look inside the loop a thread
+        //  waited for each of its 2 * ITEMS loads in turn -- 20 000 of a step's 35 000 cycles)
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            const uint32_t idx = lo + (i < len ? (rev ? len - 1u - i : i) : 0u);
+            val[k] = srcP[idx];
+            wnd[k] = srcW[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            const uint32_t p = i < len ? val[k] : 0u;
+            const WT ww = wnd[k];
             val[k] = 0;
             wnd[k] = 0;
             bool ok = false;
             uint32_t dig = 0;
-            if (i < len) {
-                const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                const uint32_t p = srcP[idx];
-                const WT ww = srcW[idx];
-                if (p != 0) {
-                    dig = wnd_first<WT>(ww, cfg);
-                    ok = induce_accept(dig, c, mode);
-                    val[k] = p - 1u;
-                    wnd[k] = wnd_pop<WT>(ww, cfg);
-                }
+            if (p != 0) {
+                dig = wnd_first<WT>(ww, cfg);
+                ok = induce_accept(dig, c, mode);
+                val[k] = p - 1u;
+                wnd[k] = wnd_pop<WT>(ww, cfg);
             }
             lpos[k] = ok ? (dig & 0xFFu) << 16 | 0x8000u : 0u;
         }
+        SX_PROBE();
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             const bool ok = (lpos[k] & 0x8000u) != 0;
             lpos[k] |= wave_rank_inorder<8, false>(lpos[k] >> 16, ok, wcount + w * 256);
         }
         __syncthreads();
+        SX_PROBE();
         uint32_t tot = 0;
         {
             if (t < 256) {
@@ -726,12 +777,16 @@ __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, co
         for (int k = 0; k < ITEMS; ++k)
             if (lpos[k] & 0x8000u) lpos[k] = (lpos[k] & 0xFFFF0000u) | 0x8000u | ((lpos[k] & 0x1FFFu) + wcount[w * 256 + (lpos[k] >> 16)]);
         __syncthreads(); // the counters are part of the staging image
+        SX_PROBE();
         // Windows that ran dry go back to the text: the round's only random access.  All of a thread's refills are
         // issued before the first one is used (under a branch per entry each would wait for its own trip to memory:
         // a seventh of the entries of a byte alphabet).
+        {
+            bool need[ITEMS];
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k)
-            if ((lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, val[k], cfg);
+            for (int k = 0; k < ITEMS; ++k) need[k] = (lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0;
+            refill_windows<WT, ITEMS>(T, val, need, cfg, wnd);
+        }
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             if (lpos[k] & 0x8000u) {
@@ -741,6 +796,7 @@ __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, co
             }
         }
         __syncthreads();
+        SX_PROBE();
         uint32_t dstv[ITEMS];
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
@@ -766,6 +822,12 @@ __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, co
             if (i < produced) SA[dstv[k]] = sval[i];
         }
         __syncthreads(); // LDS is reused by the next step
+        SX_PROBE();
+#ifdef SX_WIDE_PROBE
+        if (t == 0 && tile == 0 && blockIdx.x == 0 && (c == 60 || c == 200) && len > 100000 && step == 0)
+            printf("probe c=%u len=%u mode=%d: load %lld rank %lld scan %lld refill+stage %lld store %lld cycles\n", c, len, mode,
+                   pr[1] - pr[0], pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4]);
+#endif
     }
 }
 
@@ -1048,24 +1110,29 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
         uint32_t val[kIndItems], dig[kIndItems], rnk[kIndItems];
         WT wnd[kIndItems];
         bool ok[kIndItems];
+        // (all of the tile's loads are issued before the first is looked at: see wide_scatter_tile)
 #pragma unroll
         for (int k = 0; k < kIndItems; ++k) {
             const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            const uint32_t idx = lo + (i < len ? (rev ? len - 1u - i : i) : 0u);
+            val[k] = srcP[idx];
+            wnd[k] = srcW[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < kIndItems; ++k) {
+            const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+            const uint32_t p = i < len ? val[k] : 0u;
+            const WT ww = wnd[k];
             ok[k] = false;
             dig[k] = 0;
             val[k] = 0;
             wnd[k] = 0;
-            if (i < len) {
-                const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                const uint32_t p = srcP[idx];
-                if (p != 0) {
-                    const WT ww = srcW[idx];
-                    const uint32_t ch = wnd_first<WT>(ww, cfg);
-                    ok[k] = induce_accept(ch, c, mode);
-                    dig[k] = ch;
-                    val[k] = p - 1u;
-                    wnd[k] = wnd_pop<WT>(ww, cfg);
-                }
+            if (p != 0) {
+                const uint32_t ch = wnd_first<WT>(ww, cfg);
+                ok[k] = induce_accept(ch, c, mode);
+                dig[k] = ch;
+                val[k] = p - 1u;
+                wnd[k] = wnd_pop<WT>(ww, cfg);
             }
         }
 #pragma unroll
@@ -1107,16 +1174,20 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
             }
         }
         __syncthreads();
+        {
+            bool need[kIndItems]; // windows that ran dry: back to the text, all of a thread's reads in flight together
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) need[k] = ok[k] && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0;
+            refill_windows<WT, kIndItems>(T, val, need, cfg, wnd);
+        }
 #pragma unroll
         for (int k = 0; k < kIndItems; ++k) {
             if (ok[k]) {
                 const uint32_t d = dig[k];
                 const uint32_t r = gpos[d] + wcount[w][d] + rnk[k];
                 const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
-                const uint32_t j = val[k];
-                WT nw = wnd[k];
-                if (j != 0 && wnd_count<WT>(nw) == 0) nw = wnd_fill<WT>(T, j, cfg); // window ran dry: back to the text
-                SA[dst] = j;
+                const WT nw = wnd[k];
+                SA[dst] = val[k];
                 WN[dst] = nw;
                 BW[dst] = wnd_symbol<WT>(nw, cfg);
             }
@@ -1222,16 +1293,17 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         prev_len = len;
         if (!held) { // the range's entries from memory (the first round of a launch, or after a jump)
 #pragma unroll
+            for (int k = 0; k < kIndItems; ++k) { // (all loads issued before any is looked at)
+                const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+                const uint32_t idx = lo + (i < len ? (rev ? len - 1u - i : i) : 0u);
+                val[k] = SA[idx];
+                wnd[k] = WN[idx];
+            }
+#pragma unroll
             for (int k = 0; k < kIndItems; ++k) {
                 const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
                 live[k] = i < len;
-                val[k] = 0;
-                wnd[k] = 0;
-                if (live[k]) {
-                    const uint32_t idx = lo + (rev ? len - 1u - i : i);
-                    val[k] = SA[idx];
-                    wnd[k] = WN[idx];
-                }
+                if (!live[k]) val[k] = 0, wnd[k] = 0;
             }
         }
         uint32_t dig[kIndItems], rnk[kIndItems];
@@ -1261,6 +1333,12 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
             }
         }
         __syncthreads();
+        {
+            bool need[kIndItems];
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) need[k] = ok[k] && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0;
+            refill_windows<WT, kIndItems>(T, val, need, cfg, wnd);
+        }
 #pragma unroll
         for (int k = 0; k < kIndItems; ++k) {
             live[k] = ok[k] && dig[k] == c; // appended to bucket c itself: part of the next round
@@ -1268,9 +1346,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                 const uint32_t d = dig[k];
                 const uint32_t r = wcount[w][d & (uint32_t)(kDigits - 1)] + rnk[k];
                 const uint32_t dst = dir > 0 ? gbase[d] + r : gbase[d] - 1u - r;
-                const uint32_t j = val[k];
-                if (j != 0 && wnd_count<WT>(wnd[k]) == 0) wnd[k] = wnd_fill<WT>(T, j, cfg);
-                SA[dst] = j;
+                SA[dst] = val[k];
                 WN[dst] = wnd[k];
                 BW[dst] = wnd_symbol<WT>(wnd[k], cfg);
             }

@@ -195,6 +195,7 @@ static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsi
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3u)));
 }
 #define SX_OPAQUE_VGPR(x) ((void)0) /* a register-allocation hint on the GPU */
+#define SX_SCHED_FENCE() ((void)0)  /* a scheduling fence on the GPU */
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned add)
 {
     const int l = emu_lane();
