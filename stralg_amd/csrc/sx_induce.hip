@@ -489,24 +489,27 @@ __global__ __launch_bounds__(kWideThreads) void induce_wide_count_kernel(const W
 }
 
 // counts -> entries of earlier tiles, per bucket; the cursors move on; the range appended to bucket c.
-// One workgroup of 1024 threads (rounds of up to a few hundred tiles): thread (g, d) owns bucket d over the g-th quarter of
-// the tiles -- whole 1 KiB rows, 16 in flight -- sums it, the quarters' sums meet in LDS, and the second walk writes the
-// prefixes.  (One thread per bucket walking all the tiles, loads and in-place stores alternating: 31 us for the 500 tiles
-// of a byte text's buckets, of the 140 us such a bucket's round took.)
+// Eight workgroups, 32 buckets (128 bytes of every 1 KiB row) each: thread (g, d) owns bucket d over the g-th of 32
+// groups of tiles -- 16 rows in flight --, sums it, the groups' sums meet in LDS, and the second walk writes the prefixes.
+// Round 4: one workgroup of 1024 threads (four groups of tiles) took 16 us for the 450 tiles of a byte text's round,
+// a fifth of that bucket's whole chain of launches; a thread's walk is now an eighth as long (rounds of up to 4096
+// tiles; longer ones take the chunked form below).
 #ifndef SX_WIDE_OFF_GROUPS
-#define SX_WIDE_OFF_GROUPS 4 // (the CPU test harness: 2)
+#define SX_WIDE_OFF_GROUPS 32 // (the CPU test harness: 2)
 #endif
-constexpr int kWideOffGroups = SX_WIDE_OFF_GROUPS;
-__global__ __launch_bounds__(kBlock * kWideOffGroups) void induce_wide_offsets_kernel(uint32_t *__restrict__ hist,
+constexpr int kWideOffGroups = SX_WIDE_OFF_GROUPS, kWideOffCols = 32, kWideOffThreads = kWideOffCols * kWideOffGroups;
+constexpr uint32_t kWideOffMaxTiles = 4096;
+__global__ __launch_bounds__(kWideOffThreads) void induce_wide_offsets_kernel(uint32_t *__restrict__ hist,
                                                                      const uint32_t *__restrict__ range_in,
                                                                      uint32_t *__restrict__ range_out,
                                                                      const uint32_t *__restrict__ cursor_cur,
                                                                      uint32_t *__restrict__ cursor_nxt, int dir, uint32_t c,
                                                                      uint32_t min_len, int only_form)
 {
-    __shared__ uint32_t gsum[kWideOffGroups][256];
+    __shared__ uint32_t gsum[kWideOffGroups][kWideOffCols];
     const uint32_t len = range_in[1] - range_in[0];
-    const uint32_t d = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    const uint32_t dd = threadIdx.x % kWideOffCols, g = threadIdx.x / kWideOffCols;
+    const uint32_t d = blockIdx.x * kWideOffCols + dd; // gridDim.x = 256 / kWideOffCols
     if (len <= min_len) {
         if (only_form && g == 0) { // (no chained launch follows: an empty range is carried on here)
             cursor_nxt[d] = cursor_cur[d];
@@ -526,12 +529,11 @@ __global__ __launch_bounds__(kBlock * kWideOffGroups) void induce_wide_offsets_k
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) sum += x[i];
     }
-    gsum[g][d] = sum;
+    gsum[g][dd] = sum;
     __syncthreads();
     uint32_t run = 0, all = 0;
-#pragma unroll
     for (int gg = 0; gg < kWideOffGroups; ++gg) {
-        const uint32_t x = gsum[gg][d];
+        const uint32_t x = gsum[gg][dd];
         if ((uint32_t)gg < g) run += x;
         all += x;
     }
@@ -687,7 +689,8 @@ template <class WT, int ITEMS>
 __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW,
                                                   uint32_t lo, uint32_t len, uint32_t tile, int rev, int mode, uint32_t c, const wnd_cfg &cfg,
                                                   const uint8_t *__restrict__ T, uint32_t pre, uint32_t base_d, int dir,
-                                                  uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW)
+                                                  uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW,
+                                                  uint32_t refill_at = 0 /* windows left with at most this many symbols are read again */)
 {
     constexpr int kSub = kWideThreads * ITEMS, kSteps = kWideTile / kSub;
     static_assert(kWideTile % kSub == 0 && kSub * 8 >= kWideWaves * 256 * 4, "steps tile the tile; the counters fit the staging image");
@@ -784,7 +787,7 @@ __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, co
         {
             bool need[ITEMS];
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) need[k] = (lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0;
+            for (int k = 0; k < ITEMS; ++k) need[k] = (lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) <= refill_at;
             refill_windows<WT, ITEMS>(T, val, need, cfg, wnd);
         }
 #pragma unroll
@@ -873,6 +876,7 @@ __global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
 #define SX_BIGRAM_GRID 256u // (the CPU test harness: 2)
 #endif
 constexpr uint32_t kHoistGridX = SX_HOIST_GRID_X, kBigramGrid = SX_BIGRAM_GRID;
+constexpr int kHoistOffGroups = SX_HOIST_GRID_X >= 4u ? 4 : 2; // groups of tiles a bucket's offsets workgroup walks (256 threads each)
 constexpr uint32_t kBigramWords = 32768; // LDS counters of bigram_kernel: rows of nk counters, as many rows a pass as fit
 constexpr int kBigramThreads = 1024;
 __global__ __launch_bounds__(kBigramThreads) void bigram_kernel(const uint8_t *__restrict__ T, uint64_t n, uint32_t nk,
@@ -958,16 +962,16 @@ __global__ __launch_bounds__(kWideThreads) void hoist_count_kernel(const WT *__r
 // column totals tot[c][d] = entries of c's region that go to bucket d; dbase[c][d] = where the first of them lands
 // (L pass: the group (d, c) ends at EL[c][d] and these are its last tot entries; S pass: the group ends, downwards, at
 // ES[c][d] and these are the last ones before that end -- as the cursor the scatter counts down from)
-__global__ __launch_bounds__(kBlock * kWideOffGroups) void hoist_offsets_kernel(uint32_t *__restrict__ hist, const uint32_t *__restrict__ desc,
+__global__ __launch_bounds__(kBlock * kHoistOffGroups) void hoist_offsets_kernel(uint32_t *__restrict__ hist, const uint32_t *__restrict__ desc,
                                                                               const uint32_t *__restrict__ E, int dir,
                                                                               uint32_t *__restrict__ tot, uint32_t *__restrict__ dbase)
 {
-    __shared__ uint32_t gsum[kWideOffGroups][256];
+    __shared__ uint32_t gsum[kHoistOffGroups][256];
     const uint32_t c = blockIdx.x, len = desc[256 + c], row0 = desc[512 + c];
     const uint32_t d = threadIdx.x & 255u, g = threadIdx.x >> 8;
     const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
     uint32_t *rows = hist + (uint64_t)row0 * 256;
-    const uint32_t per = (ntiles + kWideOffGroups - 1) / kWideOffGroups;
+    const uint32_t per = (ntiles + kHoistOffGroups - 1) / kHoistOffGroups;
     const uint32_t t0 = g * per < ntiles ? g * per : ntiles, t1 = t0 + per < ntiles ? t0 + per : ntiles;
     constexpr int kBatch = 16;
     uint32_t sum = 0;
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(kBlock * kWideOffGroups) void hoist_offsets_kernel(
     __syncthreads();
     uint32_t run = 0, all = 0;
 #pragma unroll
-    for (int gg = 0; gg < kWideOffGroups; ++gg) {
+    for (int gg = 0; gg < kHoistOffGroups; ++gg) {
         const uint32_t x = gsum[gg][d];
         if ((uint32_t)gg < g) run += x;
         all += x;
@@ -1008,7 +1012,7 @@ template <class WT, int ITEMS>
 __global__ __launch_bounds__(kWideThreads, 4) void hoist_scatter_kernel(
     const uint32_t *__restrict__ srcP, const WT *__restrict__ srcW, const uint32_t *__restrict__ desc, int rev, int mode, wnd_cfg cfg,
     const uint8_t *__restrict__ T, const uint32_t *__restrict__ offs /* [row][256] */, const uint32_t *__restrict__ dbase, int dir,
-    uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW)
+    uint32_t *__restrict__ SA, WT *__restrict__ WN, uint8_t *__restrict__ BW, uint32_t refill_at)
 {
     __shared__ wide_scatter_lds<ITEMS> lds;
     const int t = (int)threadIdx.x;
@@ -1018,7 +1022,11 @@ __global__ __launch_bounds__(kWideThreads, 4) void hoist_scatter_kernel(
     const uint32_t base_d = t < 256 ? dbase[(uint64_t)c * 256 + t] : 0u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
         const uint32_t pre = t < 256 ? offs[(uint64_t)(row0 + tile) * 256 + t] : 0u;
-        wide_scatter_tile<WT, ITEMS>(lds, srcP, srcW, lo, len, tile, rev, mode, c, cfg, T, pre, base_d, dir, SA, WN, BW);
+        // The sort's seed windows hold two or three symbols: the entry a seed induces would be left with one, and the
+        // round that scans it -- one of the bucket's own, a chain of launches each bound by its latency -- would go back
+        // to the text for every such entry.  Here, at full occupancy, the read costs bandwidth only: windows that would be
+        // left with a single symbol are read again at once (refill_at = 1 in the L pass).
+        wide_scatter_tile<WT, ITEMS>(lds, srcP, srcW, lo, len, tile, rev, mode, c, cfg, T, pre, base_d, dir, SA, WN, BW, refill_at);
     }
 }
 
@@ -2203,8 +2211,8 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         const int only = only3 ? 1 : 0;
         sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_wide_count_kernel<WT>, dim3(wgrid), dim3(kWideThreads), srcW, srcB,
                   (const uint32_t *)rin, rev, mode, c, st.cfg, st.whist, chain_max);
-        if (wtiles <= 512) {
-            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_offsets_kernel, dim3(1), dim3(kBlock * kWideOffGroups),
+        if (wtiles <= kWideOffMaxTiles) {
+            sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)wtiles * 2048, induce_wide_offsets_kernel, dim3(256 / kWideOffCols), dim3(kWideOffThreads),
                       st.whist, (const uint32_t *)rin, rout, cur, nxt, dir, c, chain_max, only);
         } else {
             const uint32_t nchunks = sx_div_up(wtiles, kWideChunk);
@@ -2581,10 +2589,11 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (gx > kHoistGridX) gx = kHoistGridX;
         sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, hoist_count_kernel<WT>, dim3(gx, nk), dim3(kWideThreads), srcW, srcB, desc, rev, mode, st.cfg,
                   hz_hist);
-        sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)hz_rows[pass] * 2048, hoist_offsets_kernel, dim3(nk), dim3(kBlock * kWideOffGroups),
+        sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)hz_rows[pass] * 2048, hoist_offsets_kernel, dim3(nk), dim3(kBlock * kHoistOffGroups),
                   hz_hist, desc, (const uint32_t *)st.hoist_E, dir, hz_tot, hz_dbase);
         sx_launch(ctx, SX_KC_INDUCE_SCATTER, 0, hoist_scatter_kernel<WT, 8>, dim3(gx, nk), dim3(kWideThreads), srcP, srcW, desc, rev,
-                  mode, st.cfg, st.T, (const uint32_t *)hz_hist, (const uint32_t *)hz_dbase, dir, st.SA, st.WN, st.BW);
+                  mode, st.cfg, st.T, (const uint32_t *)hz_hist, (const uint32_t *)hz_dbase, dir, st.SA, st.WN, st.BW,
+                  (uint32_t)(pass == 0 ? 1 : 0));
         ctx->stats.induce_rounds++;
         return 0;
     };
