@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other BASELINE.json configurations measured after the timed region (default run only)")
     ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each of the other configurations")
+    ap.add_argument("--no-ro", action="store_true",
+                    help="FASTA records: skip the reverse direction (build_complete_table's include_reverse: the RO table)")
     ap.add_argument("--no-egress", action="store_true",
                     help="FASTA records: skip the egress leg (the record's index leaving the GPU on every rank at once)")
     return ap.parse_args(argv)
@@ -370,7 +372,7 @@ def other_configs(ctx, dev, steps, cuda=True, log2n=30, cpu_whole_record=False):
 
 # ---- FASTA records: the index leaves the GPU (what limits configs[4]: PCIe, host memory, NUMA) -----------------------
 
-def egress_leg(ctx, local_rank, text, n, sigma, world, red_dev, cuda=True):
+def egress_leg(ctx, local_rank, text, n, sigma, world, red_dev, cuda=True, with_ro=False):
     """Every rank at once, between barriers: the record's whole index (suffix array, C, O: 24 bytes per base) leaves
     the GPU -- (1) stralg_amd_write_complete_bwt_info_stream into /dev/null (stralg/serialise.c:7-18's file, streamed
     through two pinned buffers: no host copy of the tables), (2) memory permitting, sx_build_tables into malloc'd host
@@ -403,12 +405,25 @@ def egress_leg(ctx, local_rank, text, n, sigma, world, red_dev, cuda=True):
 
     stream()  # (the first call pays the thread context's hipMalloc and the pinned buffers)
     t_own = farm.timed(stream, 1, 0, cuda=cuda)
-    libc.fclose(f)
     t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
     out.update(stream_ms_per_record=round(t_max * 1e3, 1),
                egress_inclusive_Msuffixes_per_s=round(units / t_max / 1e6, 3),
                d2h_GBps_per_rank=round(index_bytes / t_own / 1e9, 2),
                d2h_GBps_all_ranks=round(index_bytes * world / t_max / 1e9, 2))
+    if with_ro:
+        # the index file bwt_readmapper -p writes: write_complete_bwt_info of build_complete_table(seq, TRUE) -- the RO
+        # table streams out behind the O table (44 bytes per base over PCIe instead of 24)
+        def stream_ro():
+            if lib.stralg_amd_write_complete_bwt_info_stream(f, letters, True) != 0:
+                raise RuntimeError("stralg_amd_write_complete_bwt_info_stream (include_reverse) failed")
+
+        t_own = farm.timed(stream_ro, 1, 0, cuda=cuda)
+        t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
+        ro_bytes = index_bytes + 4 * sigma * (N + 1)
+        out["egress_with_ro"] = {"index_bytes_per_record": ro_bytes, "stream_ms_per_record": round(t_max * 1e3, 1),
+                          "egress_inclusive_Msuffixes_per_s": round(units / t_max / 1e6, 3),
+                          "d2h_GBps_per_rank": round(ro_bytes / t_own / 1e9, 2)}
+    libc.fclose(f)
     lib.stralg_amd_release()
     # (2) into malloc'd host arrays, when every rank's 24 bytes per base fit the host
     need = (index_bytes + n) * world
@@ -611,13 +626,51 @@ def run_rank(args):
         job.upload()
         fasta["h2d_GBps_per_rank"] = round(job.file_len / (time.perf_counter() - t0) / 1e9, 2)
         fasta["numa_node_per_rank"] = farm.gather_ints(numa_node if numa_node is not None else -1)
+        if tables and not args.no_ro:
+            # What bwt_readmapper.c:57 actually asks for: build_complete_table(rec.seq, true) -- the reversed string's suffix
+            # array and the RO table too (bwt.c:147-158), on the device: sx_reverse_dev, a second sx_sa_bwt_build_dev,
+            # sx_bwt_tables_from_bwt_dev.  Timed like the forward step (kernel-only, then with the ingest), verified.
+            job.set_include_reverse(True)
+            job.build()  # (allocates the reverse direction's buffers)
+            k = max(1, min(args.steps, 3))
+            t_ro = farm.timed(job.build, k, 0, cuda=cuda)
+            t_ro_max, units_ro = farm.reduce_scalars(t_ro, k * N, device=red_dev)
+            t_ro_in = farm.timed(ingest_step, k, 0, cuda=cuda)
+            t_ro_in_max, units_ro_in = farm.reduce_scalars(t_ro_in, k * N, device=red_dev)
+            ro = {"steps": k, "kernel_only_ms_per_record": round(t_ro_max / k * 1e3, 3),
+                  "kernel_only_Msuffixes_per_s": round(units_ro / t_ro_max / 1e6, 3),
+                  "ingest_inclusive_ms_per_record": round(t_ro_in_max / k * 1e3, 3),
+                  "ingest_inclusive_Msuffixes_per_s": round(units_ro_in / t_ro_in_max / 1e6, 3),
+                  "forward_only_ms_per_record": round(elapsed / args.steps * 1e3, 3),
+                  "note": "build_complete_table(seq, true): forward SA + BWT + C/O, then reversal, the reverse suffix array and RO; "
+                          "Msuffixes/s counts the record's n + 1 suffixes once"}
+            if not args.no_verify:
+                from stralg_amd import verify
+                ctx.trim()
+                try:
+                    # RO is the O table of the reversed string (bwt.c:67-88): its rows by the one-hot property on that
+                    # string's BWT, its suffix array by the O(n) order check, the reversal itself entry by entry
+                    if not bool((job.d_rev[:job.n] == torch.flip(job.d_text[:job.n], dims=[0])).all()) or int(job.d_rev[job.n]) != 0:
+                        raise AssertionError("the reversed string is not the reverse")
+                    verify.verify_build_on_device(job.d_rev, job.n, job.sigma, job.rsa, job.rbwt, job.rc, job.ro)
+                    if not bool((job.rc == job.c).all()):
+                        raise AssertionError("the reverse direction's C table differs from the forward one")
+                    ro["verified"] = True
+                except AssertionError as e:
+                    ro["verified"] = False
+                    ro["error"] = str(e)
+                    print(f"bench.py: reverse-direction verification failed on rank {rank}: {e}", file=sys.stderr)
+                bad_ro, _ = farm.reduce_scalars(0.0 if ro["verified"] else 1.0, 0, device=red_dev)
+                ro["verified"] = ro["verified"] and bad_ro == 0.0
+            fasta["with_ro"] = ro
+            job.set_include_reverse(False)
         if not args.no_egress:
             job_n, job_sigma = job.n, job.sigma
             job = None  # the index is rebuilt from the host's copy of the record: free the device-resident one
             ctx.trim()
             if cuda:
                 torch.cuda.empty_cache()
-            eg = egress_leg(ctx, local_rank, text, job_n, job_sigma, world, red_dev, cuda)
+            eg = egress_leg(ctx, local_rank, text, job_n, job_sigma, world, red_dev, cuda, with_ro=tables and not args.no_ro)
             fasta.update(eg)
 
     if rank == 0:

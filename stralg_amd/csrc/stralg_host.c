@@ -97,11 +97,120 @@ static void parallel_ranges(size_t total, void (*fn)(size_t, size_t, void *), vo
 }
 
 /* result arrays: malloc-family memory (callers free() it); large ones are aligned to 2 MiB and advised to use
- * transparent huge pages, which turns 6 million page faults per 24 GiB into 12 thousand */
+ * transparent huge pages, which turns 6 million page faults per 24 GiB into 12 thousand.
+ *
+ * Round 4: a per-thread cache of large blocks.  The production loop is build_complete_table -> write -> free -> build
+ * (tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62), and for a 1 GiB record completely_free_bwt_table took 1.9 s --
+ * longer than the build: 52 GiB of huge pages unmapped -- only for the next build to map and first-touch as many again,
+ * which is what bounds its downloads.  The free_* functions of this library now hand blocks of 64 MiB and more to the
+ * calling thread's cache instead of to free(), and big_alloc takes a cached block that is large enough (and not more
+ * than twice as large) before it asks malloc.  Cached blocks are ordinary malloc blocks: a caller that free()s an array
+ * itself bypasses the cache, nothing else changes.  Bounds: 8 blocks and $STRALG_AMD_HOST_CACHE_GIB (default 64, never
+ * more than half the machine's memory; 0 disables the cache) per thread; the cache goes with stralg_amd_release() and
+ * at thread exit. */
+#include <malloc.h>
+
+#define BLOCK_CACHE_SLOTS 8
+struct block_cache {
+    void *p[BLOCK_CACHE_SLOTS];
+    size_t bytes[BLOCK_CACHE_SLOTS];
+    size_t total;
+};
+static pthread_key_t cache_key;
+static pthread_once_t cache_key_once = PTHREAD_ONCE_INIT;
+static int cache_key_ok = 0;
+
+static void block_cache_drop(void *arg)
+{
+    struct block_cache *bc = arg;
+    if (!bc) return;
+    for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i) free(bc->p[i]);
+    free(bc);
+}
+
+static void cache_key_make(void) { cache_key_ok = pthread_key_create(&cache_key, block_cache_drop) == 0; }
+
+static size_t block_cache_cap(void)
+{
+    static size_t cap = (size_t)-1;
+    if (cap != (size_t)-1) return cap;
+    const char *env = getenv("STRALG_AMD_HOST_CACHE_GIB");
+    size_t gib = env ? (size_t)atol(env) : 64;
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+    if (pages > 0 && psz > 0) {
+        const size_t half = (size_t)pages / 2 * (size_t)psz >> 30;
+        if (gib > half) gib = half;
+    }
+    cap = gib << 30;
+    return cap;
+}
+
+static struct block_cache *block_cache_get(bool create)
+{
+    pthread_once(&cache_key_once, cache_key_make);
+    if (!cache_key_ok) return NULL;
+    struct block_cache *bc = pthread_getspecific(cache_key);
+    if (!bc && create) {
+        bc = calloc(1, sizeof *bc);
+        if (bc && pthread_setspecific(cache_key, bc) != 0) {
+            free(bc);
+            bc = NULL;
+        }
+    }
+    return bc;
+}
+
+static const size_t kBlockCacheMin = (size_t)64 << 20;
+
+/* free() for the large arrays this library allocated: into the calling thread's cache when there is room */
+static void big_free(void *p)
+{
+    if (!p) return;
+    const size_t bytes = malloc_usable_size(p);
+    struct block_cache *bc = bytes >= kBlockCacheMin && block_cache_cap() ? block_cache_get(true) : NULL;
+    if (bc && bc->total + bytes <= block_cache_cap()) {
+        for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i)
+            if (!bc->p[i]) {
+                bc->p[i] = p;
+                bc->bytes[i] = bytes;
+                bc->total += bytes;
+                return;
+            }
+    }
+    free(p);
+}
+
+static void block_cache_release(void)
+{
+    struct block_cache *bc = block_cache_get(false);
+    if (!bc) return;
+    for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i) {
+        free(bc->p[i]);
+        bc->p[i] = NULL;
+        bc->bytes[i] = 0;
+    }
+    bc->total = 0;
+}
+
 static void *big_alloc(size_t bytes)
 {
     const size_t huge = (size_t)2 << 20;
     if (bytes < 4 * huge) return malloc(bytes ? bytes : 1);
+    if (bytes >= kBlockCacheMin) {
+        struct block_cache *bc = block_cache_get(false);
+        if (bc) { /* the smallest cached block that holds it, unless it is more than twice as large */
+            int best = -1;
+            for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i)
+                if (bc->p[i] && bc->bytes[i] >= bytes && bc->bytes[i] / 2 <= bytes && (best < 0 || bc->bytes[i] < bc->bytes[best])) best = i;
+            if (best >= 0) {
+                void *p = bc->p[best];
+                bc->total -= bc->bytes[best];
+                bc->p[best] = NULL;
+                bc->bytes[best] = 0;
+                return p;
+            }
+        }
+    }
     void *p = aligned_alloc(huge, (bytes + huge - 1) & ~(huge - 1));
     if (!p) return malloc(bytes);
     (void)madvise(p, (bytes + huge - 1) & ~(huge - 1), MADV_HUGEPAGE);
@@ -159,6 +268,7 @@ void stralg_amd_release(void)
     if (tls_ctx) sx_ctx_destroy(tls_ctx);
     tls_ctx = NULL;
     ctx_key_set(NULL);
+    block_cache_release();
 }
 
 /* contexts alive in this process (created minus destroyed): what the thread-exit test looks at */
@@ -205,15 +315,15 @@ struct suffix_array *skew_sa_construction(uint8_t *string)
 
 void free_suffix_array(struct suffix_array *sa)
 {
-    free(sa->array);
-    free(sa->inverse);
-    free(sa->lcp);
+    big_free(sa->array);
+    big_free(sa->inverse);
+    big_free(sa->lcp);
     free(sa);
 }
 
 void free_complete_suffix_array(struct suffix_array *sa)
 {
-    free(sa->string);
+    big_free(sa->string);
     free_suffix_array(sa);
 }
 
@@ -367,10 +477,10 @@ struct bwt_table *alloc_bwt_table(struct suffix_array *sa, struct suffix_array *
 void dealloc_bwt_table(struct bwt_table *bwt_table)
 {
     free(bwt_table->c_table);
-    free(bwt_table->o_table);
-    free(bwt_table->o_indices);
-    free(bwt_table->ro_table);
-    free(bwt_table->ro_indices);
+    big_free(bwt_table->o_table);
+    big_free(bwt_table->o_indices);
+    big_free(bwt_table->ro_table);
+    big_free(bwt_table->ro_indices);
 }
 
 void free_bwt_table(struct bwt_table *bwt_table)
@@ -499,7 +609,7 @@ static int build_complete_table_try(const uint8_t *string, bool include_reverse,
     const bool timing = getenv("STRALG_AMD_TIMING") != NULL;
     const double t0 = timing ? now_ms() : 0.0;
     const size_t n = strlen((const char *)string);
-    uint8_t *remapped = malloc(n + 1);
+    uint8_t *remapped = big_alloc(n + 1);
     if (!remapped) return SX_E_NOMEM;
     struct remap_table *remap_table = remap_record(string, n, remapped);
     if (remap_table->alphabet_size > 128) {
@@ -553,7 +663,7 @@ static int build_complete_table_try(const uint8_t *string, bool include_reverse,
     if (include_reverse) {
         /* the reverse suffix array and the reversed copy are temporary (bwt.c:147-158) */
         const double t3 = timing ? now_ms() : 0.0;
-        uint8_t *rev = malloc(n + 1);
+        uint8_t *rev = big_alloc(n + 1);
         uint32_t *c_tmp = calloc(sigma, sizeof *c_tmp);
         table->ro_table = big_alloc(o_words * sizeof *table->ro_table);
         if (!rev || !c_tmp || !table->ro_table) {
@@ -567,7 +677,7 @@ static int build_complete_table_try(const uint8_t *string, bool include_reverse,
         rev[n] = 0;
         rc = sx_build_tables(ctx, rev, n, sigma, NULL, c_tmp, table->ro_table);
         free(c_tmp);
-        free(rev);
+        big_free(rev);
         if (rc != 0) {
             fprintf(stderr, "stralg_amd: build_complete_table (reverse) failed (code %d): %s\n", rc, sx_last_error(ctx));
             free_partial_table(table);

@@ -41,6 +41,7 @@ constexpr int kIndTile = kBlock * kIndItems;
 constexpr int kTailBlock = 1024, kTailWaves = kTailBlock / kWave; // the tail kernel's workgroup: 16 waves, one tile
 constexpr int kTailTile = kTailBlock * kIndItems;
 constexpr uint32_t kTailEntries = (uint32_t)kTailTile;
+constexpr uint32_t kTailMulti = 4; // more than 8 buckets: tiles of a round the tail kernel takes one after the other
 
 enum { MODE_L_FROM_L = 0, MODE_L_FROM_LMS = 1, MODE_S_FROM_S = 2, MODE_S_FROM_L = 3 };
 __device__ __forceinline__ void tail_report(uint32_t lo, uint32_t hi, uint32_t c, uint32_t *poison, uint32_t *host_poison);
@@ -1094,7 +1095,7 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
     const uint32_t lo = range_in[0], hi = range_in[1];
     const uint32_t len = hi - lo;
     if (len > chain_max && !pass_large) return; // a large round: the three-launch form handles it
-    if (len == 0 || (range_out && tail_follows && len <= kTailEntries) || len > chain_max) {
+    if (len == 0 || (range_out && tail_follows && len <= (BITS > 3 ? kTailMulti * kTailEntries : kTailEntries)) || len > chain_max) {
         // nothing to do, or a round small enough for the tail kernel that ends the batch: carry the cursors over,
         // hand the range on as it is
         if (blockIdx.x == 0) {
@@ -1244,7 +1245,11 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
     const uint32_t wave0 = (uint32_t)w * (kWave * kIndItems);
     for (uint32_t it = 0; it < max_iters; ++it) {
         const uint32_t lo = s_range[0], len = s_range[1] - lo;
-        if (len == 0 || len > kTailEntries) break; // uniform
+        // (more than 8 buckets: a round of up to kTailMulti tiles is taken tile after tile -- the second round of a byte
+        //  text's buckets, 8 - 16 thousand entries, was a chained launch of its own in front of this kernel: 10 us of
+        //  the bucket's 70)
+        if (len == 0 || len > (BITS == 3 ? kTailEntries : kTailMulti * kTailEntries)) break; // uniform
+        const bool multi = len > kTailEntries; // uniform
         // ---- run jump -------------------------------------------------------------------
         // Inside a long run of symbol c every entry of the range induces its left neighbour
         // into bucket c again, round after round, in the same order.  If the L symbols to the
@@ -1252,7 +1257,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         // entries minus j, in the next `len` slots.  They are written at once (L = 16 symbols
         // per checking thread; 4096 rounds a step for a single run) instead of one at a time.
         // Tried only when the last round kept every entry (the sign of runs): the check reads memory.
-        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len == prev_len) {
+        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && len == prev_len && !multi) {
             const uint32_t G = len <= (uint32_t)kTailBlock ? (uint32_t)kTailBlock / len : 1u; // threads per entry
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
             // thread (i, q) looks at the q-th 16 symbols to the left of entry i; the nearest piece of any entry that is
@@ -1299,17 +1304,19 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
             }
         }
         prev_len = len;
-        if (!held) { // the range's entries from memory (the first round of a launch, or after a jump)
+        const uint32_t c_first = gbase[c]; // (where the round's appends to bucket c begin)
+        for (uint32_t sub0 = 0; sub0 < len; sub0 += kTailEntries) { // uniform; one trip unless `multi`
+        if (!held || multi) { // the range's entries from memory (the first round of a launch, after a jump, a round of several tiles)
 #pragma unroll
             for (int k = 0; k < kIndItems; ++k) { // (all loads issued before any is looked at)
-                const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+                const uint32_t i = sub0 + wave0 + (uint32_t)k * kWave + lane;
                 const uint32_t idx = lo + (i < len ? (rev ? len - 1u - i : i) : 0u);
                 val[k] = SA[idx];
                 wnd[k] = WN[idx];
             }
 #pragma unroll
             for (int k = 0; k < kIndItems; ++k) {
-                const uint32_t i = wave0 + (uint32_t)k * kWave + lane;
+                const uint32_t i = sub0 + wave0 + (uint32_t)k * kWave + lane;
                 live[k] = i < len;
                 if (!live[k]) val[k] = 0, wnd[k] = 0;
             }
@@ -1359,17 +1366,20 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                 BW[dst] = wnd_symbol<WT>(wnd[k], cfg);
             }
         }
-        held = true;
+        held = !multi; // (the entries a round of several tiles appended lie with many threads' registers' worth each: from memory)
         __syncthreads();
         if (t < kDigits) {
-            const uint32_t before = gbase[t], now = dir > 0 ? before + cnt : before - cnt;
-            gbase[t] = now;
-            if ((uint32_t)t == c) { // what the round appended to bucket c is the next round's input
-                s_range[0] = dir > 0 ? before : now;
-                s_range[1] = dir > 0 ? now : before;
-            }
+            const uint32_t before = gbase[t];
+            gbase[t] = dir > 0 ? before + cnt : before - cnt;
 #pragma unroll
             for (int ww = 0; ww < kTailWaves; ++ww) wcount[ww][t] = 0;
+        }
+        __syncthreads();
+        } // (tiles of the round)
+        if ((uint32_t)t == c) { // what the round appended to bucket c is the next round's input
+            const uint32_t now = gbase[c];
+            s_range[0] = dir > 0 ? c_first : now;
+            s_range[1] = dir > 0 ? now : c_first;
         }
         __syncthreads();
     }
@@ -2326,11 +2336,16 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
     if (!st.small_alphabet) {
         // by the symbol's share of the text: rounds are queued until the one handed to the tail kernel is expected to hold
         // an eighth of what the kernel takes (a pass queued as a whole has nobody to queue one more: 1 GiB of 20 symbols,
-        // round 3 of a bucket expected at 5400 entries, beyond 8192 in two buckets -- both passes ran twice)
+        // round 3 of a bucket expected at 5400 entries, beyond 8192 in two buckets -- both passes ran twice).  Round 4: the
+        // tail kernel takes rounds of up to kTailMulti tiles (32 768 entries), so an unattended bucket's rounds are queued
+        // by the share alone (a byte text: one round, then the tail kernel; the chained launch in between is gone) -- a
+        // bucket whose runs make the rounds shrink more slowly than its share says leaves word and is carried on attended,
+        // with the longer queue.
         double expect = (double)region_entries * share;
         int by_share = 1;
-        while (by_share < kMaxSpec && expect > (double)kTailEntries / 8.0) ++by_share, expect *= share;
-        if (by_share > spec) spec = by_share;
+        while (by_share < kMaxSpec && expect > (double)(kTailMulti * kTailEntries) / 8.0) ++by_share, expect *= share;
+        if (st.unattended && !resume) spec = by_share;
+        else if (by_share > spec) spec = by_share;
     }
     // Every batch ends with the tail kernel, which runs kTailIters rounds unless the range empties first, and a round
     // consumes one symbol of every run it follows: a bucket cannot need more batches than this (a device fault that

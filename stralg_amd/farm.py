@@ -158,13 +158,17 @@ class FastaRecordJob:
         file image (host) --H2D--> image in HBM -> sx_fasta_pack_dev (bioinf/fasta.c:92-135)
         -> sx_remap_dev (remap.c:8-31,102-114) -> sx_sa_bwt_build_dev (sa_is.c:466-509)
         -> sx_bwt_tables_from_bwt_dev (bwt.c:35-65)
+        include_reverse (what bwt_readmapper.c:57 asks build_complete_table for, bwt.c:147-158):
+        -> sx_reverse_dev -> sx_sa_bwt_build_dev on the reversed string -> sx_bwt_tables_from_bwt_dev = the RO table
+           (the reverse suffix array and C table are temporaries, as in the reference)
 
     `dev` is a torch device: cuda:k with the product library, cpu with the CPU execution harness
     of the kernels (tests).  The buffers are allocated once and reused by every call."""
 
-    def __init__(self, ctx, image_host, dev, tables=True):
+    def __init__(self, ctx, image_host, dev, tables=True, include_reverse=False):
         import torch
         self.ctx, self.dev, self.tables = ctx, dev, tables
+        self.include_reverse = bool(include_reverse and tables)
         self.h_file = image_host  # torch uint8 on the CPU (pinned when a GPU is used)
         flen = int(image_host.numel())
         self.file_len = flen
@@ -174,6 +178,7 @@ class FastaRecordJob:
         self.d_text = torch.empty(flen + 1, dtype=torch.uint8, device=dev)
         self.n = self.sigma = None
         self.sa = self.bwt = self.c = self.o = None
+        self.d_rev = self.rsa = self.rbwt = self.rc = self.ro = None
 
     def upload(self):
         """the H2D copy of the file image (what load_fasta_records' fread is to the reference)"""
@@ -181,6 +186,11 @@ class FastaRecordJob:
         if self.dev.type == "cuda":
             import torch
             torch.cuda.synchronize(self.dev)
+
+    def set_include_reverse(self, on):
+        self.include_reverse = bool(on and self.tables)
+        if not self.include_reverse:
+            self.d_rev = self.rsa = self.rbwt = self.rc = self.ro = None
 
     def build(self):
         """image in HBM -> tables; returns the number of suffixes built (n + 1)"""
@@ -199,7 +209,19 @@ class FastaRecordJob:
             self.bwt = torch.empty(N, dtype=torch.uint8, device=self.dev)
             self.c = torch.zeros(sigma, dtype=torch.int32, device=self.dev)
             self.o = torch.empty((N + 1) * sigma, dtype=torch.int32, device=self.dev) if self.tables else None
+            self.d_rev = None
         ctx.sa_bwt_build_dev(self.d_text, n, sigma, self.sa, self.bwt)
         if self.tables:
             ctx.bwt_tables_from_bwt_dev(self.bwt, n + 1, sigma, self.c, self.o)
+        if self.include_reverse:
+            N = n + 1
+            if self.d_rev is None:
+                self.d_rev = torch.empty(N, dtype=torch.uint8, device=self.dev)
+                self.rsa = torch.empty(N, dtype=torch.int32, device=self.dev)
+                self.rbwt = torch.empty(N, dtype=torch.uint8, device=self.dev)
+                self.rc = torch.zeros(sigma, dtype=torch.int32, device=self.dev)
+                self.ro = torch.empty((N + 1) * sigma, dtype=torch.int32, device=self.dev)
+            ctx.reverse_dev(self.d_text, n, self.d_rev)
+            ctx.sa_bwt_build_dev(self.d_rev, n, sigma, self.rsa, self.rbwt)
+            ctx.bwt_tables_from_bwt_dev(self.rbwt, N, sigma, self.rc, self.ro)
         return n + 1

@@ -752,3 +752,20 @@ def test_farm_goes_on_past_a_record_it_cannot_build(emu_ctx, golden):
         assert (np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,)) == c["sa"]).all(), name
         assert (np.ctypeslib.as_array(t.contents.ro_table, shape=(N + 1, c["sigma"])) == c["ro"]).all(), name
         lib.completely_free_bwt_table(t)
+
+
+def test_reverse_on_the_device(emu_ctx):
+    """sx_reverse_dev (the reversed copy build_complete_table sorts for the RO table, bwt.c:147-151): sizes around its
+    16-byte pieces, an unaligned destination, the terminator, and the overlap check"""
+    from stralg_amd import StralgAmdError
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 1000, 4099):
+        x = rng.integers(1, 6, size=n, dtype=np.uint8)
+        for shift in (0, 3):
+            buf = np.full(n + 1 + shift + 16, 0xEE, dtype=np.uint8)
+            out = buf[shift:shift + n + 1]
+            emu_ctx.reverse_dev(x, n, out)
+            assert (out[:n] == x[::-1]).all() and out[n] == 0 and (buf[:shift] == 0xEE).all() and (buf[shift + n + 1:] == 0xEE).all()
+    both = np.zeros(64, dtype=np.uint8)
+    with pytest.raises(StralgAmdError):
+        emu_ctx.reverse_dev(both[:32], 32, both[8:])

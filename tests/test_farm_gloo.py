@@ -144,6 +144,11 @@ def test_bench_launches_its_own_ranks_on_fasta_records(emu_ctx):
                 "host_tables_ms_per_record", "host_tables_Msuffixes_per_s"):
         assert key in fr and fr[key] >= 0, key
     assert fr["stream_ms_per_record"] > 0 and fr["egress_inclusive_Msuffixes_per_s"] > 0
+    # what bwt_readmapper.c:57 asks for -- build_complete_table(seq, true): the reverse direction on the device too, verified
+    ro = fr["with_ro"]
+    assert ro["verified"] is True and ro["kernel_only_ms_per_record"] > 0 and ro["ingest_inclusive_Msuffixes_per_s"] > 0
+    assert fr["egress_with_ro"]["index_bytes_per_record"] == fr["index_bytes_per_record"] + 4 * 5 * 5005
+    assert fr["egress_with_ro"]["stream_ms_per_record"] > 0
 
 
 def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up(emu_ctx):

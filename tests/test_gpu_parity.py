@@ -921,6 +921,39 @@ def test_fasta_to_tables_on_device(gpu_ctx):
         assert (o.cpu().numpy().view(np.uint32) == oracle.o_table(sym_want, sa_want, sigma).ravel()).all()
 
 
+def test_fasta_record_with_reverse_against_oracle(gpu_ctx):
+    """What the production caller asks for (bwt_readmapper.c:57: build_complete_table(rec.seq, true)) for a record that
+    never leaves the GPU: farm.FastaRecordJob with include_reverse -- image -> pack -> remap -> SA + BWT + C/O, then
+    sx_reverse_dev, the reversed string's suffix array and the RO table (bwt.c:147-158) -- every array against the oracle
+    (RO = the O table of the reversed string, bwt.c:67-88), at 4 Mi bases and at sizes around the reversal's 16-byte pieces."""
+    import torch
+    from stralg_amd import farm, workloads
+    dev = torch.device("cuda", 0)
+    for n, seed in ((1 << 22, 9), (1, 3), (15, 4), (16, 5), (17, 6), (4099, 7)):
+        text = torch.from_numpy(synth(n, 5, seed)).to(dev)
+        image = workloads.fasta_image(text, "rec")
+        job = farm.FastaRecordJob(gpu_ctx, image.cpu().pin_memory(), dev, tables=True, include_reverse=True)
+        job.upload()
+        assert job.build() == n + 1 and job.n == n
+        letters = np.frombuffer(b"NACGTN", dtype=np.uint8)[text.cpu().numpy()]
+        x, sigma, _ = oracle.remap(letters)  # (a short record may miss a letter: dense codes, remap.c:8-31)
+        assert job.sigma == sigma
+        rev = x[::-1].copy()
+        assert (job.d_text[:n].cpu().numpy() == x).all()
+        assert (job.d_rev[:n].cpu().numpy() == rev).all() and int(job.d_rev[n]) == 0
+        sa_want, rsa_want = oracle.sa_is(x, sigma), oracle.sa_is(rev, sigma)
+        assert (job.sa.cpu().numpy().view(np.uint32) == sa_want).all(), n
+        assert (job.rsa.cpu().numpy().view(np.uint32) == rsa_want).all(), n
+        assert (job.c.cpu().numpy().view(np.uint32) == oracle.c_table(x, sigma)).all()
+        assert (job.rc.cpu().numpy().view(np.uint32) == oracle.c_table(rev, sigma)).all()
+        assert (job.o.cpu().numpy().view(np.uint32) == oracle.o_table(x, sa_want, sigma).ravel()).all(), n
+        assert (job.ro.cpu().numpy().view(np.uint32) == oracle.o_table(rev, rsa_want, sigma).ravel()).all(), n
+        job.set_include_reverse(False)
+        assert job.ro is None and job.build() == n + 1
+        del job, text, image
+        torch.cuda.empty_cache()
+
+
 def test_fasta_record_at_full_size(gpu_ctx):
     """BASELINE.json configs[4]'s unit of work at its size: one FASTA record of 2^30 bases (60-column lines, as
     bench.py --gpus N gives every rank) from the file image in HBM through sx_fasta_pack_dev -> sx_remap_dev ->
