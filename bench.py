@@ -263,6 +263,34 @@ def end_to_end(ctx, sizes, seed):
             res[key] = round(best * 1e3, 1)
         res["build_complete_table_Msuffixes_per_s"] = round(N / (res["build_complete_table_ms"] * 1e-3) / 1e6, 1)
         res["bytes_over_pcie"] = moved
+        if log2n == max(sizes):
+            # the production caller's loop (tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62): build_complete_table(seq,
+            # true) -> write_complete_bwt_info -> completely_free_bwt_table, record after record on one thread.  The freed
+            # arrays go to the thread's block cache (stralg_host.c) and come back for the next record: no unmapping of
+            # 52 GiB of huge pages (1.9 s a record in round 3), no first touch of as many by the next build.
+            lib.write_complete_bwt_info.argtypes = [C.c_void_p, C.c_void_p]
+            lib.write_complete_bwt_info.restype = None
+            libc = C.CDLL(None)
+            libc.fopen.restype = C.c_void_p
+            libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+            libc.fclose.argtypes = [C.c_void_p]
+            f = libc.fopen(b"/dev/null", b"wb")
+            per, frees = [], []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                t = lib.build_complete_table(letters, True)
+                lib.write_complete_bwt_info(f, t)
+                t1 = time.perf_counter()
+                lib.completely_free_bwt_table(t)
+                t2 = time.perf_counter()
+                per.append(round((t2 - t0) * 1e3, 1))
+                frees.append(round((t2 - t1) * 1e3, 1))
+            libc.fclose(f)
+            lib.stralg_amd_release()  # (the calling thread's context and its cached host blocks)
+            res["readmapper_loop"] = {"records": 4, "ms_per_record": per, "free_ms_per_record": frees,
+                                      "steady_ms_per_record": round(sum(per[1:]) / 3, 1),
+                                      "what": "build_complete_table(seq, true) + write_complete_bwt_info(/dev/null) + "
+                                              "completely_free_bwt_table, four records in a row on one thread"}
         out[f"2^{log2n}"] = res
     out["note"] = ("pageable malloc'd host buffers as the reference's ownership rules require; build_complete_table "
                    "includes the host remap and the o_indices row-pointer table; with_ro_ms adds the reverse table")

@@ -179,6 +179,10 @@ int stralg_amd_set_device(int device);
 void stralg_amd_release(void);
 /* device contexts alive in this process */
 int stralg_amd_live_contexts(void);
+/* strlen(string) as build_complete_table takes it for long records -- the readable extent of the string's mapping
+ * (/proc/self/maps) scanned by a few threads, 4 MiB chunks in increasing order -- and the byte values the string holds
+ * (present[256], filled when *have_letters comes back 1: strings of 4 MiB and more) */
+size_t stralg_amd_strlen_and_letters(const uint8_t *string, uint8_t *present, int *have_letters);
 /* Build tables for `count` independent strings over the listed devices by host threads pinned to their GPU's NUMA
  * node -- one a device for long records, up to four for records too short to fill a GPU
  * (stralg_amd_farm_workers_per_device); strings are dealt longest first to the least loaded worker (LPT by length).

@@ -532,8 +532,182 @@ static void lut_slice(size_t lo, size_t hi, void *arg)
         for (size_t i = lo; i < hi; ++i) j->out[i] = (uint8_t)j->table[j->in[i]];
 }
 
+/* ---- the length and the letters of a long record in one parallel pass ---------------------------------------------
+ * build_complete_table gets a NUL-terminated string: the reference starts with strlen (bwt.c:139, remap.c:73-77), a
+ * single thread walking 1 GiB at the speed of one core's memory stream -- 100 of the 115 ms this library's host side
+ * spent before the device saw the record.  A terminator cannot be looked for in parallel blindly: bytes behind it may
+ * not be mapped.  But how far the mapping the string lies in is readable is no secret (/proc/self/maps), and inside that
+ * extent any byte may be read.  So: the first 4 MiB by strnlen (short strings end there), then the readable extent, then
+ * a few threads take 4 MiB chunks in increasing order (a ticket counter), each looking for the terminator (memchr) and
+ * noting which letters its chunk holds; no chunk behind the first one with a terminator is started once that is known
+ * (at most a chunk per thread is read in vain).  The letters of the chunks in front of the terminator are the record's
+ * (remap.c:8-31's table follows from them). */
+static size_t readable_extent(const void *addr)
+{
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return 0;
+    const uintptr_t a = (uintptr_t)addr;
+    uintptr_t end = 0;
+    char line[512];
+    while (fgets(line, sizeof line, f)) {
+        unsigned long lo, hi;
+        char perms[8];
+        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3) continue;
+        if (end == 0) {
+            if (a >= lo && a < hi && perms[0] == 'r') end = hi;
+        } else if (lo == end && perms[0] == 'r') {
+            end = hi; /* the next mapping continues this one */
+        } else if (lo >= end) {
+            break;
+        }
+    }
+    fclose(f);
+    return end > a ? (size_t)(end - a) : 0;
+}
+
+#define SCAN_CHUNK ((size_t)4 << 20)
+struct scan_job {
+    const uint8_t *s;
+    size_t limit;              /* readable bytes from s on */
+    size_t nchunks;
+    size_t next;               /* ticket: the next chunk to take (atomic) */
+    size_t found;              /* the lowest chunk seen to hold a terminator (atomic; nchunks: none yet) */
+    size_t *end_in_chunk;      /* per chunk: offset of its terminator, or the chunk's length */
+    uint32_t (*letters)[8];    /* per chunk: the byte values in front of its terminator, 256 bits */
+};
+
+/* A chunk's terminator and letters in one pass.  A record has few distinct letters: 32 bytes at a time are compared with the
+ * letters seen so far (up to 16 of them: a compare and an OR each), and only a block that holds a new one is walked byte
+ * by byte -- a table look-up per byte ran at a byte a cycle, 1 GiB on 16 threads in 22 ms; this form is bound by memory. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* one pass: returns the offset of the first NUL in p[0 .. len) (len: none), bits |= the byte values in front of it */
+__attribute__((target("avx2"))) static size_t scan_block_avx2(const uint8_t *p, size_t len, uint32_t bits[8])
+{
+    uint8_t known[16];
+    int nk = 0;
+    bool many = false; /* more than 16 distinct letters: every block is walked byte by byte */
+    for (int c = 1; c < 256 && nk < 16; ++c)
+        if ((bits[c >> 5] >> (c & 31)) & 1u) known[nk++] = (uint8_t)c;
+    const __m256i zero = _mm256_setzero_si256();
+    size_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(p + i));
+        const uint32_t z = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, zero));
+        if (!z && !many) {
+            __m256i m = zero;
+            for (int q = 0; q < nk; ++q) m = _mm256_or_si256(m, _mm256_cmpeq_epi8(v, _mm256_set1_epi8((char)known[q])));
+            if ((uint32_t)_mm256_movemask_epi8(m) == 0xFFFFFFFFu) continue;
+        }
+        const int stop = z ? __builtin_ctz(z) : 32;
+        for (int e = 0; e < stop; ++e) {
+            const uint8_t b = p[i + e];
+            if (!((bits[b >> 5] >> (b & 31)) & 1u)) {
+                bits[b >> 5] |= 1u << (b & 31);
+                if (nk < 16) known[nk++] = b;
+                else many = true;
+            }
+        }
+        if (z) return i + (size_t)stop;
+    }
+    for (; i < len; ++i) {
+        if (!p[i]) return i;
+        bits[p[i] >> 5] |= 1u << (p[i] & 31);
+    }
+    return len;
+}
+#endif
+
+static size_t scan_block(const uint8_t *p, size_t len, uint32_t bits[8])
+{
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return scan_block_avx2(p, len, bits);
+#endif
+    const uint8_t *z = memchr(p, 0, len);
+    const size_t upto = z ? (size_t)(z - p) : len;
+    for (size_t i = 0; i < upto; ++i) bits[p[i] >> 5] |= 1u << (p[i] & 31);
+    return upto;
+}
+
+static void *scan_worker(void *arg)
+{
+    struct scan_job *j = arg;
+    for (;;) {
+        const size_t k = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (k >= j->nchunks || k > __atomic_load_n(&j->found, __ATOMIC_ACQUIRE)) break;
+        const uint8_t *p = j->s + k * SCAN_CHUNK;
+        const size_t len = j->limit - k * SCAN_CHUNK < SCAN_CHUNK ? j->limit - k * SCAN_CHUNK : SCAN_CHUNK;
+        uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const size_t upto = scan_block(p, len, bits);
+        j->end_in_chunk[k] = upto;
+        memcpy(j->letters[k], bits, 32);
+        if (upto < len) {
+            size_t cur = __atomic_load_n(&j->found, __ATOMIC_RELAXED);
+            while (k < cur && !__atomic_compare_exchange_n(&j->found, &cur, k, false, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {
+            }
+        }
+    }
+    return NULL;
+}
+
+/* strlen(string), and which byte values the string holds (present[256]; may be NULL); *have_letters says whether
+ * `present` was filled (short strings and unreadable maps leave that to the caller) */
+static size_t long_strlen(const uint8_t *string, bool *present, bool *have_letters)
+{
+    *have_letters = false;
+    const size_t head = strnlen((const char *)string, SCAN_CHUNK);
+    if (head < SCAN_CHUNK) return head;
+    const int nt = host_threads();
+    const size_t limit = nt > 1 ? readable_extent(string) : 0;
+    if (limit <= SCAN_CHUNK) return head + strlen((const char *)string + head);
+    struct scan_job j = {string, limit, (limit + SCAN_CHUNK - 1) / SCAN_CHUNK, 1, 0, NULL, NULL}; /* (chunk 0 holds no terminator) */
+    j.found = j.nchunks;
+    j.end_in_chunk = malloc(j.nchunks * sizeof *j.end_in_chunk);
+    j.letters = malloc(j.nchunks * sizeof *j.letters);
+    if (!j.end_in_chunk || !j.letters) {
+        free(j.end_in_chunk), free(j.letters);
+        return head + strlen((const char *)string + head);
+    }
+    pthread_t th[64];
+    int started = 0;
+    for (int t = 0; t < nt && t < 64; ++t)
+        if (pthread_create(&th[started], NULL, scan_worker, &j) == 0) ++started;
+    if (started == 0) scan_worker(&j);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    size_t n;
+    if (j.found >= j.nchunks) { /* no terminator inside the readable extent: cannot be; let strlen say (or fault) */
+        n = head + strlen((const char *)string + head);
+    } else {
+        n = j.found * SCAN_CHUNK + j.end_in_chunk[j.found];
+        if (present) {
+            uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)scan_block(string, SCAN_CHUNK, bits); /* chunk 0 (it holds no terminator) */
+            for (size_t k = 1; k <= j.found; ++k)
+                for (int w = 0; w < 8; ++w) bits[w] |= j.letters[k][w];
+            for (int c = 0; c < 256; ++c) present[c] = (bits[c >> 5] >> (c & 31)) & 1u;
+            *have_letters = true;
+        }
+    }
+    free(j.end_in_chunk);
+    free(j.letters);
+    return n;
+}
+
+/* long_strlen for the tests: the length, and present[c] = 1 for every byte value c the string holds (when the parallel scan
+ * supplied them: the return value's companion *have_letters) */
+size_t stralg_amd_strlen_and_letters(const uint8_t *string, uint8_t *present /* 256 */, int *have_letters)
+{
+    bool letters[256], have = false;
+    memset(letters, 0, sizeof letters);
+    const size_t n = long_strlen(string, letters, &have);
+    if (present)
+        for (int c = 0; c < 256; ++c) present[c] = have && letters[c];
+    if (have_letters) *have_letters = have;
+    return n;
+}
+
 /* alloc_remap_table + remap (remap.c:8-41,102-114) for a record of n letters, a few threads on the byte loops */
-static struct remap_table *remap_record(const uint8_t *string, size_t n, uint8_t *remapped)
+static struct remap_table *remap_record(const uint8_t *string, size_t n, uint8_t *remapped, const bool *letters /* or NULL */)
 {
     struct remap_table *table = malloc(sizeof *table);
     const int slices = slice_count(n);
@@ -543,9 +717,13 @@ static struct remap_table *remap_record(const uint8_t *string, size_t n, uint8_t
         return table;
     }
     struct presence_job *pj = calloc(1, sizeof *pj);
-    pj->string = string;
-    pj->per = (n + (size_t)slices - 1) / (size_t)slices; /* the slicing parallel_ranges uses */
-    parallel_ranges(n, presence_slice, pj);
+    if (letters) { /* (long_strlen has looked at every byte already) */
+        memcpy(pj->present[0], letters, 256);
+    } else {
+        pj->string = string;
+        pj->per = (n + (size_t)slices - 1) / (size_t)slices; /* the slicing parallel_ranges uses */
+        parallel_ranges(n, presence_slice, pj);
+    }
     memset(table->table, -1, sizeof table->table);
     memset(table->rev_table, -1, sizeof table->rev_table);
     table->table[0] = 0;
@@ -608,10 +786,11 @@ static int build_complete_table_try(const uint8_t *string, bool include_reverse,
     *out = NULL;
     const bool timing = getenv("STRALG_AMD_TIMING") != NULL;
     const double t0 = timing ? now_ms() : 0.0;
-    const size_t n = strlen((const char *)string);
+    bool letters[256], have_letters = false;
+    const size_t n = long_strlen(string, letters, &have_letters);
     uint8_t *remapped = big_alloc(n + 1);
     if (!remapped) return SX_E_NOMEM;
-    struct remap_table *remap_table = remap_record(string, n, remapped);
+    struct remap_table *remap_table = remap_record(string, n, remapped, have_letters ? letters : NULL);
     if (remap_table->alphabet_size > 128) {
         fprintf(stderr, "stralg_amd: build_complete_table: %u distinct letters; stralg's remap table holds "
                         "at most 127 (stralg/remap.h:14-18)\n", remap_table->alphabet_size - 1);
@@ -940,9 +1119,10 @@ static int stream_to_file(void *user, int section, const void *data, size_t byte
 
 int stralg_amd_write_complete_bwt_info_stream(FILE *f, const uint8_t *string, bool include_reverse)
 {
-    const size_t n = strlen((const char *)string);
+    bool letters[256], have_letters = false;
+    const size_t n = long_strlen(string, letters, &have_letters);
     uint8_t *remapped = malloc(n + 1);
-    struct remap_table *remap_table = remap_record(string, n, remapped); /* (a few threads for a long record) */
+    struct remap_table *remap_table = remap_record(string, n, remapped, have_letters ? letters : NULL); /* (a few threads for a long record) */
     if (remap_table->alphabet_size > 128) {
         free(remapped);
         free_remap_table(remap_table);

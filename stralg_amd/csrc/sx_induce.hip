@@ -2343,7 +2343,10 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         // with the longer queue.
         double expect = (double)region_entries * share;
         int by_share = 1;
-        while (by_share < kMaxSpec && expect > (double)(kTailMulti * kTailEntries) / 8.0) ++by_share, expect *= share;
+        // (unattended: half of what the tail kernel takes -- a round's size is a sum of independent draws, and one that is
+        //  too long after all is carried on attended; attended: an eighth, nobody queues one more)
+        const double tail_takes = (double)(kTailMulti * kTailEntries) / ((st.unattended && !resume) ? 2.0 : 8.0);
+        while (by_share < kMaxSpec && expect > tail_takes) ++by_share, expect *= share;
         if (st.unattended && !resume) spec = by_share;
         else if (by_share > spec) spec = by_share;
     }

@@ -227,3 +227,43 @@ def test_links_next_to_a_real_libstralg(product_lib, tmp_path):
              for m in re.finditer(r"binding file (\S+) \[\d+\] to (\S+) \[\d+\]: normal symbol `(\w+)'", log)
              if os.path.basename(m.group(1)) == "libstralg.so" and m.group(3) in guarded_names}
     assert inner and set(inner.values()) == {"libstralg_amd.so"}, inner
+
+
+def test_long_strlen_scans_only_what_is_mapped(product_lib):
+    import numpy as np
+    """build_complete_table's strlen of a long record: parallel over the readable extent of the string's mapping, never
+    a byte behind it.  A record that ends exactly at the end of its mapping, with an unreadable page behind (mmap +
+    mprotect), strings with the terminator in every position class, and the letters that come back."""
+    import ctypes as C
+    import mmap
+    lib = product_lib
+    lib.stralg_amd_strlen_and_letters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    lib.stralg_amd_strlen_and_letters.restype = C.c_size_t
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+    chunk = 4 << 20
+    rng = np.random.default_rng(2)
+    for n in (0, 5, chunk - 1, chunk, chunk + 1, 3 * chunk + 12345, 9 * chunk):
+        total = ((n + 1 + page - 1) // page + 1) * page  # the string, then one guard page
+        m = mmap.mmap(-1, total)
+        buf = (C.c_uint8 * total).from_buffer(m)
+        base = C.addressof(buf)
+        start = total - page - (n + 1)  # the terminator is the last byte in front of the guard page
+        arr = np.frombuffer(m, dtype=np.uint8)
+        letters = rng.choice(np.array([65, 67, 71, 84, 78, 200], dtype=np.uint8), size=4, replace=False)
+        arr[start:start + n] = rng.choice(letters, size=n) if n else []
+        arr[start + n] = 0
+        assert libc.mprotect(base + total - page, page, 0) == 0  # PROT_NONE: a read there is a fault
+        present = (C.c_uint8 * 256)()
+        have = C.c_int(-1)
+        got = lib.stralg_amd_strlen_and_letters(base + start, present, C.byref(have))
+        assert got == n, (n, got)
+        if n >= chunk:
+            assert have.value == 1
+            assert sorted(c for c in range(256) if present[c]) == sorted(set(arr[start:start + n].tolist())), n
+        else:
+            assert have.value == 0
+        libc.mprotect(base + total - page, page, 3)
+        del arr, buf
+        m.close()
