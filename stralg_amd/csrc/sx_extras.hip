@@ -131,6 +131,114 @@ __global__ __launch_bounds__(kBlock) void inverse_apply_kernel(const uint2 *__re
     }
 }
 
+// ---- round 4: three passes, the last one inside LDS ---------------------------------------------------------------
+// The second pass above still scatters 4-byte stores over a 2 MiB window: rocprofv3 counted 9.9 GB written for 1 GiB of
+// inverse entries -- the L2 hands the window's lines to memory partially filled.  A window whose entries fit a workgroup's
+// LDS has no such problem: its pairs are scattered into LDS and the window leaves as one contiguous block.  Such windows
+// (2^15 targets, 128 KiB) are too many to deal the array into at once -- a tile of 8192 entries would write one 8-byte
+// pair per window --, so the pairs of every coarse window (2^19 targets, pass 1 as above) are dealt into its 16 fine
+// windows first (a pass that stays inside 4 MiB: 512-pair runs), and the fine windows are turned into inverse entries by
+// a workgroup each.  10 GiB moved instead of 14, every store a full line.
+#ifndef SX_INV_FINE_BITS
+#define SX_INV_FINE_BITS 15 // (the CPU test harness builds with 6)
+#endif
+constexpr uint32_t kInvFineBits = SX_INV_FINE_BITS, kInvFineMax = 4096; // fine windows per coarse window: at most this many
+__global__ __launch_bounds__(kInvThreads) void inverse_refine_kernel(const uint2 *__restrict__ pairs, uint64_t N, uint32_t wbits,
+                                                                      uint32_t *__restrict__ fine_cursor, uint2 *__restrict__ pairs2,
+                                                                      uint32_t *__restrict__ bad)
+{
+    __shared__ uint32_t cnt[kInvFineMax];
+    if (*bad) return; // (the first pass found that the array is no permutation: its pairs have holes)
+    const uint32_t t = threadIdx.x;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * kInvTile; tile0 < N; tile0 += (uint64_t)gridDim.x * kInvTile) { // uniform
+        // (a permutation fills every coarse window exactly, so the tile's pairs belong to the coarse windows its positions
+        //  lie in: one of them at the production sizes, several in the CPU test harness's small windows)
+        const uint64_t tile1 = tile0 + kInvTile < N ? tile0 + kInvTile : N;
+        const uint32_t fine0 = (uint32_t)((tile0 >> wbits) << (wbits - kInvFineBits));
+        const uint32_t F = (uint32_t)((((tile1 - 1) >> wbits) + 1) << (wbits - kInvFineBits)) - fine0;
+        for (uint32_t q = t; q < F; q += kInvThreads) cnt[q] = 0;
+        __syncthreads();
+        uint2 e[kInvItems];
+        uint32_t r[kInvItems];
+#pragma unroll
+        for (int k = 0; k < kInvItems; ++k) {
+            const uint64_t i = tile0 + (uint64_t)k * kInvThreads + t;
+            e[k].x = 0xFFFFFFFFu, e[k].y = 0;
+            if (i < N) {
+                const uint64_t raw = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pairs) + i);
+                e[k].x = (uint32_t)raw, e[k].y = (uint32_t)(raw >> 32);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kInvItems; ++k) {
+            const uint64_t i = tile0 + (uint64_t)k * kInvThreads + t;
+            r[k] = 0;
+            if (i < N) {
+                const uint32_t f = (e[k].x >> kInvFineBits) - fine0;
+                if ((uint64_t)e[k].x < N && f < F) r[k] = atomicAdd(&cnt[f], 1u);
+                else atomicAdd(bad, 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t q = t; q < F; q += kInvThreads) {
+            const uint32_t c = cnt[q];
+            if (c) {
+                const uint32_t at = atomicAdd(&fine_cursor[fine0 + q], c);
+                const uint64_t first = (uint64_t)(fine0 + q) << kInvFineBits;
+                const uint64_t room = first >= N ? 0 : (N - first < (1ull << kInvFineBits) ? N - first : (1ull << kInvFineBits));
+                if ((uint64_t)at + c > room) {
+                    atomicAdd(bad, 1u);
+                    cnt[q] = 0xFFFFFFFFu;
+                } else {
+                    cnt[q] = (uint32_t)first + at;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kInvItems; ++k) {
+            const uint64_t i = tile0 + (uint64_t)k * kInvThreads + t;
+            if (i < N && (uint64_t)e[k].x < N) {
+                const uint32_t f = (e[k].x >> kInvFineBits) - fine0;
+                if (f < F) {
+                    const uint32_t base = cnt[f];
+                    if (base != 0xFFFFFFFFu) pairs2[(uint64_t)base + r[k]] = e[k];
+                }
+            }
+        }
+        __syncthreads(); // `cnt` is zeroed for the next tile
+    }
+}
+
+// workgroup = fine window: its pairs into LDS by target, the window out as one block
+constexpr int kInvWinThreads = 1024;
+__global__ __launch_bounds__(kInvWinThreads) void inverse_window_kernel(const uint2 *__restrict__ pairs2, uint64_t N,
+                                                                        uint32_t *__restrict__ inv, const uint32_t *__restrict__ bad)
+{
+    __shared__ uint32_t w[1u << kInvFineBits];
+    if (*bad) return; // (not a permutation: some window's pairs have holes; the caller reports it)
+    constexpr uint32_t kWin = 1u << kInvFineBits;
+    for (uint64_t f = blockIdx.x; (f << kInvFineBits) < N; f += gridDim.x) { // uniform
+        const uint64_t first = f << kInvFineBits;
+        const uint32_t n_f = N - first < kWin ? (uint32_t)(N - first) : kWin;
+        for (uint32_t i = threadIdx.x; i < n_f; i += kInvWinThreads) {
+            const uint64_t raw = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pairs2) + first + i);
+            w[(uint32_t)raw & (kWin - 1u)] = (uint32_t)(raw >> 32);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x * 4u; i < n_f; i += kInvWinThreads * 4u) {
+            if (i + 4u <= n_f && ((uintptr_t)(inv + first) & 15u) == 0) {
+                uint4 v;
+                v.x = w[i], v.y = w[i + 1], v.z = w[i + 2], v.w = w[i + 3];
+                *reinterpret_cast<uint4 *>(inv + first + i) = v;
+            } else {
+                for (uint32_t e = i; e < n_f && e < i + 4u; ++e) inv[first + e] = w[e];
+            }
+        }
+        __syncthreads(); // `w` is refilled by the next window
+    }
+}
+
 constexpr int kLcpChunk = 64;
 
 // length of the common prefix of text[a..] and text[b..], starting the comparison at offset l
@@ -284,10 +392,33 @@ static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *
     uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
     SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
     if (sx_scatter_permutation_applies(N)) {
-        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, N * sizeof(uint2) + (size_t)kInvMaxParts * 4 + 512));
-        uint32_t *cursor = (uint32_t *)ctx->slab[SX_SLAB_SORT].p;
-        void *pairs = (char *)ctx->slab[SX_SLAB_SORT].p + (size_t)kInvMaxParts * 4 + 256;
-        SX_TRY(sx_scatter_permutation(ctx, d_sa, nullptr, N, d_inv, pairs, cursor, bad, SX_KC_LCP));
+        // three passes: coarse windows, their fine windows, the fine windows through LDS (above)
+        uint32_t wbits = kInvWindowBits;
+        while (((N + (1ull << wbits) - 1) >> wbits) > kInvMaxParts) ++wbits;
+        const uint32_t nparts = (uint32_t)((N + (1ull << wbits) - 1) >> wbits);
+        const uint64_t nfine = (N + (1ull << kInvFineBits) - 1) >> kInvFineBits;
+        const size_t pairs_b = (N * sizeof(uint2) + 255) & ~(size_t)255, cur_b = ((size_t)kInvMaxParts * 4 + 255) & ~(size_t)255,
+                     fine_b = ((size_t)nfine * 4 + 255) & ~(size_t)255;
+        SX_TRY(sx_slab_ensure(ctx, SX_SLAB_SORT, 2 * pairs_b + cur_b + fine_b + 512));
+        char *base = (char *)ctx->slab[SX_SLAB_SORT].p;
+        uint32_t *cursor = (uint32_t *)base, *fine_cursor = (uint32_t *)(base + cur_b);
+        uint2 *pairs = (uint2 *)(base + cur_b + fine_b), *pairs2 = (uint2 *)(base + cur_b + fine_b + pairs_b);
+        // (the fine windows a tile's pairs can fall into must fit the refine kernel's counters)
+        if (wbits >= kInvFineBits && ((((uint64_t)kInvTile >> wbits) + 2) << (wbits - kInvFineBits)) <= kInvFineMax) {
+            SX_CHECK(hipMemsetAsync(cursor, 0, (size_t)nparts * 4, ctx->stream));
+            SX_CHECK(hipMemsetAsync(fine_cursor, 0, (size_t)nfine * 4, ctx->stream));
+            uint32_t grid = sx_div_up(N, kInvTile);
+            if (grid > 4096) grid = 4096;
+            sx_launch(ctx, SX_KC_LCP, N * 12, inverse_partition_kernel, dim3(grid), dim3(kInvThreads), d_sa, (const uint32_t *)nullptr, N, nparts,
+                      wbits, cursor, pairs, bad);
+            sx_launch(ctx, SX_KC_LCP, N * 16, inverse_refine_kernel, dim3(grid), dim3(kInvThreads), (const uint2 *)pairs, N, wbits, fine_cursor,
+                      pairs2, bad);
+            uint32_t wgrid = (uint32_t)(nfine < 65536 ? nfine : 65536);
+            sx_launch(ctx, SX_KC_LCP, N * 12, inverse_window_kernel, dim3(wgrid), dim3(kInvWinThreads), (const uint2 *)pairs2, N, d_inv,
+                      (const uint32_t *)bad);
+        } else {
+            SX_TRY(sx_scatter_permutation(ctx, d_sa, nullptr, N, d_inv, pairs, cursor, bad, SX_KC_LCP));
+        }
     } else {
         sx_launch(ctx, SX_KC_LCP, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
     }

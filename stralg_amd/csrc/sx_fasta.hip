@@ -101,25 +101,66 @@ __device__ __forceinline__ fa_chunk fasta_walk(const uint32_t (&b)[kFaPer], uint
     return r;
 }
 
-// also finds the first NUL byte (the reference reads a C string: io.c:15-18).  The tiles behind it are never used,
-// and the tile that holds it recomputes its states with the right end in the later passes, so `end` may still be
-// the file's length here.
-__global__ __launch_bounds__(kBlock) void fasta_tile_last_kernel(const uint8_t *__restrict__ file, uint64_t end,
-                                                                 uint32_t *__restrict__ tile_last,
-                                                                 uint32_t *__restrict__ first_nul)
+// Pass 1 of 2 (round 4: it was two passes): the last '\n' / '>' of every tile (for the max-scan that gives each tile its
+// entry state), the first NUL byte (the reference reads a C string: io.c:15-18), the first '\n' of the image (where the
+// first header line ends: the image starts in header state and a '>' keeps it there) -- and what the tile emits.  A
+// thread's state is the kind of the last special byte before it; only the threads in front of the tile's first special
+// byte -- four of them in a file of 60-column lines -- depend on the state the tile is entered in, and those are walked
+// under both: tile_cnt[0] = what the other threads emit, [1] / [2] = what those threads add when the tile is entered in
+// sequence / in header state (each: bytes emitted | terminators << 16).  The tile that holds the NUL counts up to it;
+// the tiles behind it are never used.
+__global__ __launch_bounds__(kBlock) void fasta_scan_kernel(const uint8_t *__restrict__ file, uint64_t end,
+                                                            uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_cnt /* [3][tiles] */,
+                                                            uint32_t tiles_stride, uint32_t *__restrict__ scal /* [0] first NUL, [2] first newline */)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
     uint32_t b[kFaPer];
     fasta_load16(file, i0, end, b);
-    uint32_t zero_at = kFaPer;
+    uint32_t zero_at = kFaPer, nl_at = kFaPer;
 #pragma unroll
-    for (int k = kFaPer - 1; k >= 0; --k)
+    for (int k = kFaPer - 1; k >= 0; --k) {
         if (b[k] == 0 && i0 + k < end) zero_at = (uint32_t)k;
-    if (zero_at < (uint32_t)kFaPer) atomicMin(first_nul, (uint32_t)(i0 + zero_at));
-    const uint32_t tot = block_reduce<OpMax>(fasta_last_special(b, i0, end), lds);
-    if (threadIdx.x == 0) tile_last[blockIdx.x] = tot;
+        if (b[k] == '\n' && i0 + k < end) nl_at = (uint32_t)k;
+    }
+    // the tile's first NUL ends the image for every thread of the tile (a NUL in an earlier tile: this tile is never used)
+    const uint32_t my_nul = zero_at < (uint32_t)kFaPer ? (uint32_t)(i0 + zero_at) : 0xFFFFFFFFu;
+    const uint32_t tile_nul = ~block_reduce<OpMax>(~my_nul, lds); // min as a max of complements
+    if (threadIdx.x == 0 && tile_nul != 0xFFFFFFFFu) atomicMin(&scal[0], tile_nul);
+    const uint64_t end_l = tile_nul < end ? (uint64_t)tile_nul : end;
+    if (nl_at < (uint32_t)kFaPer && i0 + nl_at < end_l) atomicMin(&scal[2], (uint32_t)(i0 + nl_at));
+    uint32_t tot_last;
+    const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(b, i0, end_l), lds, tot_last);
+    const bool known = before != 0;
+    const fa_chunk c = fasta_walk(b, i0, end_l, known ? (before & 1u) != 0 : true);
+    const uint32_t mine = (uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16);
+    uint32_t other = 0;
+    if (!known) { // (the first threads of the tile only)
+        const fa_chunk h = fasta_walk(b, i0, end_l, false);
+        other = (uint32_t)__popc(h.emit) | ((uint32_t)__popc(h.term) << 16);
+    }
+    const uint32_t s_known = block_reduce<OpAdd>(known ? mine : 0u, lds);
+    const uint32_t s_seq = block_reduce<OpAdd>(known ? 0u : mine, lds);
+    const uint32_t s_hdr = block_reduce<OpAdd>(other, lds);
+    if (threadIdx.x == 0) {
+        tile_last[blockIdx.x] = tot_last;
+        tile_cnt[blockIdx.x] = s_known;
+        tile_cnt[(uint64_t)tiles_stride + blockIdx.x] = s_seq;
+        tile_cnt[2ull * tiles_stride + blockIdx.x] = s_hdr;
+    }
 }
+
+// what tile i emits, now that its entry state is known (the max-scan's carry): bytes (shift 0) or terminators (shift 16)
+struct InFaTileCount {
+    const uint32_t *cnt, *carry;
+    uint32_t stride, shift;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        const uint32_t last = carry[i];
+        const bool in_seq = last != 0 && (last & 1u);
+        return ((cnt[i] + cnt[(in_seq ? (uint64_t)stride : 2ull * stride) + i]) >> shift) & 0xFFFFu;
+    }
+};
 
 // state of every thread's first byte = kind of the last special byte before it (none: header)
 __device__ __forceinline__ bool fasta_enter_state(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end, uint32_t tile_carry,
@@ -131,54 +172,54 @@ __device__ __forceinline__ bool fasta_enter_state(const uint32_t (&b)[kFaPer], u
     return last != 0 && (last & 1u);
 }
 
-__global__ __launch_bounds__(kBlock) void fasta_count_kernel(const uint8_t *__restrict__ file, uint64_t end,
+// Pass 2: the walk again, now in the right state, and the packed image.  The tile's output is staged in LDS at the
+// offset its first byte has inside a 16-byte piece of the destination, so that whole pieces leave as aligned 16-byte
+// stores; only the two pieces the tile shares with its neighbours go byte by byte.  (A byte store per emitted byte,
+// 16 store instructions a thread, each touching 64 lines: 1.6 ms per GiB, more than the two reading passes together.)
+__global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__restrict__ file, uint64_t end,
                                                              const uint32_t *__restrict__ tile_carry,
-                                                             uint32_t *__restrict__ tile_emit, uint32_t *__restrict__ tile_term,
-                                                             uint32_t *__restrict__ scal /* [1] malformed, [2] first header end */)
+                                                             const uint32_t *__restrict__ tile_eoff,
+                                                             const uint32_t *__restrict__ tile_toff, uint8_t *__restrict__ packed,
+                                                             uint32_t *__restrict__ term_out, uint64_t term_cap,
+                                                             uint32_t *__restrict__ scal /* [1] <- malformed; [2] first header end -> [0] its packed position */)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kFaTile + 48];
     const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
     uint32_t b[kFaPer];
     fasta_load16(file, i0, end, b);
     const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[blockIdx.x], lds);
     const fa_chunk c = fasta_walk(b, i0, end, in_seq);
     if (c.eof_in_name) atomicOr(&scal[1], 1u);
-    if (c.name_end) atomicMin(&scal[2], (uint32_t)(i0 + (uint32_t)(__ffs(c.name_end) - 1)));
-    const uint32_t tot = block_reduce<OpAdd>((uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16), lds);
-    if (threadIdx.x == 0) {
-        tile_emit[blockIdx.x] = tot & 0xFFFFu;
-        tile_term[blockIdx.x] = tot >> 16;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__restrict__ file, uint64_t end,
-                                                             const uint32_t *__restrict__ tile_carry,
-                                                             const uint32_t *__restrict__ tile_eoff,
-                                                             const uint32_t *__restrict__ tile_toff, uint8_t *__restrict__ packed,
-                                                             uint32_t *__restrict__ term_out, uint64_t term_cap,
-                                                             uint32_t *__restrict__ scal /* [2] first header end -> [0] its packed position */)
-{
-    __shared__ uint32_t lds[kWavesPerBlock];
-    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
-    uint32_t b[kFaPer];
-    fasta_load16(file, i0, end, b);
-    const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[blockIdx.x], lds);
-    const fa_chunk c = fasta_walk(b, i0, end, in_seq);
     uint32_t tot;
     const uint32_t ex = block_exclusive_scan<OpAdd>((uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16), lds, tot);
-    uint32_t out = tile_eoff[blockIdx.x] + (ex & 0xFFFFu), tq = tile_toff[blockIdx.x] + (ex >> 16);
+    const uint32_t eoff = tile_eoff[blockIdx.x];
+    const uint32_t sh = (uint32_t)((uintptr_t)(packed + eoff) & 15u); // the tile's first byte inside its 16-byte piece
+    uint32_t at = sh + (ex & 0xFFFFu), out = eoff + (ex & 0xFFFFu), tq = tile_toff[blockIdx.x] + (ex >> 16);
     const uint32_t first_end = scal[2];
 #pragma unroll
     for (int k = 0; k < kFaPer; ++k) {
         if ((c.emit >> k) & 1u) {
             const bool is_term = (c.term >> k) & 1u;
-            packed[out] = is_term ? (uint8_t)0 : (uint8_t)b[k];
+            stage[at] = is_term ? (uint8_t)0 : (uint8_t)b[k];
             if (is_term) {
                 if (term_out && tq < term_cap) term_out[tq] = out;
                 ++tq;
                 if (((c.name_end >> k) & 1u) && (uint32_t)(i0 + k) == first_end) scal[0] = out;
             }
+            ++at;
             ++out;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = tot & 0xFFFFu, last = sh + total; // staged bytes: [sh, last)
+    uint8_t *dst = packed + eoff - sh;                        // 16-byte aligned
+    for (uint32_t q = threadIdx.x; q * 16u < last; q += kBlock) {
+        const uint32_t lo = q * 16u, hi = lo + 16u;
+        if (lo >= sh && hi <= last) {
+            *reinterpret_cast<uint4 *>(dst + lo) = *reinterpret_cast<const uint4 *>(stage + lo);
+        } else {
+            for (uint32_t e = lo < sh ? sh : lo; e < hi && e < last; ++e) dst[e] = stage[e];
         }
     }
 }
@@ -271,37 +312,43 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
     SX_CHECK(hipSetDevice(ctx->device));
     *packed_len_out = 0;
     *n_records_out = 0;
-    // scratch: four scalars and five u32 per 4096-byte tile
+    // scratch: a few scalars and eight u32 per 4096-byte tile
     const uint64_t span_max = file_len + 1;
     const uint32_t tiles_max = sx_div_up(span_max, kFaTile);
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, 256 + (size_t)5 * tiles_max * sizeof(uint32_t) + 1024));
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, 256 + (size_t)8 * tiles_max * sizeof(uint32_t) + 1024));
     uint32_t *scal = (uint32_t *)ctx->slab[SX_SLAB_N].p; // [0] first NUL / packed position, [1] malformed, [2] first header end
-    uint32_t *tile_last = scal + 64, *tile_carry = tile_last + tiles_max, *tile_emit = tile_carry + tiles_max,
-             *tile_term = tile_emit + tiles_max, *tile_eoff = tile_term + tiles_max;
+    uint32_t *tile_last = scal + 64, *tile_carry = tile_last + tiles_max, *tile_cnt = tile_carry + tiles_max,
+             *tile_eoff = tile_cnt + 3 * (size_t)tiles_max, *tile_toff = tile_eoff + tiles_max;
     const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
     SX_CHECK(hipMemcpyAsync(scal, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    // pass 1 over the whole image: last '\n' / '>' of every tile, and the first NUL (which ends the image)
+    // pass 1 over the whole image: last '\n' / '>' of every tile, the first NUL (which ends the image), the first newline,
+    // and every tile's emitted bytes and terminators for either entry state
     uint32_t first_nul = 0xFFFFFFFFu;
+    const uint32_t tiles_file = sx_div_up(file_len ? file_len : 1, kFaTile);
     if (file_len) {
-        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_tile_last_kernel, dim3(sx_div_up(file_len, kFaTile)), dim3(kBlock), d_file,
-                  file_len, tile_last, scal);
+        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_scan_kernel, dim3(tiles_file), dim3(kBlock), d_file, file_len, tile_last, tile_cnt,
+                  tiles_max, scal);
         SX_TRY(sx_readback(ctx, scal, 1, &first_nul));
     }
     const uint64_t end = first_nul < file_len ? first_nul : file_len;
     const uint64_t span = end + 1; // with the terminating NUL of the reference's buffer
     const uint32_t tiles = sx_div_up(span, kFaTile);
     const dim3 grid(tiles), block(kBlock);
-    if (tiles > sx_div_up(file_len, kFaTile)) // (the span's last tile lies behind the image: it holds the terminator only)
-        SX_CHECK(hipMemsetAsync(tile_last + tiles - 1, 0, sizeof(uint32_t), ctx->stream));
-    // (the last tile's entry is never used -- the scan below is exclusive --, so the tile that holds the NUL needs no
-    //  second look although it saw the bytes behind it)
+    if (!file_len || tiles > tiles_file) {
+        // the span's last tile lies behind the image: it holds the terminator of the reference's buffer only -- a sequence's
+        // terminator when the tile is entered in sequence state, nothing to emit in a header (MALFORMED, found by pass 2)
+        const uint32_t t = tiles - 1;
+        const uint32_t zero = 0, seq_term = 1u | (1u << 16);
+        SX_CHECK(hipMemcpyAsync(tile_last + t, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        SX_CHECK(hipMemcpyAsync(tile_cnt + t, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        SX_CHECK(hipMemcpyAsync(tile_cnt + (size_t)tiles_max + t, &seq_term, 4, hipMemcpyHostToDevice, ctx->stream));
+        SX_CHECK(hipMemcpyAsync(tile_cnt + 2 * (size_t)tiles_max + t, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // (the last tile's own entry is never used by the exclusive scan, so the tile that holds the NUL needs no second look
+    //  although its last-special word saw the bytes behind the NUL too -- it did not: the scan kernel ends a tile at its NUL)
     SX_TRY((device_scan<OpMax>(ctx, tiles, InU32{tile_last}, OutExclusive{tile_carry}, nullptr, SX_KC_FASTA, 0)));
-    sx_launch(ctx, SX_KC_FASTA, span, fasta_count_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry, tile_emit,
-              tile_term, scal);
-    // (tile_last is free again: the terminator offsets go there)
-    uint32_t *tile_toff = tile_last;
-    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_emit}, OutExclusive{tile_eoff}, scal + 3, SX_KC_FASTA, 0)));
-    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_term}, OutExclusive{tile_toff}, scal + 4, SX_KC_FASTA, 0)));
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InFaTileCount{tile_cnt, tile_carry, tiles_max, 0u}, OutExclusive{tile_eoff}, scal + 3, SX_KC_FASTA, 0)));
+    SX_TRY((device_scan<OpAdd>(ctx, tiles, InFaTileCount{tile_cnt, tile_carry, tiles_max, 16u}, OutExclusive{tile_toff}, scal + 4, SX_KC_FASTA, 0)));
     sx_launch(ctx, SX_KC_FASTA, span * 2, fasta_write_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry,
               (const uint32_t *)tile_eoff, (const uint32_t *)tile_toff, d_packed_out, d_term_out, d_term_out ? term_cap : 0, scal);
     uint32_t h[5];

@@ -315,7 +315,8 @@ def test_inverse_of_a_non_permutation_stays_inside(emu_ctx):
     x = synth(9000, 5, 77)
     emu_ctx.sa_build(x, 5)  # leaves sort keys (large words) in the slab the pairs are staged in
     sa = oracle.sa_is(x, 5)
-    for src, dst in ((10, 8000), (8000, 10)):  # (windows of 256 targets in the harness)
+    # (windows of 256 targets in the harness, their fine windows of 64: the last pair overflows a fine window only)
+    for src, dst in ((10, 8000), (8000, 10), (10, 200)):
         bad = sa.copy()
         bad[np.flatnonzero(sa == dst)[0]] = src  # value `src` twice, `dst` never: one window overflows, one has a slot left
         with pytest.raises(StralgAmdError):
