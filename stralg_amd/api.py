@@ -249,6 +249,11 @@ class Context:
         front, placed by the text's bigram counts (default), or by launches of each bucket's own (rounds 1 - 3)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 13, 0 if on else 1), "sx_ctx_set_flag")
 
+    def set_text_keys(self, on=True):
+        """SX_FLAG_TEXT_KEYS_OFF: the direct sort's first radix pass computes its keys from the text (default) or reads
+        them from a key kernel's output (rounds 1 - 3)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 14, 0 if on else 1), "sx_ctx_set_flag")
+
     def set_recurse_min(self, symbols):
         """SX_FLAG_RECURSE_MIN: reduced strings of at most 255 names recurse from this length on (negative: default)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 11, int(symbols)), "sx_ctx_set_flag")

@@ -181,6 +181,7 @@ int sx_child_begin(sx_ctx *ctx, sx_ctx **out)
     c->induce_batch_min = ctx->induce_batch_min;
     c->induce_attended = ctx->induce_attended;
     c->induce_no_hoist = ctx->induce_no_hoist;
+    c->text_keys_off = ctx->text_keys_off;
     c->copy_text_first = ctx->copy_text_first;
     c->recurse_min = ctx->recurse_min;
     c->sample_min = ctx->sample_min;
@@ -338,6 +339,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     if (flag == SX_FLAG_INDUCE_ATTENDED) {
         if (value < 0 || value > 2) return SX_E_ARG;
         ctx->induce_attended = value == 1 ? 1 : 0; // (2: what 0 is now)
+        return 0;
+    }
+    if (flag == SX_FLAG_TEXT_KEYS_OFF) {
+        ctx->text_keys_off = value ? 1 : 0;
         return 0;
     }
     if (flag == SX_FLAG_INDUCE_NO_HOIST) {

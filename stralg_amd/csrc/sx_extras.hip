@@ -221,9 +221,20 @@ __global__ __launch_bounds__(kInvWinThreads) void inverse_window_kernel(const ui
     for (uint64_t f = blockIdx.x; (f << kInvFineBits) < N; f += gridDim.x) { // uniform
         const uint64_t first = f << kInvFineBits;
         const uint32_t n_f = N - first < kWin ? (uint32_t)(N - first) : kWin;
-        for (uint32_t i = threadIdx.x; i < n_f; i += kInvWinThreads) {
-            const uint64_t raw = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pairs2) + first + i);
-            w[(uint32_t)raw & (kWin - 1u)] = (uint32_t)(raw >> 32);
+        // (eight loads of a thread in flight together: with a load and its LDS store in one loop body a window's 32 768 pairs
+        //  were 32 trips to memory one after the other, and a workgroup of this size is alone on its CU)
+        for (uint32_t i0 = 0; i0 < n_f; i0 += kInvWinThreads * 8u) { // uniform
+            uint64_t raw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = i0 + (uint32_t)j * kInvWinThreads + threadIdx.x;
+                raw[j] = i < n_f ? __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pairs2) + first + i) : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = i0 + (uint32_t)j * kInvWinThreads + threadIdx.x;
+                if (i < n_f) w[(uint32_t)raw[j] & (kWin - 1u)] = (uint32_t)(raw[j] >> 32);
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x * 4u; i < n_f; i += kInvWinThreads * 4u) {

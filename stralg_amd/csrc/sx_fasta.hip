@@ -128,7 +128,11 @@ __global__ __launch_bounds__(kBlock) void fasta_scan_kernel(const uint8_t *__res
     const uint32_t tile_nul = ~block_reduce<OpMax>(~my_nul, lds); // min as a max of complements
     if (threadIdx.x == 0 && tile_nul != 0xFFFFFFFFu) atomicMin(&scal[0], tile_nul);
     const uint64_t end_l = tile_nul < end ? (uint64_t)tile_nul : end;
-    if (nl_at < (uint32_t)kFaPer && i0 + nl_at < end_l) atomicMin(&scal[2], (uint32_t)(i0 + nl_at));
+    // (only a newline in front of the first one known so far is reported: one atomic a newline -- 18 million on one word for
+    //  1 GiB of 60-column lines -- took 10 ms; after the image's first tiles have run, no thread has one to report)
+    if (nl_at < (uint32_t)kFaPer && i0 + nl_at < end_l &&
+        (uint32_t)(i0 + nl_at) < __hip_atomic_load(&scal[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(&scal[2], (uint32_t)(i0 + nl_at));
     uint32_t tot_last;
     const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(b, i0, end_l), lds, tot_last);
     const bool known = before != 0;

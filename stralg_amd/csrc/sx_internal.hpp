@@ -3,9 +3,20 @@
 #include "sx_common.hpp"
 
 // ---- sx_radix.hip
+// Keys that are a function of the text: pair i of a sort of ALL suffixes has the key of text[i .. i + C) in base `base`
+// (most significant symbol first) and, with wnd, the symbol in front of position i as a one-symbol window above bit
+// kbits (sx_window.hpp).  A sort given such a description computes the keys in its first pass instead of reading them
+// (the direct sort of wide alphabets: no key kernel, no 8 bytes a suffix written and read back).
+struct sx_textkey {
+    const uint8_t *T; // the build's padded copy of the text (readable 16 bytes beyond any position)
+    uint32_t base, C; // C <= 12
+    uint32_t pow3, powR; // base^3, base^(C mod 3)
+    uint32_t kbits, wnd;
+};
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
                   int begin_bit, int end_bit, int *result_in_b, bool values_are_indices = false,
-                  bool first_digits_ready = false, int digit_bits = 0 /* 8, 9, 10; 0: the context's choice */);
+                  bool first_digits_ready = false, int digit_bits = 0 /* 8, 9, 10; 0: the context's choice */,
+                  const sx_textkey *text_keys = nullptr /* the first pass computes the keys (ka is not read; values = indices) */);
 // where the key generator of a sort of n pairs may leave the first pass's digit of every key
 // ((key >> begin_bit) & (2^digit_bits - 1); one byte each for 8-bit digits, two for wider ones): the first
 // histogram then reads these instead of the keys (first_digits_ready)

@@ -1315,7 +1315,16 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         const bool hybrid = top_bits != 0;
         const uint32_t dig_shift = hybrid ? (uint32_t)(kbits - top_bits) : 0u;
         const uint32_t dig_mask = kbits - (int)dig_shift >= 8 ? 0xFFu : (1u << (kbits - (int)dig_shift)) - 1u;
-        if (all_suffixes && C <= 12) {
+        // The direct sort's keys are a function of the text alone, so where the hybrid sort applies its first HBM pass computes
+        // them itself (sx_textkey, sx_radix.hip): no key kernel, and 8 bytes a suffix that are neither written nor read back
+        // (1 GiB of bytes: 2.4 ms of key kernel and 7.5 GB of the first scatter's reads).  Switch for the A/B and the
+        // tests: SX_FLAG_TEXT_KEYS_OFF keeps the key kernel.
+        const bool text_keyed = all_suffixes && C <= 12 && hybrid && sort_db == 8 && !ctx->text_keys_off;
+        sx_textkey tkey = {ti.T, base, C, 1u, 1u, (uint32_t)kbits, wcfg.CW ? 1u : 0u};
+        for (uint32_t i = 0; i < 3; ++i) tkey.pow3 *= base;
+        for (uint32_t i = 0; i < C % 3; ++i) tkey.powR *= base;
+        if (text_keyed) {
+        } else if (all_suffixes && C <= 12) {
             const pkey_cfg kc = pkey_make(base, C);
             const dim3 grid16(sx_div_up(m, kBlock * 16));
 #define SX_KEYS16(G) sx_launch(ctx, SX_KC_KEYS, m * 10, all_keys16_kernel<G>, grid16, block, ti.T, m, kc, (uint32_t)kbits, wcfg, ka, dig0, dig_shift, dig_mask)
@@ -1361,7 +1370,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         bool listed = false; // the members of groups of equal keys are in (apos, ap, head), A of them
         if (hybrid) {
             // three stable passes on the top 24 bits, then the sub-buckets in LDS: positions, windows and ties in one go
-            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - top_bits, kbits, &in_b, all_suffixes, true, 8));
+            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - top_bits, kbits, &in_b, all_suffixes, true, 8, text_keyed ? &tkey : nullptr));
             const uint64_t *kin = in_b ? kb : ka;
             const uint32_t *vin = in_b ? vb : va;
             uint32_t *vo = in_b ? va : vb;

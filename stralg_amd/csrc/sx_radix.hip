@@ -88,6 +88,68 @@ __global__ __launch_bounds__(kHT) void radix_hist_kernel(const uint64_t *__restr
     for (int i = (int)threadIdx.x; i < ND; i += kHT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
 }
 
+// key of position p of a text-keyed sort (sx_textkey): the value all_keys16_kernel (sx_lmssort.hip) would have stored
+__device__ __forceinline__ uint64_t textkey_at(const sx_textkey &tk, uint64_t p)
+{
+    uint64_t q0, q1;
+    load_bytes16(tk.T, p, q0, q1);
+    uint64_t acc;
+    if (tk.base == 256u) { // (uniform) bytes: the first C of them as a big-endian number
+        acc = tk.C <= 8u ? __builtin_bswap64(q0) >> (64u - 8u * tk.C)
+                         : (__builtin_bswap64(q0) << (8u * (tk.C - 8u))) | (__builtin_bswap64(q1) >> (64u - 8u * (tk.C - 8u)));
+    } else { // Horner, three symbols at a time (base^3 <= 2^24: 24-bit multiply-adds; the accumulator once a group)
+        acc = 0;
+        uint32_t g = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < 12; ++s) {
+            if (s < tk.C) { // uniform
+                g = __umul24(g, tk.base) + (uint32_t)(((s < 8 ? q0 : q1) >> (8u * (s & 7u))) & 0xFFull);
+                if (s % 3 == 2) { // static
+                    acc = acc * tk.pow3 + g;
+                    g = 0;
+                }
+            }
+        }
+        if (tk.C % 3u) acc = acc * tk.powR + g; // uniform
+    }
+    if (tk.wnd && p) { // the symbol in front of the suffix as a one-symbol window (it becomes the BWT)
+        const uint32_t before = tk.T[p - 1];
+        if (before) acc |= (uint64_t)(((before - 1u) << 4) | 1u) << tk.kbits;
+    }
+    return acc;
+}
+
+template <int DB>
+__global__ __launch_bounds__(kHT) void radix_hist_text_kernel(sx_textkey tk, uint64_t n, int shift, uint32_t mask,
+                                                              uint32_t *__restrict__ hist, uint32_t ntiles)
+{
+    constexpr int ND = 1 << DB;
+    __shared__ uint32_t h[ND];
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // (workgroups walk over their tiles)
+        for (int i = (int)threadIdx.x; i < ND; i += kHT) h[i] = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)tile * kRadixTile;
+        // bytes whose digit is a whole byte of the key: that byte of the text, no key to compute
+        const bool byte_digit = tk.base == 256u && (shift & 7) == 0 && mask == 0xFFu && shift < (int)(8u * tk.C);
+        const uint32_t byte_at = byte_digit ? tk.C - 1u - (uint32_t)(shift >> 3) : 0u;
+#pragma unroll
+        for (int k = 0; k < kHI; ++k) {
+            const uint64_t i = base + (uint64_t)k * kHT + threadIdx.x;
+            uint32_t d = 0;
+            if (i < n) d = byte_digit ? (uint32_t)tk.T[i + byte_at] : (uint32_t)(textkey_at(tk, i) >> shift) & mask;
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            if (__all((i < n && d == lead) ? 1 : 0)) {
+                if (lane_id() == 0) atomicAdd(&h[d], (uint32_t)kWave);
+            } else if (i < n) {
+                atomicAdd(&h[d], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < ND; i += kHT) hist[(uint64_t)tile * ND + i] = h[i];
+        __syncthreads();
+    }
+}
+
 // The same from the digits the previous pass's scatter wrote next to its output (one byte per key for 8-bit
 // digits, two for wider ones, in the order of that output): an eighth / a quarter of the key array's traffic.
 template <int DB>
@@ -260,8 +322,8 @@ __global__ __launch_bounds__(ND) void radix_offsets_small_kernel(uint32_t *__res
 // IOTA: the values of the input are its indices 0, 1, 2, ... (the first pass of a sort of all positions): not read.
 // wcount: kRW rows of ND per-wave digit counters.  For digits wider than 8 bits the rows live in the key image
 // (they are dead before the first key is staged), so that two workgroups still fit a CU's LDS.
-template <int DB, bool IOTA, bool FULL>
-__device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+template <int DB, bool IOTA, bool FULL, bool TEXT>
+__device__ __forceinline__ void radix_scatter_tile(const sx_textkey &tk, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                    uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint64_t n,
                                                    int shift, uint32_t mask, uint32_t tile, const uint32_t *__restrict__ offs,
                                                    typename radix_dig_type<DB>::type *__restrict__ dig_out, int next_shift,
@@ -285,7 +347,8 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
         // read once, never again: streaming loads leave L2 to the runs being written (10.1 -> 9.95 ms per sort)
-        key[k] = (FULL || i < n) ? __builtin_nontemporal_load(kin + i) : ~0ull;
+        if (TEXT) key[k] = (FULL || i < n) ? textkey_at(tk, i) : ~0ull; // (the keys of a text-keyed sort's first pass)
+        else key[k] = (FULL || i < n) ? __builtin_nontemporal_load(kin + i) : ~0ull;
     }
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
@@ -371,9 +434,9 @@ __device__ __forceinline__ void radix_scatter_tile(const uint64_t *__restrict__ 
 }
 
 // (second launch bound: workgroups per CU to plan registers for; LDS already limits a CU to two)
-template <int DB, bool IOTA>
+template <int DB, bool IOTA, bool TEXT = false>
 __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
-    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
+    sx_textkey tk, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
     uint32_t *__restrict__ vout, uint64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
     uint32_t ntiles, typename radix_dig_type<DB>::type *__restrict__ dig_out /* digits of the NEXT pass, or null */,
     int next_shift, uint32_t next_mask)
@@ -397,11 +460,11 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
     for (int i = t; i < kRW * ND; i += kRT) wcount[i] = 0;
     __syncthreads();
     if ((uint64_t)(tile + 1) * kRadixTile <= n) // uniform
-        radix_scatter_tile<DB, IOTA, true>(kin, vin, kout, vout, n, shift, mask, tile, offs, dig_out, next_shift, next_mask,
-                                           wcount, goff, scan_lds, skey);
+        radix_scatter_tile<DB, IOTA, true, TEXT>(tk, kin, vin, kout, vout, n, shift, mask, tile, offs, dig_out, next_shift, next_mask,
+                                                 wcount, goff, scan_lds, skey);
     else
-        radix_scatter_tile<DB, IOTA, false>(kin, vin, kout, vout, n, shift, mask, tile, offs, dig_out, next_shift, next_mask,
-                                            wcount, goff, scan_lds, skey);
+        radix_scatter_tile<DB, IOTA, false, TEXT>(tk, kin, vin, kout, vout, n, shift, mask, tile, offs, dig_out, next_shift, next_mask,
+                                                  wcount, goff, scan_lds, skey);
 }
 
 } // namespace sx
@@ -432,8 +495,9 @@ void *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n, int digit_bits)
 
 template <int DB>
 static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n, int begin_bit,
-                         int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready)
+                         int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready, const sx_textkey *text_keys)
 {
+    const sx_textkey no_text = {nullptr, 0, 0, 1, 1, 0, 0};
     constexpr int ND = 1 << DB;
     typedef typename radix_dig_type<DB>::type dig_t;
     uint32_t ntiles, nchunks;
@@ -451,7 +515,10 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
         const int next_shift = shift + DB;
         const bool has_next = next_shift < end_bit;
         const int next_bits = has_next ? (end_bit - next_shift < DB ? end_bit - next_shift : DB) : 0;
-        if (shift == begin_bit && !first_digits_ready)
+        if (shift == begin_bit && text_keys)
+            sx_launch(ctx, SX_KC_RADIX_HIST, n, radix_hist_text_kernel<DB>, dim3(ntiles < SX_HIST_GRID ? ntiles : SX_HIST_GRID), dim3(kHT),
+                      *text_keys, n, shift, mask, hist, ntiles);
+        else if (shift == begin_bit && !first_digits_ready)
             sx_launch(ctx, SX_KC_RADIX_HIST, n * 8, radix_hist_kernel<DB>, dim3(ntiles), dim3(kHT), (const uint64_t *)kin, n, shift,
                       mask, hist, ntiles);
         else
@@ -467,14 +534,19 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
             sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 8, radix_apply_kernel<ND>, dim3(nchunks), dim3(ND), hist, ntiles,
                       (const uint32_t *)sums, (const uint32_t *)digit_base);
         }
-        if (values_are_indices && shift == begin_bit)
+        if (text_keys && shift == begin_bit)
+            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (13 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true, true>,
+                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), *text_keys, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
+                      mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
+                      has_next ? (1u << next_bits) - 1u : 0u);
+        else if (values_are_indices && shift == begin_bit)
             sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (20 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true>,
-                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
+                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), no_text, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
                       mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
                       has_next ? (1u << next_bits) - 1u : 0u);
         else
             sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (24 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, false>,
-                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
+                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), no_text, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
                       mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
                       has_next ? (1u << next_bits) - 1u : 0u);
         uint64_t *tk = kin; kin = kout; kout = tk;
@@ -488,15 +560,15 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
 
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
                   int begin_bit, int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready,
-                  int digit_bits)
+                  int digit_bits, const sx_textkey *text_keys)
 {
     *result_in_b = 0;
     if (n == 0 || end_bit <= begin_bit) return 0;
     if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
     switch (digit_bits ? digit_bits : sx_sort_digit_bits(ctx)) {
-    case 9: return sort_pairs_db<9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready);
-    case 10: return sort_pairs_db<10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready);
-    default: return sort_pairs_db<8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready);
+    case 9: return sort_pairs_db<9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys);
+    case 10: return sort_pairs_db<10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys);
+    default: return sort_pairs_db<8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys);
     }
 }
 
