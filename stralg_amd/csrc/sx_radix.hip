@@ -88,11 +88,10 @@ __global__ __launch_bounds__(kHT) void radix_hist_kernel(const uint64_t *__restr
     for (int i = (int)threadIdx.x; i < ND; i += kHT) hist[(uint64_t)blockIdx.x * ND + i] = h[i];
 }
 
-// key of position p of a text-keyed sort (sx_textkey): the value all_keys16_kernel (sx_lmssort.hip) would have stored
-__device__ __forceinline__ uint64_t textkey_at(const sx_textkey &tk, uint64_t p)
+// key of a position of a text-keyed sort (sx_textkey) from the 16 bytes at the position (q0, q1) and the byte in front of
+// it: the value all_keys16_kernel (sx_lmssort.hip) would have stored
+__device__ __forceinline__ uint64_t textkey_from(const sx_textkey &tk, uint64_t q0, uint64_t q1, uint32_t before)
 {
-    uint64_t q0, q1;
-    load_bytes16(tk.T, p, q0, q1);
     uint64_t acc;
     if (tk.base == 256u) { // (uniform) bytes: the first C of them as a big-endian number
         acc = tk.C <= 8u ? __builtin_bswap64(q0) >> (64u - 8u * tk.C)
@@ -112,11 +111,15 @@ __device__ __forceinline__ uint64_t textkey_at(const sx_textkey &tk, uint64_t p)
         }
         if (tk.C % 3u) acc = acc * tk.powR + g; // uniform
     }
-    if (tk.wnd && p) { // the symbol in front of the suffix as a one-symbol window (it becomes the BWT)
-        const uint32_t before = tk.T[p - 1];
-        if (before) acc |= (uint64_t)(((before - 1u) << 4) | 1u) << tk.kbits;
-    }
+    // the symbol in front of the suffix as a one-symbol window (it becomes the BWT)
+    if (tk.wnd && before) acc |= (uint64_t)(((before - 1u) << 4) | 1u) << tk.kbits;
     return acc;
+}
+__device__ __forceinline__ uint64_t textkey_at(const sx_textkey &tk, uint64_t p)
+{
+    uint64_t q0, q1;
+    load_bytes16(tk.T, p, q0, q1);
+    return textkey_from(tk, q0, q1, p ? (uint32_t)tk.T[p - 1] : 0u);
 }
 
 template <int DB>
@@ -132,6 +135,14 @@ __global__ __launch_bounds__(kHT) void radix_hist_text_kernel(sx_textkey tk, uin
         // bytes whose digit is a whole byte of the key: that byte of the text, no key to compute
         const bool byte_digit = tk.base == 256u && (shift & 7) == 0 && mask == 0xFFu && shift < (int)(8u * tk.C);
         const uint32_t byte_at = byte_digit ? tk.C - 1u - (uint32_t)(shift >> 3) : 0u;
+        if (byte_digit && kHI == 16) { // (uniform) the digits are the text's own bytes: 16 consecutive ones a thread, one load
+            const uint64_t i0 = base + (uint64_t)threadIdx.x * 16u;
+            uint64_t q0 = 0, q1 = 0;
+            if (i0 < n) load_bytes16(tk.T, i0 + byte_at, q0, q1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (i0 + (uint64_t)e < n) atomicAdd(&h[(uint32_t)((e < 8 ? q0 : q1) >> (8 * (e & 7))) & 0xFFu], 1u);
+        } else {
 #pragma unroll
         for (int k = 0; k < kHI; ++k) {
             const uint64_t i = base + (uint64_t)k * kHT + threadIdx.x;
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(kHT) void radix_hist_text_kernel(sx_textkey tk, uin
             } else if (i < n) {
                 atomicAdd(&h[d], 1u);
             }
+        }
         }
         __syncthreads();
         for (int i = (int)threadIdx.x; i < ND; i += kHT) hist[(uint64_t)tile * ND + i] = h[i];
@@ -343,12 +355,33 @@ __device__ __forceinline__ void radix_scatter_tile(const sx_textkey &tk, const u
     uint64_t key[kRadixItems];
     uint32_t lpos[kRadixItems]; // [12:0] rank within (wave, digit), then slot in the tile's digit order; [31:16] digit
     static_assert(kRadixTile <= 65536, "slot and digit share a register");
+    // TEXT: the tile's text, bytes [tile0 - 16, tile0 + kRadixTile + 32), behind the per-wave counters in the key image
+    // (both are dead before the first key is staged): every key is then a few LDS reads instead of an unaligned 16-byte
+    // load from memory (8 of them a thread: the first version of this pass lost to the key kernel it replaced)
+    uint8_t *stxt = reinterpret_cast<uint8_t *>(skey) + (size_t)kRW * ND * sizeof(uint32_t);
+    if constexpr (TEXT) {
+        static_assert((size_t)kRW * ND * 4 + kRadixTile + 64 <= sizeof(uint64_t) * kRadixTile, "text image fits behind the counters");
+        for (uint32_t piece = (uint32_t)t; piece < (uint32_t)kRadixTile / 16u + 3u; piece += kRT) {
+            const uint64_t p0 = tile0 + (uint64_t)piece * 16u; // the piece holds text[p0 - 16, p0)
+            uint4 v;
+            v.x = v.y = v.z = v.w = 0;
+            if (p0 >= 16u && p0 - 16u < n + 64u) v = *reinterpret_cast<const uint4 *>(tk.T + p0 - 16u); // (T is 16-byte aligned, padded 128 bytes beyond n)
+            *reinterpret_cast<uint4 *>(stxt + (size_t)piece * 16u) = v;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
         // read once, never again: streaming loads leave L2 to the runs being written (10.1 -> 9.95 ms per sort)
-        if (TEXT) key[k] = (FULL || i < n) ? textkey_at(tk, i) : ~0ull; // (the keys of a text-keyed sort's first pass)
-        else key[k] = (FULL || i < n) ? __builtin_nontemporal_load(kin + i) : ~0ull;
+        if (TEXT) { // the keys of a text-keyed sort's first pass, from the tile's text staged in LDS (below)
+            uint64_t q0, q1;
+            const uint32_t at = 16u + (uint32_t)(i - tile0);
+            lds_bytes16(stxt, at, q0, q1);
+            key[k] = (FULL || i < n) ? textkey_from(tk, q0, q1, i ? (uint32_t)stxt[at - 1u] : 0u) : ~0ull;
+        } else {
+            key[k] = (FULL || i < n) ? __builtin_nontemporal_load(kin + i) : ~0ull;
+        }
     }
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
@@ -534,12 +567,15 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
             sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles * ND * 8, radix_apply_kernel<ND>, dim3(nchunks), dim3(ND), hist, ntiles,
                       (const uint32_t *)sums, (const uint32_t *)digit_base);
         }
-        if (text_keys && shift == begin_bit)
-            sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (13 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true, true>,
-                      dim3(((ntiles + 7) / 8) * 8), dim3(kRT), *text_keys, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
-                      mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
-                      has_next ? (1u << next_bits) - 1u : 0u);
-        else if (values_are_indices && shift == begin_bit)
+        if (text_keys && shift == begin_bit) {
+            if constexpr (DB == 8) // (the text image lies behind the counters in the key image: 8-bit digits only)
+                sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (13 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true, true>,
+                          dim3(((ntiles + 7) / 8) * 8), dim3(kRT), *text_keys, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n,
+                          shift, mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
+                          has_next ? (1u << next_bits) - 1u : 0u);
+            else
+                return sx_fail_msg(ctx, SX_E_INTERNAL, "sort: text-keyed first pass with digits wider than 8 bits");
+        } else if (values_are_indices && shift == begin_bit)
             sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (20 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true>,
                       dim3(((ntiles + 7) / 8) * 8), dim3(kRT), no_text, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n, shift,
                       mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
