@@ -730,6 +730,12 @@ def test_thread_exit_releases_its_context(emu_ctx, golden):
         th = threading.Thread(target=work, args=(release,))
         th.start()
         th.join()
+        # (Thread.join returns when the thread's Python side is done; its pthread keys' destructors run a moment later)
+        import time
+        for _ in range(400):
+            if lib.stralg_amd_live_contexts() == before:
+                break
+            time.sleep(0.01)
         assert lib.stralg_amd_live_contexts() == before, "the exited thread's context is still alive"
     assert all(live == before + 1 and (arr == c["sa"]).all() for live, arr in seen)
 

@@ -798,6 +798,44 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
         assert bool((c2 == c).all()) and bool((o2 == o).all())
 
 
+def test_wide_induction_forms_agree_at_size(gpu_ctx):
+    """More than 8 buckets through the LMS sort + induced-sort passes at sizes where round 4's forms are all taken: every
+    bucket's other-region round up front (bigram counts; sx_induce_wide.hpp) against a launch set per bucket
+    (SX_FLAG_INDUCE_NO_HOIST), second rounds of 8 - 32 thousand entries taken by the tail kernel tile after tile, and the
+    direct sort of all suffixes with its first pass computing the keys or reading a key kernel's -- one suffix array,
+    the sorted permutation (verify.py)."""
+    import torch
+    from stralg_amd import verify
+    for log2n, sigma in ((27, 64), (26, 200), (25, 12)):
+        n = 1 << log2n
+        text = torch.empty(n, dtype=torch.uint8, device="cuda")
+        gpu_ctx.synth_dev(text, n, sigma, 77 + log2n)
+        got = []
+        try:
+            variants = [(True, True, True), (True, False, True)]
+            if sigma >= 17:  # (the direct sort takes alphabets of 17 symbols and more)
+                variants += [(False, True, True), (False, True, False)]
+            for no_direct, hoist, text_keys in variants:
+                gpu_ctx.set_no_direct_sort(no_direct)
+                gpu_ctx.set_induce_hoist(hoist)
+                gpu_ctx.set_text_keys(text_keys)
+                sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+                gpu_ctx.sa_build_dev(text, n, sigma, sa)
+                st = gpu_ctx.last_stats()
+                assert (st["lms_path"] in (1, 2)) == no_direct, (log2n, sigma, st)
+                got.append((sa, st["induce_rounds"]))
+        finally:
+            gpu_ctx.set_no_direct_sort(False)
+            gpu_ctx.set_induce_hoist(True)
+            gpu_ctx.set_text_keys(True)
+        verify.verify_sa_on_device(text, got[0][0], n)
+        for sa, _ in got[1:]:
+            assert bool((sa == got[0][0]).all()), (log2n, sigma)
+        assert got[0][1] < got[1][1]  # (the up-front form queues about half the rounds)
+        del got, text
+        torch.cuda.empty_cache()
+
+
 def test_wide_tables_beyond_launch_limit(gpu_ctx):
     """sigma > 8 tables at N = 2^30 + 1: one workgroup per 64-row tile would be 2^24 + 1 workgroups of 256
     threads, more threads than a launch can hold (the kernels loop over tiles instead).  The O rows are checked

@@ -62,6 +62,10 @@ for k in range(cases):
     ctx.set_copy_text_first(bool(rng.integers(0, 4) == 0))
     ctx.set_recurse_min(int(rng.choice([-1, -1, 50, 3000])))  # reduced strings of few names sorted by the pipeline itself
     ctx.set_sample_min(int(rng.choice([-1, -1, 2000, 100000])))  # the look at a sample before the prefix sorts (sigma > 8)
+    # round 4: more than 8 buckets -- every bucket's other-region round up front (bigram counts) or a launch set of its own;
+    # the direct sort's first pass computing its keys from the text or reading a key kernel's
+    ctx.set_induce_hoist(bool(rng.integers(0, 4)))
+    ctx.set_text_keys(bool(rng.integers(0, 4)))
     # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
     want = oracle.sa_is_strict(x, sigma) if sigma == n + 1 else oracle.sa_is(x, sigma)
     sa = np.zeros(n + 1, np.uint32)
@@ -80,4 +84,5 @@ for k in range(cases):
 ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(-1); ctx.set_prefix_symbols(0)
 ctx.set_sort_mode(0); ctx.set_radix_digit_bits(0)
 ctx.set_induce_batch_min(-1); ctx.set_induce_batch(True); ctx.set_induce_attended(0); ctx.set_copy_text_first(False); ctx.set_recurse_min(-1); ctx.set_sample_min(-1)
+ctx.set_induce_hoist(True); ctx.set_text_keys(True)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
