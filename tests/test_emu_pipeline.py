@@ -409,13 +409,23 @@ def test_wide_alphabets_direct_sort_and_induction(emu_ctx):
         x[100:112] = x[1000:1012]
         x[5:17] = x[1000:1012]  # ties beyond the first key: refinement rounds
         want = oracle.sa_is(x, sigma)
-        for no_direct in (False, True):
+        rounds = {}
+        # (round 4's switches: every bucket's other-region round up front / a launch set per bucket; the direct sort's
+        #  first pass computing its keys / reading a key kernel's)
+        for no_direct, hoist, text_keys in ((False, True, True), (False, True, False), (True, True, True), (True, False, True)):
             emu_ctx.set_no_direct_sort(no_direct)
+            emu_ctx.set_induce_hoist(hoist)
+            emu_ctx.set_text_keys(text_keys)
             sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
             emu_ctx.sa_bwt_build_dev(x, n, sigma, sa, bw)
-            assert emu_ctx.last_stats()["lms_path"] == (1 if no_direct else 3), (sigma, no_direct)
-            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (sigma, no_direct)
+            st = emu_ctx.last_stats()
+            assert st["lms_path"] == (1 if no_direct else 3), (sigma, no_direct)
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (sigma, no_direct, hoist, text_keys)
+            rounds[(no_direct, hoist)] = st["induce_rounds"]
+        assert rounds[(True, True)] < rounds[(True, False)]  # about half the rounds are queued
     emu_ctx.set_no_direct_sort(False)
+    emu_ctx.set_induce_hoist(True)
+    emu_ctx.set_text_keys(True)
 
 
 def test_serialisation_bytes(emu_ctx, tmp_path):
