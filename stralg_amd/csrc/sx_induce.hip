@@ -140,7 +140,7 @@ void launch_round(induce_state<WT> &st, const uint32_t *srcP, const WT *srcW, in
         // wide alphabets: the round as a radix pass over tiles of 8192 entries (count, offsets, scatter)
         const uint8_t *srcB = srcP == st.SA ? (const uint8_t *)st.BW : nullptr;
         const uint32_t wtiles = sx_div_up((uint64_t)(tiles_bound < 1 ? 1 : tiles_bound) * kIndTile, kWideTile);
-        const uint32_t wgrid = wtiles > 2048 ? 2048 : (wtiles >= 8 ? ((wtiles + 7u) & ~7u) : wtiles); // (a multiple of 8: see xcd_tiles)
+        const uint32_t wgrid = wtiles > 2048 ? 2048 : wtiles;
         const int only = only3 ? 1 : 0;
         sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, induce_wide_count_kernel<WT>, dim3(wgrid), dim3(kWideThreads), srcW, srcB,
                   (const uint32_t *)rin, rev, mode, c, st.cfg, st.whist, chain_max);
@@ -531,8 +531,6 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         st.hoist_from = pass == 0 ? 0u : nk - 1u;
         uint32_t gx = hz_most[pass];
         if (gx > kHoistGridX) gx = kHoistGridX;
-        if (gx >= 8) gx = (gx + 7u) & ~7u; // (a multiple of 8: a bucket's tiles are dealt XCD by XCD, xcd_tiles)
-        if (gx > kHoistGridX && kHoistGridX >= 8) gx = kHoistGridX & ~7u;
         sx_launch(ctx, SX_KC_INDUCE_GATHER, 0, hoist_count_kernel<WT>, dim3(gx, nk), dim3(kWideThreads), srcW, srcB, desc, rev, mode, st.cfg,
                   hz_hist);
         sx_launch(ctx, SX_KC_INDUCE_SCAN, (uint64_t)hz_rows[pass] * 2048, hoist_offsets_kernel, dim3(nk), dim3(kBlock * kHoistOffGroups),

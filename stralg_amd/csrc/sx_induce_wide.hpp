@@ -276,27 +276,6 @@ __device__ __forceinline__ void refill_windows(const uint8_t *__restrict__ T, co
     SX_SCHED_FENCE();
 }
 
-// The tiles of a round dealt to the scatter's workgroups so that neighbouring tiles share an XCD: workgroups go round
-// robin to the 8 XCDs, each with its own L2, and neighbouring tiles write neighbouring runs into every destination bucket --
-// 32 entries a bucket and tile, a 32-byte run of symbol bytes: four tiles to a cache line --, which leave as whole lines
-// only if they meet in one L2 (the radix scatter's tile order, sx_radix.hip).  G: workgroups (a multiple of 8, else
-// round robin), b: this one.
-#ifndef SX_WIDE_XCD_ORDER
-#define SX_WIDE_XCD_ORDER 1
-#endif
-struct xcd_tile_walk { uint32_t first, end, step; };
-__device__ __forceinline__ xcd_tile_walk xcd_tiles(uint32_t b, uint32_t G, uint32_t ntiles)
-{
-    xcd_tile_walk r{b, ntiles, G};
-    if (SX_WIDE_XCD_ORDER && G >= 8u && (G & 7u) == 0u) {
-        const uint32_t per = (ntiles + 7u) / 8u, x = b & 7u;
-        r.first = x * per + (b >> 3);
-        r.end = (x + 1u) * per < ntiles ? (x + 1u) * per : ntiles;
-        r.step = G >> 3;
-    }
-    return r;
-}
-
 // LDS of one scatter workgroup (the kernels below declare it and hand it to wide_scatter_tile)
 template <int ITEMS> struct wide_scatter_lds {
     static constexpr int kSub = kWideThreads * ITEMS;
@@ -472,8 +451,7 @@ __global__ __launch_bounds__(kWideThreads, 4) void induce_wide_scatter_kernel(
     if (len <= min_len) return;
     const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
     const uint32_t base_d = t < 256 ? cursor_cur[t] : 0u;
-    const xcd_tile_walk tw = xcd_tiles(blockIdx.x, gridDim.x, ntiles);
-    for (uint32_t tile = tw.first; tile < tw.end; tile += tw.step) { // uniform per workgroup
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
         const uint32_t pre = t < 256 ? offs[(uint64_t)tile * 256 + t] : 0u; // entries of earlier tiles (and steps) for bucket t
         wide_scatter_tile<WT, ITEMS>(lds, srcP, srcW, lo, len, tile, rev, mode, c, cfg, T, pre, base_d, dir, SA, WN, BW);
     }
@@ -646,8 +624,7 @@ __global__ __launch_bounds__(kWideThreads, 4) void hoist_scatter_kernel(
     if (len == 0) return;
     const uint32_t ntiles = (len + kWideTile - 1) / kWideTile;
     const uint32_t base_d = t < 256 ? dbase[(uint64_t)c * 256 + t] : 0u;
-    const xcd_tile_walk tw = xcd_tiles(blockIdx.x, gridDim.x, ntiles); // (gridDim.x is a multiple of 8: a bucket's workgroup x is on XCD x % 8)
-    for (uint32_t tile = tw.first; tile < tw.end; tile += tw.step) { // uniform per workgroup
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { // uniform per workgroup
         const uint32_t pre = t < 256 ? offs[(uint64_t)(row0 + tile) * 256 + t] : 0u;
         // The sort's seed windows hold two or three symbols: the entry a seed induces would be left with one, and the
         // round that scans it -- one of the bucket's own, a chain of launches each bound by its latency -- would go back
