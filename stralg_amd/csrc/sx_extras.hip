@@ -416,9 +416,12 @@ static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *
     uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
     SX_CHECK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
     if (sx_scatter_permutation_applies(N)) {
-        // three passes: coarse windows, their fine windows, the fine windows through LDS (above)
-        uint32_t wbits = kInvWindowBits;
-        while (((N + (1ull << wbits) - 1) >> wbits) > kInvMaxParts) ++wbits;
+        // three passes: coarse windows, their fine windows, the fine windows through LDS (above).  The coarse windows are
+        // chosen so that BOTH dealing passes write long runs: at most 128 of them (a tile of 8192 entries leaves 64-pair,
+        // 512-byte runs; with the two-pass form's 512 windows of 2^19 targets the first pass wrote 128-byte runs at
+        // arbitrary offsets and took 3.1 of the inverse's 4.5 ms for a third of its traffic), each of at least 64 fine ones
+        uint32_t wbits = kInvFineBits + 6u;
+        while (((N + (1ull << wbits) - 1) >> wbits) > 128u) ++wbits;
         const uint32_t nparts = (uint32_t)((N + (1ull << wbits) - 1) >> wbits);
         const uint64_t nfine = (N + (1ull << kInvFineBits) - 1) >> kInvFineBits;
         const size_t pairs_b = (N * sizeof(uint2) + 255) & ~(size_t)255, cur_b = ((size_t)kInvMaxParts * 4 + 255) & ~(size_t)255,
