@@ -160,7 +160,17 @@ static struct block_cache *block_cache_get(bool create)
     return bc;
 }
 
-static const size_t kBlockCacheMin = (size_t)64 << 20;
+/* blocks of at least this many bytes are cached (64 MiB; $STRALG_AMD_HOST_CACHE_MIN, in bytes, lets the tests cache small ones) */
+static size_t block_cache_min(void)
+{
+    static size_t v = 0;
+    if (!v) {
+        const char *env = getenv("STRALG_AMD_HOST_CACHE_MIN");
+        v = env && atol(env) > 0 ? (size_t)atol(env) : (size_t)64 << 20;
+    }
+    return v;
+}
+#define kBlockCacheMin block_cache_min()
 
 /* free() for the large arrays this library allocated: into the calling thread's cache when there is room */
 static void big_free(void *p)
@@ -168,14 +178,25 @@ static void big_free(void *p)
     if (!p) return;
     const size_t bytes = malloc_usable_size(p);
     struct block_cache *bc = bytes >= kBlockCacheMin && block_cache_cap() ? block_cache_get(true) : NULL;
-    if (bc && bc->total + bytes <= block_cache_cap()) {
-        for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i)
-            if (!bc->p[i]) {
-                bc->p[i] = p;
-                bc->bytes[i] = bytes;
-                bc->total += bytes;
-                return;
-            }
+    while (bc && bytes <= block_cache_cap()) {
+        int empty = -1, smallest = -1;
+        for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i) {
+            if (!bc->p[i]) empty = i;
+            else if (smallest < 0 || bc->bytes[i] < bc->bytes[smallest]) smallest = i;
+        }
+        if (empty >= 0 && bc->total + bytes <= block_cache_cap()) {
+            bc->p[empty] = p;
+            bc->bytes[empty] = bytes;
+            bc->total += bytes;
+            return;
+        }
+        /* no room: a smaller cached block makes way (a caller that went from short records to long ones: the short
+         * records' blocks would otherwise sit in the slots for ever while the long ones' are unmapped every time) */
+        if (smallest < 0 || bc->bytes[smallest] >= bytes) break;
+        free(bc->p[smallest]);
+        bc->total -= bc->bytes[smallest];
+        bc->p[smallest] = NULL;
+        bc->bytes[smallest] = 0;
     }
     free(p);
 }
@@ -195,7 +216,7 @@ static void block_cache_release(void)
 static void *big_alloc(size_t bytes)
 {
     const size_t huge = (size_t)2 << 20;
-    if (bytes < 4 * huge) return malloc(bytes ? bytes : 1);
+    if (bytes < 4 * huge && bytes < kBlockCacheMin) return malloc(bytes ? bytes : 1);
     if (bytes >= kBlockCacheMin) {
         struct block_cache *bc = block_cache_get(false);
         if (bc) { /* the smallest cached block that holds it, unless it is more than twice as large */
@@ -211,6 +232,7 @@ static void *big_alloc(size_t bytes)
             }
         }
     }
+    if (bytes < 4 * huge) return malloc(bytes ? bytes : 1);
     void *p = aligned_alloc(huge, (bytes + huge - 1) & ~(huge - 1));
     if (!p) return malloc(bytes);
     (void)madvise(p, (bytes + huge - 1) & ~(huge - 1), MADV_HUGEPAGE);

@@ -794,3 +794,53 @@ def test_reverse_on_the_device(emu_ctx):
     both = np.zeros(64, dtype=np.uint8)
     with pytest.raises(StralgAmdError):
         emu_ctx.reverse_dev(both[:32], 32, both[8:])
+
+
+def test_host_block_cache(golden):
+    """The per-thread cache of large host blocks (stralg_host.c): arrays freed through completely_free_bwt_table come back
+    to the thread's next build_complete_table (the read-mapper's loop build -> write -> free -> build stops unmapping and
+    first-touching its tables), a smaller cached block makes way for a larger one, and stralg_amd_release() drops the cache.
+    In a child process: the threshold ($STRALG_AMD_HOST_CACHE_MIN, normally 64 MiB) is read once."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r)
+from stralg_amd.api import Context
+ctx = Context(0, lib_path=%r)
+lib = ctx.lib
+class SA(C.Structure):
+    _fields_ = [("string", C.c_void_p), ("length", C.c_uint32), ("array", C.c_void_p), ("inverse", C.c_void_p), ("lcp", C.c_void_p)]
+class BT(C.Structure):
+    _fields_ = [("remap_table", C.c_void_p), ("sa", C.POINTER(SA)), ("c_table", C.c_void_p), ("o_table", C.c_void_p),
+                ("o_indices", C.c_void_p), ("ro_table", C.c_void_p), ("ro_indices", C.c_void_p)]
+lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
+lib.build_complete_table.restype = C.POINTER(BT)
+lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+lib.completely_free_bwt_table.restype = None
+rng = np.random.default_rng(1)
+def text(n):
+    return bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n))
+def blocks(t):
+    return {t.contents.o_table, t.contents.ro_table, t.contents.o_indices, t.contents.ro_indices, t.contents.sa.contents.array}
+a = lib.build_complete_table(text(3000), True)
+first = blocks(a)
+lib.completely_free_bwt_table(a)
+b = lib.build_complete_table(text(2900), True)       # a little shorter: every large array fits a cached block
+assert blocks(b) <= first, "the second table's arrays are not the first one's blocks"
+lib.completely_free_bwt_table(b)
+big = lib.build_complete_table(text(40000), True)    # ten times longer: nothing cached fits; freed, its blocks evict the small ones
+big_blocks = blocks(big)
+assert not (big_blocks & first)
+lib.completely_free_bwt_table(big)
+again = lib.build_complete_table(text(39000), True)
+assert blocks(again) <= big_blocks, "the long record's blocks were not kept"
+lib.completely_free_bwt_table(again)
+lib.stralg_amd_release()
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libstralg_amd_emu.so"))
+    env = dict(os.environ, STRALG_AMD_HOST_CACHE_MIN="4096")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
