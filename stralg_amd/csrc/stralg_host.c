@@ -572,12 +572,20 @@ static size_t readable_extent(const void *addr)
     uintptr_t end = 0;
     char line[512];
     while (fgets(line, sizeof line, f)) {
-        unsigned long lo, hi;
-        char perms[8];
-        if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perms) != 3) continue;
+        unsigned long lo, hi, off, ino;
+        char perms[8], dev[16], path[8];
+        path[0] = 0;
+        if (sscanf(line, "%lx-%lx %7s %lx %15s %lu %7s", &lo, &hi, perms, &off, dev, &ino, path) < 6) continue;
+        /* only memory that is there for sure: anonymous mappings, the heap, a stack.  A page of a file mapping behind the
+         * file's end is mapped and readable by these lines and still a SIGBUS to touch -- strlen, which stops at the
+         * terminator, would never get there; a scan that reads ahead of it could */
+        const bool safe = perms[0] == 'r' && (path[0] == 0 || path[0] == '[');
         if (end == 0) {
-            if (a >= lo && a < hi && perms[0] == 'r') end = hi;
-        } else if (lo == end && perms[0] == 'r') {
+            if (a >= lo && a < hi) {
+                if (!safe) break;
+                end = hi;
+            }
+        } else if (lo == end && safe) {
             end = hi; /* the next mapping continues this one */
         } else if (lo >= end) {
             break;

@@ -246,7 +246,7 @@ def test_long_strlen_scans_only_what_is_mapped(product_lib):
     rng = np.random.default_rng(2)
     for n in (0, 5, chunk - 1, chunk, chunk + 1, 3 * chunk + 12345, 9 * chunk):
         total = ((n + 1 + page - 1) // page + 1) * page  # the string, then one guard page
-        m = mmap.mmap(-1, total)
+        m = mmap.mmap(-1, total, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)  # (what malloc hands out for a long record)
         buf = (C.c_uint8 * total).from_buffer(m)
         base = C.addressof(buf)
         start = total - page - (n + 1)  # the terminator is the last byte in front of the guard page
@@ -267,3 +267,15 @@ def test_long_strlen_scans_only_what_is_mapped(product_lib):
         libc.mprotect(base + total - page, page, 3)
         del arr, buf
         m.close()
+    # a record inside a FILE mapping is scanned by strlen itself: pages of such a mapping behind the file's end are listed
+    # as readable and are a SIGBUS to touch (Python's default mmap(-1, ...) is a shared mapping of /dev/zero: a path)
+    n = 2 * chunk + 77
+    m = mmap.mmap(-1, n + 1)
+    arr = np.frombuffer(m, dtype=np.uint8)
+    arr[:n] = 65
+    arr[n] = 0
+    buf = (C.c_uint8 * (n + 1)).from_buffer(m)
+    have = C.c_int(-1)
+    assert lib.stralg_amd_strlen_and_letters(C.addressof(buf), None, C.byref(have)) == n and have.value == 0
+    del arr, buf
+    m.close()
