@@ -170,6 +170,31 @@ def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up(emu_ctx):
     assert [r["rank"] for r in co["ranks"]] == [0, 1]
 
 
+def test_bench_under_torch_distributed_run(emu_ctx):
+    """the driver's own launch form for N > 1 -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W: RANK / LOCAL_RANK / WORLD_SIZE come from the environment,
+    rank 0 prints the one line (here over the CPU execution harness, so the collectives stay on gloo)"""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(STRALG_BENCH_EMU="1", STRALG_BENCH_LOG2N="12")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 2 and doc["warmup"] == 1 and doc["scaling"] == "weak"
+    assert doc["verified"] is True and doc["n_ranks_seen"] == 2
+    assert [r["local_rank"] for r in doc["collectives"]["ranks"]] == [0, 1]
+    assert doc["config"]["n"] == 4096 and "FASTA" in doc["config"]["workload"]
+
+
 def test_bench_default_run_carries_the_other_configs(emu_ctx):
     """the default (one GPU, DNA) line also measures BASELINE.json's other single-GPU configurations after the timed
     region, each verified, and names the algorithm that ran (here at 2^12 symbols over the CPU execution harness)"""
