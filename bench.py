@@ -51,6 +51,8 @@ def parse_args(argv=None):
                     help="wide alphabets: LMS sort + induced-sort passes even where the direct sort of all suffixes applies")
     ap.add_argument("--sort-mode", type=int, default=0,
                     help="prefix-key sort: 0 choose, 1 LSD passes over all key bits, 2 hybrid (top bits in HBM passes, sub-buckets in LDS)")
+    ap.add_argument("--prefix-symbols", type=int, default=0,
+                    help="prefix-key sort: symbols of the first attempt's key (0: by the text's size; A/B)")
     ap.add_argument("--chain-max", type=int, default=-1,
                     help="induce rounds of up to this many entries take the single chained launch (default: by alphabet size)")
     ap.add_argument("--no-induce-batch", action="store_true",
@@ -509,6 +511,8 @@ def run_rank(args):
         ctx.set_no_direct_sort(True)
     if args.sort_mode:
         ctx.set_sort_mode(args.sort_mode)
+    if args.prefix_symbols:
+        ctx.set_prefix_symbols(args.prefix_symbols)
     if args.chain_max >= 0:
         ctx.set_chain_max_entries(args.chain_max)
     if args.no_induce_batch:
