@@ -597,7 +597,10 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
 // is refilled from the text first (by both kernels alike).
 constexpr int kBatchRounds = 8;
 constexpr int kBatchRows = kBatchRounds * 8; // (round, bucket) count rows
-constexpr uint32_t kBatchFrom = 1u << 21;    // rounds expected to hold more entries than this are launches of their own
+#ifndef SX_BATCH_FROM
+#define SX_BATCH_FROM (1u << 21)
+#endif
+constexpr uint32_t kBatchFrom = SX_BATCH_FROM;    // rounds expected to hold more entries than this are launches of their own
 
 template <class WT> struct batch_plan {
     uint32_t a;    // descendants that stay in bucket c (rounds 0 .. a-1), at most kBatchRounds
