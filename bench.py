@@ -55,6 +55,8 @@ def parse_args(argv=None):
                     help="prefix-key sort: symbols of the first attempt's key (0: by the text's size; A/B)")
     ap.add_argument("--chain-max", type=int, default=-1,
                     help="induce rounds of up to this many entries take the single chained launch (default: by alphabet size)")
+    ap.add_argument("--no-text-keys", action="store_true",
+                    help="the hybrid sort's first pass reads keys a key kernel wrote instead of computing them from the text (A/B)")
     ap.add_argument("--no-induce-batch", action="store_true",
                     help="induced-sort passes: every self round of a bucket as a launch of its own (no eight-rounds-at-a-time form)")
     ap.add_argument("--induce-attended", action="store_true",
@@ -517,6 +519,8 @@ def run_rank(args):
         ctx.set_chain_max_entries(args.chain_max)
     if args.no_induce_batch:
         ctx.set_induce_batch(False)
+    if args.no_text_keys:
+        ctx.set_text_keys(False)
     if args.copy_text_first:
         ctx.set_copy_text_first(True)
     if args.induce_attended:

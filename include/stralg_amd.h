@@ -77,7 +77,8 @@ typedef struct sx_build_stats {
     uint32_t sort_passes;    /* radix passes, all sorts */
     uint32_t lms_path;       /* 1: prefix-key LMS sort resolved everything, 2: general path, 3: direct sort of all suffixes */
     uint32_t sort_local;     /* bit 0: the prefix-key sort finished in LDS (hybrid: HBM passes on the top 24 key bits only);
-                                bit 1: some workgroup of it met crowded bins and took stable passes; bit 2: HBM passes on the top 32 bits (four) */
+                                bit 1: some workgroup of it met crowded bins and took stable passes; bit 2: HBM passes on the top 32 bits (four);
+                                bit 3: its first HBM pass computed the keys from the text (no key kernel) */
     uint32_t refine_tiers;   /* tie refinement of the prefix-key sort: bit 0: some round ordered groups of 9 .. 2048 members in
                                 LDS; bit 1: some round sent the members of longer groups through radix sorts; prefix doubling of the
                                 general path: bit 2: some round ordered small groups by one wave each, bit 3: some round sent

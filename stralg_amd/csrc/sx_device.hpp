@@ -171,6 +171,9 @@ template <class Op> __device__ __forceinline__ uint32_t block_reduce(uint32_t v,
 #endif
 // nothing is scheduled across this point (keeps the compiler from interleaving the unrolled copies of a register-hungry
 // step -- eight window decodes at once spilled a thousand registers)
+#ifndef SX_WAVES_PER_EU // exactly N waves a SIMD: the register budget of a kernel whose workgroups must fit a CU two at a time
+#define SX_WAVES_PER_EU(N) __attribute__((amdgpu_waves_per_eu(N, N)))
+#endif
 #ifndef SX_SCHED_FENCE // (the CPU test harness defines it away as well)
 #define SX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif

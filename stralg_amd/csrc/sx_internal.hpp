@@ -7,6 +7,7 @@
 // (most significant symbol first) and, with wnd, the symbol in front of position i as a one-symbol window above bit
 // kbits (sx_window.hpp).  A sort given such a description computes the keys in its first pass instead of reading them
 // (the direct sort of wide alphabets: no key kernel, no 8 bytes a suffix written and read back).
+namespace sx { struct sx_lmskey; }
 struct sx_textkey {
     const uint8_t *T; // the build's padded copy of the text (readable 16 bytes beyond any position)
     uint32_t base, C; // C <= 12
@@ -16,7 +17,11 @@ struct sx_textkey {
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
                   int begin_bit, int end_bit, int *result_in_b, bool values_are_indices = false,
                   bool first_digits_ready = false, int digit_bits = 0 /* 8, 9, 10; 0: the context's choice */,
-                  const sx_textkey *text_keys = nullptr /* the first pass computes the keys (ka is not read; values = indices) */);
+                  const sx_textkey *text_keys = nullptr /* the first pass computes the keys (ka is not read; values = indices) */,
+                  const sx::sx_lmskey *lms_keys = nullptr /* the first pass lists the LMS suffixes and computes their keys (sx_lmskey.hpp;
+                                                             ka, va are not read, ka holds that pass's tile table) */);
+// whether a sort of m LMS suffixes of a text of cls_tiles classification tiles can take that first pass for keys of this shape
+bool sx_sort_lms_keys_applies(uint64_t m, uint32_t cls_tiles, uint32_t shape);
 // where the key generator of a sort of n pairs may leave the first pass's digit of every key
 // ((key >> begin_bit) & (2^digit_bits - 1); one byte each for 8-bit digits, two for wider ones): the first
 // histogram then reads these instead of the keys (first_digits_ready)

@@ -26,191 +26,10 @@
 #include "sx_scan.hpp"
 #include "sx_internal.hpp"
 #include "sx_window.hpp"
+#include "sx_lmskey.hpp"
 
 namespace sx {
 
-// The first C symbols of suffix p as one number in base `base` (= largest symbol + 1),
-// most significant first: numeric order == lexicographic order, the sentinel (0) is the
-// smallest digit, and no bits are wasted when the alphabet is not a power of two
-// (DNA + sentinel: base 5, 17 symbols in 40 bits).  Three aligned 16-byte loads when
-// C <= 32 (statically indexed: no scratch), byte loads otherwise.
-// A 64-bit multiply per symbol would cost more than everything else in the kernel, so the
-// symbols are taken G at a time with base^G <= 2^24: inside a group the Horner steps are
-// 24-bit multiply-adds, and the 64-bit accumulator is touched once per group (DNA: G = 10,
-// two groups for 17 symbols).  G is one of four compile-time sizes so that the group ends
-// are static; the last group is the short one.
-// Bases up to 6 (DNA + sentinel = 5) go four symbols at a time: the weights base^3, base^2, base, 1 of a
-// word's symbols fit a byte each, so one v_dot4_u32_u8 is the Horner step of a whole word; three words
-// (base^12 < 2^32) are joined with 24-bit multiply-adds before the 64-bit accumulator is touched.  17
-// symbols: 5 dot products, 3 short multiply-adds and one long one instead of 17 extract-multiply-add steps
-// (the key kernel is bound by vector instructions, not by memory).
-struct pkey_cfg {
-    uint32_t base, C;
-    uint32_t G;    // 10, 6, 4 or 3: the largest of these with base^G <= 2^24
-    uint32_t powG; // base^G
-    uint32_t powR; // base^(C mod G)
-    uint32_t dot;   // base <= 6: the dot-product form below
-    uint32_t coef4; // base^3 | base^2 << 8 | base << 16 | 1 << 24
-    uint32_t B4, B12, Br; // base^4, base^12, base^(C mod 4)
-    uint32_t powT;  // weight of the last, short group: base^(4 * ((C / 4) mod 3) + C mod 4)
-};
-static inline pkey_cfg pkey_make(uint32_t base, uint32_t C)
-{
-    pkey_cfg k{base, C, base <= 5 ? 10u : (base <= 16 ? 6u : (base <= 64 ? 4u : 3u)), 1, 1, 0, 0, 1, 1, 1, 1};
-    for (uint32_t i = 0; i < k.G; ++i) k.powG *= base;
-    for (uint32_t i = 0; i < C % k.G; ++i) k.powR *= base;
-    if (base >= 2 && base <= 6 && C <= 32) {
-        k.dot = 1;
-        k.coef4 = (base * base * base) | (base * base) << 8 | base << 16 | 1u << 24;
-        for (uint32_t i = 0; i < 4; ++i) k.B4 *= base;
-        for (uint32_t i = 0; i < 12; ++i) k.B12 *= base;
-        for (uint32_t i = 0; i < C % 4; ++i) k.Br *= base;
-        for (uint32_t i = 0; i < 4 * ((C / 4) % 3) + C % 4; ++i) k.powT *= base;
-    }
-    return k;
-}
-// kw[k] holds symbols 4k .. 4k+3 of the prefix, the first one in the low byte
-template <int NW> __device__ __forceinline__ uint64_t prefix_key_dot(const uint32_t (&kw)[NW], const pkey_cfg &kc)
-{
-    const uint32_t nw = kc.C >> 2, r = kc.C & 3u;
-    uint64_t acc = 0;
-    uint32_t g = 0;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) {
-        if ((uint32_t)k < nw) { // uniform
-            g = __builtin_amdgcn_udot4(kw[k], kc.coef4, __umul24(g, kc.B4), false);
-            if (k % 3 == 2) { // static
-                acc = acc * kc.B12 + g;
-                g = 0;
-            }
-        } else if ((uint32_t)k == nw && r) { // uniform
-            g = __builtin_amdgcn_udot4(kw[k], kc.coef4 >> (8u * (4u - r)), __umul24(g, kc.Br), false);
-        }
-    }
-    if (kc.powT > 1) acc = acc * kc.powT + g; // uniform
-    return acc;
-}
-template <int G>
-__device__ __forceinline__ uint64_t prefix_key_grouped(const uint64_t (&q)[4], const pkey_cfg &kc)
-{
-    uint64_t acc = 0;
-    uint32_t g = 0;
-#pragma unroll
-    for (uint32_t s = 0; s < 32; ++s) {
-        if (s < kc.C) { // uniform
-            g = __umul24(g, kc.base) + (uint32_t)((q[s >> 3] >> (8u * (s & 7u))) & 0xFFull);
-            if ((s + 1) % G == 0) { // static
-                acc = acc * kc.powG + g;
-                g = 0;
-            }
-        }
-    }
-    if (kc.C % G) acc = acc * kc.powR + g; // uniform
-    return acc;
-}
-__device__ __forceinline__ uint64_t prefix_key_of(const uint64_t (&q)[4], const pkey_cfg &kc)
-{
-    if (kc.dot) { // uniform
-        const uint32_t kw[8] = {(uint32_t)q[0], (uint32_t)(q[0] >> 32), (uint32_t)q[1], (uint32_t)(q[1] >> 32),
-                                (uint32_t)q[2], (uint32_t)(q[2] >> 32), (uint32_t)q[3], (uint32_t)(q[3] >> 32)};
-        return prefix_key_dot<8>(kw, kc);
-    }
-    switch (kc.G) { // uniform
-    case 10: return prefix_key_grouped<10>(q, kc);
-    case 6: return prefix_key_grouped<6>(q, kc);
-    case 4: return prefix_key_grouped<4>(q, kc);
-    default: return prefix_key_grouped<3>(q, kc);
-    }
-}
-__device__ __forceinline__ uint64_t prefix_key(const uint8_t *__restrict__ T, uint64_t p, const pkey_cfg &kc)
-{
-    if (kc.C <= 32) {
-        uint64_t q[4];
-        load_bytes32(T, p, q);
-        return prefix_key_of(q, kc);
-    }
-    uint64_t acc = 0;
-    for (uint32_t s = 0; s < kc.C; ++s) acc = acc * kc.base + (uint64_t)T[p + s];
-    return acc;
-}
-
-// Key and window of a suffix for DNA-like texts with everything static: C key symbols of a base <= 6, a window
-// of CW two-bit codes.  The bytes text[p - CW .. p + C) come from the staged tile as nine aligned words and
-// one byte-align step each; window and key are dot products (sx_window.hpp, prefix_key_dot).  The key kernel
-// is bound by instruction issue (260 instructions per suffix with run-time C, base and window shape: 2.0 ms
-// at 1 GiB); this form needs about 90.
-template <int C, int CW, int B>
-__device__ __forceinline__ uint64_t key_and_window_dna(const uint8_t *img, uint32_t off, const pkey_cfg &kc,
-                                                       uint32_t kbits)
-{
-    static_assert(B == 2 || B == 3, "two-bit codes (up to 4 symbols) or three-bit codes (5 ... 8 symbols)");
-    static_assert(C >= 1 && CW >= 1 && CW * B <= 28 && C + CW <= 32, "window and key inside one 32-byte span");
-    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(img + (off & ~3u));
-    const uint32_t sh = off & 3u;
-    uint32_t raw[9], W[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) raw[k] = w32[k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) W[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh); // bytes 4k .. 4k+3 of the span
-    W[8] = 0;
-    // window: span bytes 0 .. CW-1, the farthest symbol first (wnd_from_bytes).  Two-bit codes: the weights 64, 16, 4,
-    // 1 of a word's symbols fit a byte each, one dot product per word; three-bit codes: 512 does not, two symbols
-    // (weights 8, 1) per dot product.
-    uint32_t a = 0;
-#pragma unroll
-    for (int k = 0; k < (CW + 3) / 4; ++k) {
-        constexpr uint32_t wcoef = (1u << 24) | (1u << (16 + 2)) | (1u << (8 + 4)) | (1u << 6);
-        const int nsym = CW - 4 * k < 4 ? CW - 4 * k : 4; // (static: the loop is unrolled)
-        if (B == 2) {
-            a = __builtin_amdgcn_udot4(W[k], wcoef >> ((8 * (4 - nsym)) & 31), a << (nsym * 2), false);
-        } else {
-            const int nh = nsym < 2 ? nsym : 2, nl = nsym - nh;
-            a = __builtin_amdgcn_udot4(W[k], nh == 2 ? 0x00000108u : 0x00000001u, a << (3 * nh), false);
-            if (nl) a = __builtin_amdgcn_udot4(W[k], nl == 2 ? 0x01080000u : 0x00010000u, a << (3 * nl), false);
-        }
-    }
-    constexpr uint32_t bias = ((1u << (B * CW)) - 1u) / ((1u << B) - 1u); // a one in each code field
-    const uint32_t wnd = ((a - bias) << kCntBits) | (uint32_t)CW;
-    // key: span bytes CW .. CW + C
-    constexpr int NW = (C + 3) / 4, R = C % 4, d0 = CW / 4, sb = 8 * (CW % 4);
-    static_assert(d0 + NW <= 8, "the key's words end inside the span");
-    uint64_t acc = 0;
-    uint32_t g = 0;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) {
-        const uint32_t kw = sb ? (W[d0 + k] >> sb) | (W[d0 + k + 1] << ((32 - sb) & 31)) : W[d0 + k];
-        if (k < C / 4) {
-            g = __builtin_amdgcn_udot4(kw, kc.coef4, k % 3 ? __umul24(g, kc.B4) : 0u, false);
-            if (k % 3 == 2) {
-                acc = k == 2 ? (uint64_t)g : acc * kc.B12 + g;
-                g = 0;
-            }
-        } else {
-            g = __builtin_amdgcn_udot4(kw, kc.coef4 >> ((8 * (4 - R)) & 31), __umul24(g, kc.Br), false);
-        }
-    }
-    if ((C / 4) % 3 || R) acc = acc * kc.powT + g;
-    return acc | (uint64_t)wnd << kbits;
-}
-
-// ---- dense keys for texts of four symbols (A C G T: the symbols 1 .. 4, the sentinel 0) ------------------------------
-// The base-5 key leaves a fifth of the key space per symbol unused (no symbol is 0 before the end of the text), and
-// inside a sub-bucket of the hybrid sort -- a range of 2^16 key values -- the keys that do occur sit in clumps: the
-// local sort's bins fill unevenly, and a wave's ranking inside the bins takes as many steps as its fullest bin
-// (8 - 10 on random DNA; 3.36 ms at 1 GiB, 2.83 with the steps capped at 5).  Two bits a symbol use every key value:
-//     key = (sum over the C symbols of (symbol - 1) * 4^(C - 1 - i)) << lenbits | (symbols before the text's end)
-// A suffix that runs into the sentinel counts it and the padding behind it as the smallest symbol, and the length
-// field puts it in front of every suffix that has real symbols there: the order of the base-5 keys, and two suffixes
-// have equal keys exactly when they did (same C symbols, none at the end of the text).  The sum comes from the same
-// dot products with base 4 (symbols as they are: sum(symbol * 4^k), a constant too large), minus the constant, plus
-// what the z = C - len zeros at the end took too much.
-__device__ __forceinline__ uint64_t dense4_finish(uint64_t raw, uint32_t C, uint32_t z, uint32_t lenbits)
-{
-    const uint64_t ones = 0x5555555555555555ull; // 4^k summed: 0b...010101
-    const uint64_t k0 = ones & ((1ull << (2u * C)) - 1ull), corr = z ? ones & ((1ull << (2u * z)) - 1ull) : 0ull;
-    return ((raw - k0 + corr) << lenbits) | (uint64_t)(C - z);
-}
-__device__ __forceinline__ uint32_t dense4_zeros(uint64_t p, uint32_t C, uint64_t n) { return p + C > n ? (uint32_t)(p + C - n) : 0u; }
 
 // One workgroup per classification tile (4096 text positions): the tile's LMS positions are
 // listed in LDS from the LMS bit array, then every thread turns listed positions into
@@ -255,24 +74,8 @@ __global__ __launch_bounds__(kBlock) void lms_tile_keys_kernel(const uint8_t *__
     for (uint32_t i = (uint32_t)t; i < total; i += kBlock) {
         const uint32_t p = spos[i];
         uint64_t key;
-        if (CS > 0 && p >= (uint32_t)WS) { // (everywhere but at the very start of the text)
-            key = key_and_window_dna<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1), (CS > 0 ? BS : 2)>(img, (uint32_t)((uint64_t)(p - (uint32_t)WS) - origin), kc, kbits);
-            if (dense_n) { // (uniform) the key bits again, dense; the window above them stays
-                const uint64_t kmask = (1ull << kbits) - 1ull;
-                key = (key & ~kmask) | dense4_finish(key & kmask /* the sum is below 4^C * 4/3 < 2^(2C+1) <= 2^kbits */, kc.C, dense4_zeros(p, kc.C, dense_n - 1), lenbits);
-            }
-        } else if (CS > 0 && dense_n) {
-            uint64_t raw = 0;
-            for (uint32_t s2 = 0; s2 < kc.C; ++s2) raw = raw * 4u + (uint64_t)T[(uint64_t)p + s2];
-            key = dense4_finish(raw, kc.C, dense4_zeros(p, kc.C, dense_n - 1), lenbits);
-            if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
-        } else if (CS > 0) {
-            // the first few positions of the text, in the static forms: symbol by symbol from memory.  (With the general
-            // form below compiled in here, the compiler evaluated its 64 uniform tests once per workgroup and parked them
-            // in a register's lanes -- 130 instructions up front for a path that a handful of suffixes of the whole text take.)
-            key = 0;
-            for (uint32_t s = 0; s < kc.C; ++s) key = key * kc.base + (uint64_t)T[(uint64_t)p + s];
-            if (wcfg.CW) key |= (uint64_t)wnd_fill<uint32_t>(T, p, wcfg) << kbits;
+        if (CS > 0) {
+            key = lms_key_static<(CS > 0 ? CS : 1), (CS > 0 ? WS : 1), (CS > 0 ? BS : 2)>(img, origin, p, T, kc, kbits, wcfg, dense_n, lenbits);
         } else {
             if (kc.C <= 32) { // uniform
                 uint64_t q[4];
@@ -1346,7 +1149,16 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         sx_textkey tkey = {ti.T, base, C, 1u, 1u, (uint32_t)kbits, wcfg.CW ? 1u : 0u};
         for (uint32_t i = 0; i < 3; ++i) tkey.pow3 *= base;
         for (uint32_t i = 0; i < C % 3; ++i) tkey.powR *= base;
-        if (text_keyed) {
+        // The LMS sort of a four-letter text likewise (sx_lmskey, round 4): the hybrid sort's first pass lists the LMS
+        // suffixes of its piece of the text and computes their dense keys itself -- no key kernel, and 13 bytes an LMS suffix
+        // (key, position, first digit) that are neither written nor read back.  Same switch.
+        const pkey_cfg lms_kc = pkey_make(dense4 ? 4u : base, C);
+        const uint32_t lms_shape = (!all_suffixes && lms_kc.dot && wcfg.B == 2 && wcfg.CW) ? lms_key_shape(C, wcfg.CW, 2) : 0u;
+        const bool lms_keyed = !all_suffixes && hybrid && dense4 && sort_db == 8 && !ctx->text_keys_off && lms_shape != 0 &&
+                               sx_sort_lms_keys_applies(m, ti.ntiles, lms_shape);
+        const sx_lmskey lkey = {ti.T, (const uint16_t *)ti.lmsbits, (const uint32_t *)tile_off, ti.ntiles, (uint32_t)m, lms_kc, wcfg,
+                                (uint32_t)kbits, lenbits, (uint64_t)ti.n + 1, lms_shape};
+        if (text_keyed || lms_keyed) {
         } else if (all_suffixes && C <= 12) {
             const pkey_cfg kc = pkey_make(base, C);
             const dim3 grid16(sx_div_up(m, kBlock * 16));
@@ -1393,7 +1205,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         bool listed = false; // the members of groups of equal keys are in (apos, ap, head), A of them
         if (hybrid) {
             // three stable passes on the top 24 bits, then the sub-buckets in LDS: positions, windows and ties in one go
-            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - top_bits, kbits, &in_b, all_suffixes, true, 8, text_keyed ? &tkey : nullptr));
+            SX_TRY(sx_sort_pairs(ctx, ka, va, kb, vb, m, kbits - top_bits, kbits, &in_b, all_suffixes, true, 8, text_keyed ? &tkey : nullptr,
+                                 lms_keyed ? &lkey : nullptr));
             const uint64_t *kin = in_b ? kb : ka;
             const uint32_t *vin = in_b ? vb : va;
             uint32_t *vo = in_b ? va : vb;
@@ -1421,7 +1234,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 vs = vo;
                 ks = nullptr; // (the sorted keys are not written by this path; nothing below reads them)
                 listed = true;
-                ctx->stats.sort_local = 1u | (res[1] & 2u) | (top_bits == 32 ? 4u : 0u); // (bit 1: some workgroup ordered its pairs by stable passes)
+                ctx->stats.sort_local = 1u | (res[1] & 2u) | (top_bits == 32 ? 4u : 0u) | ((text_keyed || lms_keyed) ? 8u : 0u); // (bit 1: some workgroup ordered its pairs by stable passes)
             } else {
                 // a sub-bucket too long for a workgroup (a repeated prefix): plain LSD passes over all key bits from here
                 // -- unless the workgroups that did finish have listed more tied suffixes already than the refinement

@@ -22,6 +22,7 @@
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
 #include "sx_internal.hpp"
+#include "sx_lmskey.hpp"
 
 namespace sx {
 
@@ -500,6 +501,330 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
                                                   wcount, goff, scan_lds, skey);
 }
 
+// ---- the first pass of a four-letter text's LMS sort, keys computed on the way (sx_lmskey) -----------------------------------
+// The key kernel wrote 13 bytes an LMS suffix (key, position, first digit) that the first pass read back at once: 8.3 GB of
+// the 1 GiB DNA build's 91.  Here the first pass's tiles are pieces of the TEXT: a workgroup lists its piece's LMS positions
+// from the classification's bit array, computes their keys from the text staged in LDS (the value lms_tile_keys_kernel
+// stores) and goes on as radix_scatter_tile does.  Tiles hold as many pairs as their piece has LMS suffixes, in text order,
+// so the pass is stable like any other.  1 GiB of DNA, same box: key kernel 1.16 + histogram 0.11 + scatter 1.70 ms before,
+// histogram 0.42 + scatter 1.85 now; the whole build 21.3 - 21.4 -> 20.6 - 21.0 ms.
+#if SX_RADIX_THREADS == 1024 && SX_RADIX_ITEMS == 8
+#define SX_RADIX_LMS_PASS 1
+// Tiles of the pass: the text in blocks of kLmsBlockCls classification tiles.  Four of them (16 384 positions) hold at most a
+// radix tile's 8192 LMS suffixes -- no two are neighbours --, 5 000 on uniform DNA.  (SX_LMS_BLOCK_CLS 6, measured: 24 576
+// positions, 7 500 LMS suffixes of uniform DNA, a tile nearly as full as any other pass's; a block with more than a radix
+// tile holds is then taken as two halves, so every block owns two rows of the tile table, the second one empty unless the
+// block is split, and a workgroup has to look the block's counts up before it can ask for its text: the pass took 2.8
+// instead of 2.1 ms.)
+#ifndef SX_LMS_BLOCK_CLS
+#define SX_LMS_BLOCK_CLS 4
+#endif
+constexpr int kLmsBlockCls = SX_LMS_BLOCK_CLS;
+constexpr int kLmsRows = kLmsBlockCls * (kClsTile / 2) > kRadixTile ? 2 : 1; // rows of the tile table a block owns
+constexpr int kLmsBlock = kLmsBlockCls * kClsTile; // text positions of a block
+constexpr int kLmsPerThread = kLmsBlock / kRT;     // positions whose LMS bits a thread lists
+static_assert((kLmsPerThread == 16 || kLmsPerThread == 24) && kLmsPerThread * kRT == kLmsBlock, "two or three bytes of the bit array a thread");
+static_assert((kLmsBlockCls / kLmsRows) * (kClsTile / 2) <= kRadixTile && kLmsBlockCls % kLmsRows == 0, "a row's span cannot overflow a radix tile");
+static_assert(kLmsBlock <= 65536, "positions inside a tile are kept as 16-bit offsets");
+// The tile's text in LDS, two bits a symbol: word q holds text[pos0 - 16 + 16 q ...), sixteen symbols, the first one in the
+// top bits, codes symbol - 1 (the sentinel and the padding behind it: 0).  Read as one big-endian bit stream, the dense key
+// of suffix p (dense4_finish) is the 2 C bits from symbol p on and its window (sx_window.hpp: the nearest symbol in the
+// lowest field) the 2 W bits in front of them: three words and two funnel shifts a suffix, where the byte image cost nine
+// words, eight byte-align steps and eight dot products (a hundred instructions: this pass was bound by them).
+constexpr int kLmsPackWords = (kLmsBlock + 64) / 16;
+constexpr size_t kLmsImgAt = (size_t)kRW * 256 * sizeof(uint32_t);          // behind the per-wave counters
+constexpr size_t kLmsPosAt = kLmsImgAt + (size_t)kLmsPackWords * sizeof(uint32_t) + 16; // the listed positions behind the text
+static_assert(kLmsPosAt + 2 * (size_t)kRadixTile <= sizeof(uint64_t) * kRadixTile, "text and positions fit the key image");
+
+struct lms_span {
+    uint32_t pos0, npos; // first text position, positions (a multiple of kClsTile; 0: the row is empty)
+};
+// what row `slot` of the pass's tile table stands for
+__device__ __forceinline__ lms_span lms_slot_span(const sx_lmskey &lk, uint32_t slot)
+{
+    lms_span sp = {0, 0};
+    if (kLmsRows == 1) { // (static) no look-up: a block is a row
+        const uint32_t c0 = slot * kLmsBlockCls;
+        if (c0 < lk.cls_tiles) sp = {c0 * (uint32_t)kClsTile, (c0 + kLmsBlockCls < lk.cls_tiles ? (uint32_t)kLmsBlockCls : lk.cls_tiles - c0) * (uint32_t)kClsTile};
+        return sp;
+    }
+    const uint32_t c0 = (slot >> 1) * kLmsBlockCls;
+    const uint32_t c1 = c0 + kLmsBlockCls < lk.cls_tiles ? c0 + kLmsBlockCls : lk.cls_tiles;
+    const uint32_t cm = c0 + kLmsBlockCls / 2 < lk.cls_tiles ? c0 + kLmsBlockCls / 2 : lk.cls_tiles;
+    if (c0 >= lk.cls_tiles) return sp;
+    const uint32_t o0 = lk.tile_off[c0], o1 = c1 < lk.cls_tiles ? lk.tile_off[c1] : lk.m;
+    if (o1 - o0 <= (uint32_t)kRadixTile) {
+        if (!(slot & 1u)) sp = {c0 * (uint32_t)kClsTile, (c1 - c0) * (uint32_t)kClsTile};
+    } else if (slot & 1u) {
+        sp = {cm * (uint32_t)kClsTile, (c1 - cm) * (uint32_t)kClsTile};
+    } else {
+        sp = {c0 * (uint32_t)kClsTile, (cm - c0) * (uint32_t)kClsTile};
+    }
+    return sp;
+}
+
+__device__ __forceinline__ uint32_t lms_pack16(const uint4 &v, bool zeros)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = w[k];
+        if (zeros) x += ((x - 0x01010101u) & ~x & 0x80808080u) >> 7; // a zero byte counts as symbol 1: code 0
+        out = (out << 8) | (__builtin_amdgcn_udot4(x, 0x01041040u, 0u, false) - 85u); // sum (symbol - 1) * 4^(3 - j)
+    }
+    return out;
+}
+template <int THREADS, bool FLIGHT>
+__device__ __forceinline__ void lms_tile_pack(const sx_lmskey &lk, const lms_span &sp, uint32_t *pk)
+{
+    if (!FLIGHT) { // (the scatter kernel has no registers to spare for a second load in flight: two workgroups a CU at 64)
+        const uint64_t text_end = (uint64_t)lk.cls_tiles * kClsTile + 128;
+        for (uint32_t q = threadIdx.x; q < (sp.npos + 64u) / 16u; q += THREADS) {
+            const uint64_t at = (uint64_t)sp.pos0 + 16ull * q;
+            uint4 v = {0, 0, 0, 0};
+            if (at >= 16 && at <= text_end) v = *reinterpret_cast<const uint4 *>(lk.T + at - 16);
+            pk[q] = lms_pack16(v, at < 16 || at >= lk.dense_n);
+        }
+        return;
+    }
+    constexpr int ROUNDS = (kLmsPackWords + THREADS - 1) / THREADS;
+    const uint64_t text_end = (uint64_t)lk.cls_tiles * kClsTile + 128; // the build's copy of the text is padded that far
+    const uint32_t words = (sp.npos + 64u) / 16u;
+    uint4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) { // (every load asked for before the first is packed)
+        const uint32_t q = threadIdx.x + (uint32_t)r * THREADS;
+        const uint64_t at = (uint64_t)sp.pos0 + 16ull * q; // the word holds text[at - 16, at)
+        v[r] = {0, 0, 0, 0};
+        if (q < words && at >= 16 && at <= text_end) v[r] = *reinterpret_cast<const uint4 *>(lk.T + at - 16);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t q = threadIdx.x + (uint32_t)r * THREADS;
+        const uint64_t at = (uint64_t)sp.pos0 + 16ull * q;
+        if (q < words) pk[q] = lms_pack16(v[r], at < 16 || at >= lk.dense_n /* text[n] = 0 and the padding; in front of the text */);
+    }
+}
+
+// (key, window) word of LMS suffix p -- what lms_key_static returns for dense keys of CS symbols and windows of WS two-bit
+// codes --, WND false: without the window.  pos0: first position of the span that pk holds.
+template <int CS, int WS, bool WND>
+__device__ __forceinline__ uint64_t lms_key_packed(const uint32_t *pk, uint32_t pos0, uint32_t p, const sx_lmskey &lk)
+{
+    static_assert(CS + WS <= 32, "key and window inside 64 bits of the stream");
+    if (p < (uint32_t)WS) // the first few positions of the text: symbol by symbol from memory
+        return lms_key_static<CS, WS, 2>(nullptr, 0, p, lk.T, lk.kc, lk.kbits, lk.wcfg, lk.dense_n, lk.lenbits);
+    const uint32_t s0 = p - (uint32_t)WS - pos0 + 16u; // symbol of the stream where the window begins
+    const uint32_t w = s0 >> 4, sh = (s0 & 15u) * 2u;
+    const uint32_t a = pk[w], b = pk[w + 1], c = pk[w + 2];
+    const uint32_t hi = sh ? (a << sh) | (b >> (32u - sh)) : a, lo = sh ? (b << sh) | (c >> (32u - sh)) : b;
+    const uint64_t X = (uint64_t)hi << 32 | lo; // symbols p - WS ... p - WS + 31
+    const uint64_t D = (X >> (64 - 2 * (WS + CS))) & ((1ull << (2 * CS)) - 1ull);
+    uint64_t key = (D << lk.lenbits) | (uint64_t)((uint32_t)CS - dense4_zeros(p, (uint32_t)CS, lk.dense_n - 1));
+    if (WND) key |= (uint64_t)(((uint32_t)(X >> (64 - 2 * WS)) << kCntBits) | (uint32_t)WS) << lk.kbits;
+    return key;
+}
+
+// Lists the span's LMS suffixes and computes the keys of this thread's slots (slot i of the tile: wave w, item k, lane l
+// <-> i = 512 w + 64 k + l, radix_scatter_tile's order); pos16[k / 2] holds the offsets of items k, k + 1 inside the span.
+// Returns their number.  Ends behind a barrier; scan_lds is free again.
+template <int CS, int WS, int BS>
+__device__ __forceinline__ uint32_t lms_tile_keys(const sx_lmskey &lk, const lms_span &sp, uint32_t *pk, uint16_t *spos, uint32_t *scan_lds,
+                                                  uint64_t (&key)[kRadixItems], uint32_t (&pos16)[kRadixItems / 2])
+{
+    static_assert(BS == 2, "two-bit codes");
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    uint32_t bits = 0;
+    if ((uint32_t)t * kLmsPerThread < sp.npos) { // the thread's positions: two or three bytes of the bit array
+        if (kLmsPerThread == 16) {
+            bits = (uint32_t)lk.lmsbits[(size_t)sp.pos0 / 16 + (uint32_t)t];
+        } else {
+            const uint8_t *by = reinterpret_cast<const uint8_t *>(lk.lmsbits) + (size_t)sp.pos0 / 8 + (kLmsPerThread / 8) * (uint32_t)t;
+            bits = (uint32_t)by[0] | (uint32_t)by[1] << 8 | (uint32_t)by[2] << 16;
+        }
+        const uint32_t left = sp.npos - (uint32_t)t * kLmsPerThread; // (a span is whole classification tiles, not whole threads)
+        if (left < (uint32_t)kLmsPerThread) bits &= (1u << left) - 1u;
+    }
+    lms_tile_pack<kRT, false>(lk, sp, pk);
+    const uint32_t mine = (uint32_t)__popc(bits);
+    const uint32_t inc = wave_inclusive_scan<OpAdd>(mine);
+    if (lane == kWave - 1) scan_lds[w] = inc;
+    __syncthreads();
+    uint32_t at = inc - mine, cnt = 0;
+#pragma unroll
+    for (int ww = 0; ww < kRW; ++ww) {
+        const uint32_t x = scan_lds[ww];
+        if (ww < w) at += x;
+        cnt += x;
+    }
+    if (cnt > (uint32_t)kRadixTile) cnt = (uint32_t)kRadixTile; // (cannot be: a row's span holds at most that many, or the block was split)
+    while (bits) {
+        const int i = __ffs(bits) - 1;
+        bits &= bits - 1u;
+        if (at < (uint32_t)kRadixTile) spos[at] = (uint16_t)(t * kLmsPerThread + i);
+        ++at;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = (uint32_t)w * (kWave * kRadixItems) + (uint32_t)k * kWave + (uint32_t)lane;
+        const uint32_t off = i < cnt ? (uint32_t)spos[i] : 0u;
+        key[k] = ~0ull;
+        if (i < cnt) key[k] = lms_key_packed<CS, WS, true>(pk, sp.pos0, sp.pos0 + off, lk);
+        if (k & 1) pos16[k / 2] |= off << 16;
+        else pos16[k / 2] = off;
+    }
+    __syncthreads(); // (text and positions are dead: the image is the scatter's from here)
+    return cnt;
+}
+
+// The digit counts of every row of the tile table.  No order is needed here, so a workgroup is four waves and every thread
+// takes the LMS positions of its own 64 (96) positions.
+constexpr int kLmsHistThreads = 256;
+template <int CS, int WS, int BS>
+__global__ __launch_bounds__(kLmsHistThreads) void radix_hist_lms_kernel(sx_lmskey lk, int shift, uint32_t mask, uint32_t *__restrict__ hist, uint32_t ntiles)
+{
+    constexpr int ND = 256, kCopies = 4, kPer = kLmsBlock / kLmsHistThreads, kWords = kPer / 32; // words of the bit array a thread
+    static_assert(kPer % 32 == 0 && ND == kLmsHistThreads, "a thread per digit, whole 32-bit words of LMS bits a thread");
+    __shared__ uint32_t pk[kLmsPackWords];
+    __shared__ uint32_t hh[kCopies][ND];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return; // uniform
+    const int t = (int)threadIdx.x;
+    const lms_span sp = lms_slot_span(lk, tile);
+    if (sp.npos == 0) { // (an unsplit block's second row)
+        hist[(uint64_t)tile * ND + t] = 0;
+        return;
+    }
+    for (int i = t; i < kCopies * ND; i += kLmsHistThreads) (&hh[0][0])[i] = 0;
+    uint32_t bits[kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) bits[j] = 0;
+    if ((uint32_t)t * kPer < sp.npos) {
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lk.lmsbits) + (size_t)sp.pos0 / 8) + (uint32_t)kWords * (uint32_t)t;
+        const uint32_t left = sp.npos - (uint32_t)t * kPer; // (a span is whole classification tiles, not whole threads)
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) {
+            bits[j] = bw[j];
+            if (left < 32u * (j + 1)) bits[j] = left > 32u * j ? bits[j] & ((1u << (left - 32u * j)) - 1u) : 0u;
+        }
+    }
+    lms_tile_pack<kLmsHistThreads, true>(lk, sp, pk);
+    __syncthreads();
+    uint32_t *h = hh[t & (kCopies - 1)];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        uint32_t bj = bits[j];
+        while (bj) {
+            const int i = __ffs(bj) - 1;
+            bj &= bj - 1u;
+            const uint32_t p = sp.pos0 + (uint32_t)(t * kPer + 32 * j + i);
+            atomicAdd(&h[(uint32_t)(lms_key_packed<CS, WS, false>(pk, sp.pos0, p, lk) >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int cpy = 0; cpy < kCopies; ++cpy) sum += hh[cpy][t];
+    hist[(uint64_t)tile * ND + t] = sum;
+}
+
+template <int CS, int WS, int BS>
+__global__ __launch_bounds__(kRT) SX_WAVES_PER_EU(8) void radix_scatter_lms_kernel(
+    sx_lmskey lk, uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
+    uint32_t ntiles, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift, uint32_t next_mask)
+{
+    constexpr int ND = 256;
+    __shared__ uint64_t skey[kRadixTile]; // counters, text, positions; then the tile in digit order: keys, then values
+    __shared__ uint32_t goff[ND];
+    __shared__ uint32_t scan_lds[kRW];
+    static_assert(radix_alias<8>::value, "the per-wave counters live in the key image");
+    uint32_t *wcount = reinterpret_cast<uint32_t *>(skey);
+    uint32_t *pk = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(skey) + kLmsImgAt);
+    uint16_t *spos = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(skey) + kLmsPosAt);
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t per_xcd = (ntiles + 7u) / 8u; // (tile order: see radix_scatter_kernel)
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return; // uniform
+    const lms_span sp = lms_slot_span(lk, tile);
+    if (sp.npos == 0) return; // uniform (an unsplit block's second row)
+    for (int i = t; i < kRW * ND; i += kRT) wcount[i] = 0;
+    const uint32_t first_out = t < ND ? offs[(uint64_t)tile * ND + t] : 0u; // asked for now, needed after the ranking
+    uint64_t key[kRadixItems];
+    uint32_t pos16[kRadixItems / 2];
+    const uint32_t cnt = lms_tile_keys<CS, WS, BS>(lk, sp, pk, spos, scan_lds, key, pos16);
+    const uint32_t wave0 = (uint32_t)w * (kWave * kRadixItems);
+    uint32_t lpos[kRadixItems]; // [12:0] rank within (wave, digit), then slot in the tile's digit order; [31:16] digit
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = wave0 + (uint32_t)k * kWave + (uint32_t)lane;
+        const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+        lpos[k] = wave_rank_inorder<8, false>(d, i < cnt, wcount + w * ND) | (d << 16);
+    }
+    __syncthreads();
+    {
+        uint32_t s = 0;
+        if (t < ND) {
+#pragma unroll
+            for (int ww = 0; ww < kRW; ++ww) {
+                const uint32_t x = wcount[ww * ND + t];
+                wcount[ww * ND + t] = s;
+                s += x;
+            }
+        }
+        const uint32_t inc = wave_inclusive_scan<OpAdd>(s);
+        if (lane == kWave - 1) scan_lds[w] = inc;
+        __syncthreads();
+        uint32_t ex = inc - s; // first slot of the thread's digit inside the tile
+        for (int ww = 0; ww < w; ++ww) ex += scan_lds[ww];
+        if (t < ND) {
+#pragma unroll
+            for (int ww = 0; ww < kRW; ++ww) wcount[ww * ND + t] += ex; // first slot of (wave, digit)
+            goff[t] = first_out - ex;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) lpos[k] = (lpos[k] & 0xFFFFu) + wcount[w * ND + (lpos[k] >> 16)];
+    __syncthreads(); // the counters share the key image: every slot is known before the first key lands
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = wave0 + (uint32_t)k * kWave + (uint32_t)lane;
+        if (i < cnt) skey[lpos[k]] = key[k];
+    }
+    __syncthreads();
+    uint32_t dstv[kRadixItems]; // destinations of the slots this thread copies out
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
+        dstv[k] = 0;
+        if (i < cnt) {
+            const uint64_t kk = skey[i];
+            const uint32_t d = (uint32_t)(kk >> shift) & mask;
+            dstv[k] = goff[d] + i;
+            kout[dstv[k]] = kk;
+            if (dig_out) dig_out[dstv[k]] = (uint8_t)((uint32_t)(kk >> next_shift) & next_mask); // uniform test
+        }
+    }
+    __syncthreads();
+    uint32_t *sval = reinterpret_cast<uint32_t *>(skey);
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = wave0 + (uint32_t)k * kWave + (uint32_t)lane;
+        if (i < cnt) sval[lpos[k]] = sp.pos0 + ((pos16[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRadixItems; ++k) {
+        const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
+        if (i < cnt) vout[dstv[k]] = sval[i];
+    }
+}
+#else
+#define SX_RADIX_LMS_PASS 0
+#endif
+
 } // namespace sx
 
 using namespace sx;
@@ -526,9 +851,30 @@ void *sx_sort_digit_buffer(sx_ctx *ctx, uint64_t n, int digit_bits)
     return (uint8_t *)ctx->slab[SX_SLAB_SORT].p + ((size_t)ntiles + nchunks + 1) * ((size_t)1 << digit_bits) * sizeof(uint32_t);
 }
 
+// The LMS-keyed first pass (sx_lmskey): its tile table -- kLmsRows rows per kLmsBlockCls classification tiles, not one per 8192 pairs --
+// lies in the sort's first key array, which such a sort never reads.
+bool sx_sort_lms_keys_applies(uint64_t m, uint32_t cls_tiles, uint32_t shape)
+{
+#if SX_RADIX_LMS_PASS
+    const uint64_t ntiles1 = (uint64_t)kLmsRows * sx_div_up(cls_tiles, kLmsBlockCls), nchunks1 = sx_div_up(ntiles1, kRadixChunk);
+    if ((ntiles1 + nchunks1 + 1) * 256 * sizeof(uint32_t) > m * sizeof(uint64_t)) return false;
+    switch (shape) {
+    case lms_key_shape(15, 12, 2):
+    case lms_key_shape(16, 11, 2):
+    case lms_key_shape(17, 10, 2):
+    case lms_key_shape(18, 9, 2): return true;
+    default: return false;
+    }
+#else
+    (void)m, (void)cls_tiles, (void)shape;
+    return false;
+#endif
+}
+
 template <int DB>
 static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n, int begin_bit,
-                         int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready, const sx_textkey *text_keys)
+                         int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready, const sx_textkey *text_keys,
+                         const sx_lmskey *lms_keys)
 {
     const sx_textkey no_text = {nullptr, 0, 0, 1, 1, 0, 0};
     constexpr int ND = 1 << DB;
@@ -548,6 +894,61 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
         const int next_shift = shift + DB;
         const bool has_next = next_shift < end_bit;
         const int next_bits = has_next ? (end_bit - next_shift < DB ? end_bit - next_shift : DB) : 0;
+#if SX_RADIX_LMS_PASS
+        if (shift == begin_bit && lms_keys) {
+            if constexpr (DB == 8) {
+                const sx_lmskey &lk = *lms_keys;
+                const uint32_t ntiles1 = (uint32_t)kLmsRows * sx_div_up(lk.cls_tiles, kLmsBlockCls), nchunks1 = sx_div_up(ntiles1, kRadixChunk);
+                if (!sx_sort_lms_keys_applies(n, lk.cls_tiles, lk.shape) || lk.m != n) return sx_fail_msg(ctx, SX_E_INTERNAL, "sort: LMS-keyed first pass");
+                uint32_t *hist1 = (uint32_t *)ka, *sums1 = hist1 + (size_t)ntiles1 * ND, *base1 = sums1 + (size_t)nchunks1 * ND;
+                const uint64_t text_bytes = (uint64_t)lk.cls_tiles * (kClsTile + kClsTile / 8);
+                const uint8_t next_mask8 = has_next ? (uint8_t)((1u << next_bits) - 1u) : 0;
+#define SX_LMS_PASS(CS, WS, BS)                                                                                                          \
+    case lms_key_shape(CS, WS, BS):                                                                                                      \
+        sx_launch(ctx, SX_KC_RADIX_HIST, text_bytes, radix_hist_lms_kernel<CS, WS, BS>, dim3(ntiles1), dim3(kLmsHistThreads), lk, shift, mask, hist1, \
+                  ntiles1);                                                                                                              \
+        break;
+                switch (lk.shape) {
+                    SX_LMS_PASS(15, 12, 2)
+                    SX_LMS_PASS(16, 11, 2)
+                    SX_LMS_PASS(17, 10, 2)
+                    SX_LMS_PASS(18, 9, 2)
+                }
+#undef SX_LMS_PASS
+                if (nchunks1 == 1) {
+                    sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles1 * ND * 12, radix_offsets_small_kernel<ND>, dim3(1), dim3(ND), hist1, ntiles1);
+                } else {
+                    sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles1 * ND * 4, radix_colsum_kernel<ND>, dim3(nchunks1), dim3(ND),
+                              (const uint32_t *)hist1, ntiles1, sums1);
+                    sx_launch(ctx, SX_KC_SCAN, (uint64_t)nchunks1 * ND * 8, radix_bases_kernel<ND>, dim3(1), dim3(ND), sums1, nchunks1, base1);
+                    sx_launch(ctx, SX_KC_SCAN, (uint64_t)ntiles1 * ND * 8, radix_apply_kernel<ND>, dim3(nchunks1), dim3(ND), hist1, ntiles1,
+                              (const uint32_t *)sums1, (const uint32_t *)base1);
+                }
+#define SX_LMS_PASS(CS, WS, BS)                                                                                                          \
+    case lms_key_shape(CS, WS, BS):                                                                                                      \
+        sx_launch(ctx, SX_KC_RADIX_SCATTER, text_bytes + n * (12 + (has_next ? 1 : 0)), radix_scatter_lms_kernel<CS, WS, BS>,            \
+                  dim3(((ntiles1 + 7) / 8) * 8), dim3(kRT), lk, kout, vout, shift, mask, (const uint32_t *)hist1, ntiles1,                \
+                  has_next ? (uint8_t *)dig : (uint8_t *)nullptr, next_shift & 63, (uint32_t)next_mask8);                                 \
+        break;
+                switch (lk.shape) {
+                    SX_LMS_PASS(15, 12, 2)
+                    SX_LMS_PASS(16, 11, 2)
+                    SX_LMS_PASS(17, 10, 2)
+                    SX_LMS_PASS(18, 9, 2)
+                }
+#undef SX_LMS_PASS
+                uint64_t *tk = kin; kin = kout; kout = tk;
+                uint32_t *tv = vin; vin = vout; vout = tv;
+                ++flips;
+                ctx->stats.sort_passes++;
+                continue;
+            } else {
+                return sx_fail_msg(ctx, SX_E_INTERNAL, "sort: LMS-keyed first pass with digits wider than 8 bits");
+            }
+        }
+#else
+        if (lms_keys) return sx_fail_msg(ctx, SX_E_INTERNAL, "sort: LMS-keyed first pass not built");
+#endif
         if (shift == begin_bit && text_keys)
             sx_launch(ctx, SX_KC_RADIX_HIST, n, radix_hist_text_kernel<DB>, dim3(ntiles < SX_HIST_GRID ? ntiles : SX_HIST_GRID), dim3(kHT),
                       *text_keys, n, shift, mask, hist, ntiles);
@@ -596,15 +997,15 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
 
 int sx_sort_pairs(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint64_t n,
                   int begin_bit, int end_bit, int *result_in_b, bool values_are_indices, bool first_digits_ready,
-                  int digit_bits, const sx_textkey *text_keys)
+                  int digit_bits, const sx_textkey *text_keys, const sx_lmskey *lms_keys)
 {
     *result_in_b = 0;
     if (n == 0 || end_bit <= begin_bit) return 0;
     if (n > 0xFFFFFFFFull) return sx_fail_msg(ctx, SX_E_ARG, "sort: n exceeds 32-bit positions");
     switch (digit_bits ? digit_bits : sx_sort_digit_bits(ctx)) {
-    case 9: return sort_pairs_db<9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys);
-    case 10: return sort_pairs_db<10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys);
-    default: return sort_pairs_db<8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys);
+    case 9: return sort_pairs_db<9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys, lms_keys);
+    case 10: return sort_pairs_db<10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys, lms_keys);
+    default: return sort_pairs_db<8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, result_in_b, values_are_indices, first_digits_ready, text_keys, lms_keys);
     }
 }
 

@@ -196,6 +196,7 @@ static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsi
 }
 #define SX_OPAQUE_VGPR(x) ((void)0) /* a register-allocation hint on the GPU */
 #define SX_SCHED_FENCE() ((void)0)  /* a scheduling fence on the GPU */
+#define SX_WAVES_PER_EU(N)          /* a register budget on the GPU */
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned add)
 {
     const int l = emu_lane();

@@ -132,20 +132,42 @@ def test_hybrid_prefix_sort(emu_ctx):
             x[700:760] = x[100:160]      # ties beyond the key: refinement rounds after the local sort
             x[n - 300:n - 260] = x[100:140]
             emu_ctx.set_prefix_symbols(syms)
-            sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
-            emu_ctx.sa_bwt_build_dev(x, n, sigma, sa, bw)
-            st = emu_ctx.last_stats()
             want = oracle.sa_is(x, sigma)
-            assert st["lms_path"] == 1 and st["sort_local"] == (1 if mode == 2 else 5), (mode, sigma, syms, n, st)
-            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (mode, sigma, syms, n)
+            # (four letters, 15 ... 18 key symbols: the first HBM pass lists the LMS suffixes and computes their keys itself --
+            #  radix_scatter_lms_kernel --, bit 3 of sort_local; SX_FLAG_TEXT_KEYS_OFF keeps the key kernel)
+            for text_keys in (True, False):
+                emu_ctx.set_text_keys(text_keys)
+                sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+                emu_ctx.sa_bwt_build_dev(x, n, sigma, sa, bw)
+                st = emu_ctx.last_stats()
+                keyed = 8 if (text_keys and sigma == 5 and 15 <= syms <= 18) else 0
+                assert st["lms_path"] == 1 and st["sort_local"] == (1 if mode == 2 else 5) + keyed, (mode, sigma, syms, n, text_keys, st)
+                assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (mode, sigma, syms, n, text_keys)
+            emu_ctx.set_text_keys(True)
         emu_ctx.set_sort_mode(2)
+        # an LMS suffix at every other position (low, high, low, high ...): more than a radix tile's worth in a block of six
+        # classification tiles, which the keyed first pass then takes as two halves (lms_slot_span)
+        n = 60000
+        x = np.empty(n, np.uint8)
+        x[0::2] = rng.integers(1, 3, size=n // 2)
+        x[1::2] = rng.integers(3, 5, size=n // 2)
+        emu_ctx.set_prefix_symbols(18)
+        want = oracle.sa_is(x, 5)
+        for text_keys in (True, False):
+            emu_ctx.set_text_keys(text_keys)
+            sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+            emu_ctx.sa_bwt_build_dev(x, n, 5, sa, bw)
+            st = emu_ctx.last_stats()
+            assert st["n_lms"] > n // 2 - 2 and st["sort_local"] & 9 == (9 if text_keys else 1), st
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), text_keys
+        emu_ctx.set_text_keys(True)
         # 40 copies of a 60-symbol piece: equal keys crowd a bin of the counting pass, that workgroup takes stable passes
         x = rng.integers(1, 5, size=20000, dtype=np.uint8)
         for i in range(40):
             x[300 + 400 * i:360 + 400 * i] = x[100:160]
         emu_ctx.set_prefix_symbols(17)
         sa = _sa(emu_ctx, x, 5)
-        assert emu_ctx.last_stats()["sort_local"] == 3, emu_ctx.last_stats()
+        assert emu_ctx.last_stats()["sort_local"] & 7 == 3, emu_ctx.last_stats()
         assert (sa == oracle.sa_is(x, 5)).all()
         # one 12-symbol prefix in front of thousands of LMS suffixes: a sub-bucket no workgroup can hold
         unit = np.array([1, 3, 2, 4, 4, 2, 3, 1, 1, 3, 2, 4, 2, 1], np.uint8)
@@ -169,6 +191,7 @@ def test_hybrid_prefix_sort(emu_ctx):
     finally:
         emu_ctx.set_sort_mode(0)
         emu_ctx.set_prefix_symbols(0)
+        emu_ctx.set_text_keys(True)
 
 
 def test_long_repeats_finish_by_comparison(emu_ctx):

@@ -217,7 +217,7 @@ def test_hybrid_prefix_sort(gpu_ctx):
         gpu_ctx.set_prefix_symbols(17)
         gpu_ctx.set_sort_mode(2)
         sa = gpu_ctx.sa_build(x, 5)
-        assert gpu_ctx.last_stats()["sort_local"] == 3, gpu_ctx.last_stats()
+        assert gpu_ctx.last_stats()["sort_local"] & 7 == 3, gpu_ctx.last_stats()
         assert (sa == oracle.sa_is(x, 5)).all()
         # one 14-symbol prefix in front of tens of thousands of LMS suffixes
         unit = np.array([1, 3, 2, 4, 4, 2, 3, 1, 1, 3, 2, 4, 2, 1], np.uint8)

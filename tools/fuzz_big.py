@@ -31,6 +31,7 @@ for k in range(cases):
     ctx.set_sort_mode(int(rng.choice([0, 0, 0, 1, 2, 3])))
     ctx.force_general_path(bool(rng.integers(0, 6) == 0))
     ctx.set_no_direct_sort(bool(rng.integers(0, 3) == 0))
+    ctx.set_text_keys(bool(rng.integers(0, 4)))
     want = oracle.sa_is(x, sigma)
     got = ctx.sa_build(x, sigma)
     st = ctx.last_stats()
@@ -38,5 +39,5 @@ for k in range(cases):
     paths[pk] = paths.get(pk, 0) + 1
     assert (got == want).all(), ("SA", k, sigma, n, kind, st)
     if k % 10 == 9: print(f"{k + 1} cases, {time.time() - t0:.0f} s", flush=True)
-ctx.set_sort_mode(0); ctx.force_general_path(False); ctx.set_no_direct_sort(False)
+ctx.set_sort_mode(0); ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_text_keys(True)
 print(f"{cases} cases ok in {time.time() - t0:.0f} s; (lms_path, sort_local, key_bits, refine_tiers): {paths}")
