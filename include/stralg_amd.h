@@ -38,7 +38,8 @@ enum {
 enum {
     SX_KC_CLASSIFY = 0,   /* S/L types, LMS flags, bucket histograms      sa_is.c:134-174 */
     SX_KC_SAMPLES,        /* sample (LMS + cut) flags and compaction                       */
-    SX_KC_KEYS,           /* LMS-substring pieces -> 64-bit keys          sa_is.c:265-292 */
+    SX_KC_KEYS,           /* LMS-substring pieces / prefixes -> 64-bit keys sa_is.c:265-292; a sort's first pass when it
+                             computes its keys from the text itself (no key kernel) */
     SX_KC_RADIX_HIST,     /* radix sort: per-tile digit histogram                          */
     SX_KC_RADIX_SCATTER,  /* radix sort: stable scatter                                    */
     SX_KC_SCAN,           /* device-wide scans / compactions                               */

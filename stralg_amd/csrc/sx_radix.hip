@@ -506,7 +506,8 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
 // the 1 GiB DNA build's 91.  Here the first pass's tiles are pieces of the TEXT: a workgroup lists its piece's LMS positions
 // from the classification's bit array, computes their keys from the text staged in LDS (the value lms_tile_keys_kernel
 // stores) and goes on as radix_scatter_tile does.  Tiles hold as many pairs as their piece has LMS suffixes, in text order,
-// so the pass is stable like any other.  1 GiB of DNA, same box: key kernel 1.16 + histogram 0.11 + scatter 1.70 ms before,
+// so the pass is stable like any other.  (Accounted under SX_KC_KEYS, like the key kernel it replaces and the direct sort's
+// text-keyed first pass: key generation, here with the first scatter in it.)  1 GiB of DNA, same box: key kernel 1.16 + histogram 0.11 + scatter 1.70 ms before,
 // histogram 0.42 + scatter 1.85 now; the whole build 21.3 - 21.4 -> 20.6 - 21.0 ms.
 #if SX_RADIX_THREADS == 1024 && SX_RADIX_ITEMS == 8
 #define SX_RADIX_LMS_PASS 1
@@ -948,7 +949,7 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
                 }
 #define SX_LMS_PASS(CS, WS, BS)                                                                                                          \
     case lms_key_shape(CS, WS, BS):                                                                                                      \
-        sx_launch(ctx, SX_KC_RADIX_SCATTER, text_bytes + n * (12 + (has_next ? 1 : 0)), radix_scatter_lms_kernel<CS, WS, BS>,            \
+        sx_launch(ctx, SX_KC_KEYS, text_bytes + n * (12 + (has_next ? 1 : 0)), radix_scatter_lms_kernel<CS, WS, BS>,                     \
                   dim3(((ntiles1 + 7) / 8) * 8), dim3(kRT), lk, kout, vout, shift, mask, (const uint32_t *)hist1, ntiles1,                \
                   has_next ? (uint8_t *)dig : (uint8_t *)nullptr, next_shift & 63, (uint32_t)next_mask8);                                 \
         break;
@@ -992,7 +993,7 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
         }
         if (text_keys && shift == begin_bit) {
             if constexpr (DB == 8) // (the text image lies behind the counters in the key image: 8-bit digits only)
-                sx_launch(ctx, SX_KC_RADIX_SCATTER, n * (13 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true, true>,
+                sx_launch(ctx, SX_KC_KEYS, n * (13 + (has_next ? dig_bytes : 0)), radix_scatter_kernel<DB, true, true>,
                           dim3(((ntiles + 7) / 8) * 8), dim3(kRT), *text_keys, (const uint64_t *)kin, (const uint32_t *)vin, kout, vout, n,
                           shift, mask, (const uint32_t *)hist, ntiles, has_next ? dig : (dig_t *)nullptr, next_shift & 63,
                           has_next ? (1u << next_bits) - 1u : 0u);

@@ -16,7 +16,7 @@ CLASS_OF = [
     # round 4's kernels (first: the first match counts)
     ("hoist_scatter_kernel", "induce_scatter"), ("hoist_count_kernel", "induce_gather"), ("hoist_offsets_kernel", "induce_scan"),
     ("hoist_tables_kernel", "induce_scan"), ("bucket_begin_kernel", "induce_scan"), ("bigram_kernel", "induce_gather"),
-    ("widen_windows_kernel", "induce_gather"), ("radix_hist_text_kernel", "radix_hist"), ("radix_hist_digits_kernel", "radix_hist"),
+    ("widen_windows_kernel", "induce_gather"), ("radix_hist_text_kernel", "radix_hist"), ("radix_hist_lms_kernel", "radix_hist"), ("radix_scatter_lms_kernel", "keys"), ("radix_scatter_kernel<8, true, true>", "keys"), ("radix_hist_digits_kernel", "radix_hist"),
     ("fasta_", "fasta"), ("remap_", "remap"), ("reverse_kernel", "remap"), ("inverse_", "lcp"), ("lcp_", "lcp"),
     ("induce_batch_offsets_kernel", "induce_scan"), ("induce_count_bytes_kernel", "induce_gather"), ("induce_tail", "induce_chain"),
     ("radix_scatter_kernel", "radix_scatter"), ("radix_hist_kernel", "radix_hist"),
