@@ -132,8 +132,9 @@ enum {
     ,SX_FLAG_INDUCE_NO_HOIST = 13  /* texts of more than 8 symbols: 1 = every bucket's LMS seeds (L pass) and L-type entries (S pass)
                                        are scanned by launches of the bucket's own, as in rounds 1 - 3; 0 (default) = all buckets'
                                        at once, up front, placed by the text's bigram counts */
-    ,SX_FLAG_TEXT_KEYS_OFF = 14    /* the direct sort of all suffixes: 1 = a key kernel writes the keys before the first radix pass
-                                       (rounds 1 - 3); 0 (default) = the first pass computes them from the text */
+    ,SX_FLAG_TEXT_KEYS_OFF = 14    /* the direct sort of all suffixes and the LMS sort of four-letter texts: 1 = a key kernel writes
+                                       the keys before the first radix pass (rounds 1 - 3); 0 (default) = the first pass computes them
+                                       from the text */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

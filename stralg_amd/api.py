@@ -250,8 +250,8 @@ class Context:
         self._check(self.lib.sx_ctx_set_flag(self.h, 13, 0 if on else 1), "sx_ctx_set_flag")
 
     def set_text_keys(self, on=True):
-        """SX_FLAG_TEXT_KEYS_OFF: the direct sort's first radix pass computes its keys from the text (default) or reads
-        them from a key kernel's output (rounds 1 - 3)"""
+        """SX_FLAG_TEXT_KEYS_OFF: the first radix pass of the direct sort, and of a four-letter text's LMS sort, computes
+        its keys from the text (default) or reads them from a key kernel's output (rounds 1 - 3)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 14, 0 if on else 1), "sx_ctx_set_flag")
 
     def set_recurse_min(self, symbols):
