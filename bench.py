@@ -215,6 +215,27 @@ def pmc_traffic(workload, log2n, sigma, tables, klass):
         return None, None
 
 
+def pmc_whole_step(workload, log2n, sigma, tables, launches_per_class):
+    """HBM bytes of one whole step as rocprofv3's counters saw them: the committed per-class figures (pmc_traffic above)
+    times this run's launches per class.  Returns (bytes, stale, classes the passes have no figure for) or (None, None, None)."""
+    try:
+        from stralg_amd._lib import kernel_sources_sha16
+        doc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
+        key = f"log2n={log2n} sigma={sigma} tables={int(tables)}"
+        entry = doc[key if workload == "dna" else f"workload={workload} " + key]
+        total, missing = 0.0, []
+        for klass, launches in launches_per_class.items():
+            c = entry["classes"].get(klass)
+            if c is None:
+                if launches:
+                    missing.append(klass)  # (a class without a figure counts as no traffic: the total is a lower bound)
+                continue
+            total += c["hbm_bytes_per_launch"] * launches
+        return total, entry.get("kernel_sources_sha16") != kernel_sources_sha16(), missing
+    except (OSError, KeyError, ValueError):
+        return None, None, None
+
+
 # ---- host-buffer (PCIe-inclusive) measurements, outside the timed region --------------------------------------
 
 def end_to_end(ctx, sizes, seed):
@@ -776,6 +797,14 @@ def run_rank(args):
         out["whole_step"] = {"alg_GB": round(alg_total / 1e9, 2),
                              "GBps": round(alg_total / (elapsed / args.steps) / 1e9, 1),
                              "frac_of_peak": round(alg_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the same from the hardware counters (BASELINE's target is stated on rocprof's HBM bytes): replayed like roofline.traffic
+        hbm_total, hbm_stale, hbm_missing = pmc_whole_step(workload, args.log2n if args.n == 0 else -1, sigma, tables,
+                                                           {k: v["launches"] for k, v in table.items()})
+        if hbm_total is not None:
+            out["whole_step"].update({"hbm_GB_pmc": round(hbm_total / 1e9, 2),
+                                      "hbm_GBps_pmc": round(hbm_total / (elapsed / args.steps) / 1e9, 1),
+                                      "hbm_frac_of_peak_pmc": round(hbm_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "hbm_pmc_stale": hbm_stale, "hbm_pmc_classes_without_figure": hbm_missing})
         if fasta is not None:
             out["fasta_record"] = fasta
         if coll is not None:
