@@ -783,6 +783,10 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
     o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
     bw = torch.empty(N, dtype=torch.uint8, device="cuda")
     gpu_ctx.sa_bwt_build_dev(text, n, sigma, sa, bw)
+    st = gpu_ctx.last_stats()
+    # what was timed is what is checked: four letters at these sizes take the hybrid sort (bit 0) whose first HBM pass lists
+    # the LMS suffixes and computes their keys itself (bit 3: radix_scatter_lms_kernel), with the one key symbol more
+    assert st["lms_path"] == 1 and st["sort_local"] & 9 == 9 and st["key_slots"] == (17 if log2n == 28 else 18), st
     gpu_ctx.bwt_tables_from_bwt_dev(bw, N, sigma, c, o)
     gpu_ctx.trim()  # the checks need the memory more than the library's cached workspace does
     done = verify.verify_build_on_device(text, n, sigma, sa, bw, c, o)
