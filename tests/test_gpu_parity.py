@@ -197,19 +197,25 @@ def test_hybrid_prefix_sort(gpu_ctx):
             want = oracle.sa_is(x, sigma)
             bw_want = oracle.bwt(x, want)
             for C in ((14, 16, 17, 18) if sigma == 5 else (13, 16)):
-                for mode in (1, 2, 3):  # plain passes; HBM passes on the top 24 / 32 key bits, then sub-buckets in LDS
+                # (modes: plain passes; HBM passes on the top 24 / 32 key bits, then sub-buckets in LDS.  Four letters, 16 ... 18
+                #  symbols, a hybrid mode: the first HBM pass computes the keys itself -- bit 3 --, or, with the switch off, a key
+                #  kernel does as in rounds 1 - 3)
+                for mode, text_keys in ((1, True), (2, True), (2, False), (3, True), (3, False)):
                     gpu_ctx.set_prefix_symbols(C)
                     gpu_ctx.set_sort_mode(mode)
+                    gpu_ctx.set_text_keys(text_keys)
                     xd = torch.from_numpy(x).cuda()
                     sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
                     bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
                     gpu_ctx.sa_bwt_build_dev(xd, n, sigma, sa, bw)
                     st = gpu_ctx.last_stats()
                     assert (st["sort_local"] & 5) == (0, 1, 5)[mode - 1] and st["key_slots"] == C, (sigma, n, C, mode, st)
+                    assert bool(st["sort_local"] & 8) == (text_keys and mode > 1 and sigma == 5 and 15 <= C <= 18), (sigma, n, C, mode, text_keys, st)
                     if sigma == 5 and mode < 3:  # four-letter texts: dense keys with the hybrid sort, base-5 keys with plain passes
                         assert st["key_bits"] == (2 * C + (4 if C < 16 else 5) if mode == 2 else int(np.ceil(C * np.log2(5)))), st
                     assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n, C, mode)
                     assert (bw.cpu().numpy() == bw_want).all(), (sigma, n, C, mode)
+        gpu_ctx.set_text_keys(True)
         # 40 copies of a 60-symbol piece: equal keys crowd a bin of the counting pass, that workgroup takes stable passes
         x = synth(1 << 20, 5, 33)
         for i in range(40):
@@ -238,6 +244,7 @@ def test_hybrid_prefix_sort(gpu_ctx):
         gpu_ctx.set_prefix_symbols(0)
         gpu_ctx.set_sort_mode(0)
         gpu_ctx.set_radix_digit_bits(0)
+        gpu_ctx.set_text_keys(True)
 
 
 def test_runs_of_many_lengths(gpu_ctx):
