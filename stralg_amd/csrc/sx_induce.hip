@@ -86,6 +86,8 @@ template <class WT> struct induce_state {
     uint32_t *hoist_tot;     // the current pass's up-front entries from bucket c to bucket d, [c][d]
     uint32_t *hoist_err;     // set by bucket_begin_kernel when a cursor is not where the bigram counts put it
     uint32_t hoist_from;     // the last bucket of the pass that had rounds of its own (L pass: 0, S pass: nk - 1 before the first)
+    int next_c;              // unattended pass: the next bucket with rounds of its own, whose head the tail kernel of this one takes (-1: none)
+    int begun_c;             // the bucket whose rounds the last tail kernel has opened (-1: none)
 };
 
 template <class WT>
@@ -199,11 +201,17 @@ void launch_tail(induce_state<WT> &st, int range_slot, int out_slot, int rev, in
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters, st.unattended ? st.poison : (uint32_t *)nullptr,
                   st.host_poison);
-    else
+    else {
+        tail_next nb = {-1, st.nk, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
+        if (st.hoist && st.unattended && st.next_c >= 0)
+            nb = {st.next_c, st.nk, (const uint32_t *)st.d_begin, (const uint32_t *)st.hoist_E, (const uint32_t *)st.hoist_tot, st.ranges,
+                  st.tickets, (uint32_t)(kMaxSpec + 2), st.hoist_err};
         sx_launch(ctx, SX_KC_INDUCE_CHAIN, 0, induce_tail_kernel<WT, 8>, dim3(1), dim3(kTailBlock), st.SA, st.WN, st.BW,
                   (const uint32_t *)(st.ranges + 2 * range_slot), st.ranges + 2 * out_slot, rev, mode, c, st.cfg, st.T,
                   cur, nxt, dir, st.unattended ? kTailItersUnattended : kTailIters, st.unattended ? st.poison : (uint32_t *)nullptr,
-                  st.host_poison);
+                  st.host_poison, nb);
+        st.begun_c = nb.c;
+    }
     st.par ^= 1;
 }
 
@@ -287,9 +295,12 @@ int run_self_rounds(induce_state<WT> &st, uint32_t fixed_bound, uint32_t region_
         if (batch > max_batches) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: the rounds of a bucket did not come to an end");
         if (!resuming) {
         if (first && st.hoist) {
-            sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, bucket_begin_kernel, dim3(1), dim3(256), st.ranges, st.cursor[st.par],
-                      (const uint32_t *)st.d_begin, (const uint32_t *)st.hoist_E, (const uint32_t *)st.hoist_tot, st.nk, c, st.hoist_from,
-                      dir, st.tickets, (uint32_t)(kMaxSpec + 2), (const uint32_t *)(st.unattended ? st.poison : nullptr), st.hoist_err);
+            // (the tail kernel of the bucket before has done it, in an unattended pass: launch_tail)
+            if (st.begun_c != (int)c)
+                sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, bucket_begin_kernel, dim3(1), dim3(256), st.ranges, st.cursor[st.par],
+                          (const uint32_t *)st.d_begin, (const uint32_t *)st.hoist_E, (const uint32_t *)st.hoist_tot, st.nk, c, st.hoist_from,
+                          dir, st.tickets, (uint32_t)(kMaxSpec + 2), (const uint32_t *)(st.unattended ? st.poison : nullptr), st.hoist_err);
+            st.begun_c = -1;
             st.hoist_from = c;
         } else if (first)
             sx_launch(ctx, SX_KC_INDUCE_SCAN, 0, set_range_kernel, dim3(1), dim3(1), st.ranges, fixed_bound, fixed_bound,
@@ -478,6 +489,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
     st.hoist = (!st.small_alphabet && !ctx->induce_no_hoist) ? 1 : 0;
     st.d_begin = st.hoist_E = st.hoist_tot = st.hoist_err = nullptr;
     st.hoist_from = 0;
+    st.next_c = st.begun_c = -1;
     uint32_t *hz_BG = nullptr, *hz_EL = nullptr, *hz_ES = nullptr, *hz_tot = nullptr, *hz_dbase = nullptr, *hz_hist = nullptr,
              *hz_desc = nullptr;
     uint32_t h_desc[2][768]; // per pass: lo[256], len[256], first hist row[256] of every bucket's region (uploaded; alive to the end)
@@ -564,6 +576,9 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             if (ti.h_l[c]) {
                 uint32_t head_end = 0;
                 st.unattended = (unattended_ok && !carry_on) ? 1 : 0;
+                st.next_c = -1; // (the next bucket with an L region: its rounds are opened by this bucket's tail kernel)
+                for (uint32_t c2 = c + 1; c2 < nk && st.next_c < 0; ++c2)
+                    if (ti.h_all[c2] && ti.h_l[c2]) st.next_c = (int)c2;
                 SX_TRY(run_self_rounds<WT>(st, begin[c], ti.h_l[c], 0, MODE_L_FROM_L, c, +1, 1, &head_end, (double)ti.h_all[c] / (double)N,
                                            carry_on ? resume : nullptr));
                 if (!st.unattended && head_end - begin[c] != ti.h_l[c])
@@ -592,6 +607,9 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             if (c > 0 && n_s) {
                 uint32_t tail_end = 0;
                 st.unattended = (unattended_ok && !carry_on) ? 1 : 0;
+                st.next_c = -1; // (the next bucket with an S region)
+                for (uint32_t c2 = c; c2-- > 1 && st.next_c < 0;)
+                    if (ti.h_all[c2] && ti.h_all[c2] - ti.h_l[c2]) st.next_c = (int)c2;
                 SX_TRY(run_self_rounds<WT>(st, begin[c + 1], n_s, 1, MODE_S_FROM_S, c, -1, 2, &tail_end, (double)ti.h_all[c] / (double)N,
                                            carry_on ? resume : nullptr));
                 if (!st.unattended && begin[c + 1] - tail_end != n_s)
@@ -622,6 +640,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
                 *(volatile uint32_t *)st.host_poison = 0;
                 SX_CHECK(hipMemsetAsync(st.poison, 0, 4 * sizeof(uint32_t), ctx->stream));
             }
+            st.next_c = st.begun_c = -1;
             SX_TRY(pass == 0 ? pass_L(from, resume) : pass_S(from, resume));
             if (!unattended_ok) break;
             SX_TRY(sx_readback(ctx, (const uint32_t *)st.poison, 4, rec));

@@ -151,19 +151,46 @@ __global__ __launch_bounds__(kBlock) void induce_round_kernel(
 // cannot, but then the host's ordinary rounds take over) or max_iters rounds have run.
 // Entries written in one iteration are read in the next by other waves of the same
 // workgroup: the barrier's workgroup-scope fence orders them (the waves share the CU's L1).
+// what the tail kernel of bucket c needs to open the next bucket's rounds (c < 0: nothing to do)
+struct tail_next {
+    int c;                   // the next bucket of the pass with rounds of its own
+    uint32_t nk;
+    const uint32_t *begin;   // bucket boundaries, 257
+    const uint32_t *E;       // the pass's group ends [c][d]
+    const uint32_t *tot;     // the pass's up-front entries from bucket c to bucket d, [c][d]
+    uint32_t *range;         // the first range of the next bucket's rounds
+    uint32_t *tickets;
+    uint32_t ntickets;
+    uint32_t *err;
+};
 template <class WT, int BITS>
 __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, WT *WN, uint8_t *BW, const uint32_t *__restrict__ range_in,
                                                              uint32_t *__restrict__ range_out, int rev, int mode,
                                                              uint32_t c, wnd_cfg cfg, const uint8_t *__restrict__ T,
                                                              const uint32_t *__restrict__ cursor_cur,
                                                              uint32_t *__restrict__ cursor_nxt, int dir,
-                                                             uint32_t max_iters, uint32_t *poison, uint32_t *host_poison)
+                                                             uint32_t max_iters, uint32_t *poison, uint32_t *host_poison,
+                                                             tail_next nb)
 {
     constexpr int kDigits = BITS == 3 ? 8 : 256; // buckets that can receive anything
     __shared__ uint32_t wcount[kTailWaves][kDigits];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t s_range[2];
     __shared__ uint32_t s_flag;
+    // More than 8 buckets: a round of thousands of entries leaves the workgroup in bucket order -- staged in LDS, every
+    // bucket's entries next to each other, then stored as runs.  Stored from the registers that hold them, entry by entry
+    // into 256 buckets, a wave's store touches 64 lines: the first round of a byte text's bucket (4 - 8 thousand entries,
+    // three stores each) spent 12 of the kernel's 25 us handing its lines to the memory system one at a time (clock64
+    // around the phases; the window refills, suspected first, were not it).
+    constexpr int kStageCap = BITS > 3 ? kTailTile : 1;
+#ifndef SX_TAIL_STAGE_FROM
+#define SX_TAIL_STAGE_FROM 512u // (the CPU test harness: 8, so that short texts' rounds take this form too)
+#endif
+    constexpr uint32_t kStageFrom = SX_TAIL_STAGE_FROM; // entries of a round (a tile of it) from which the stores are staged
+    __shared__ WT st_w[kStageCap];
+    __shared__ uint32_t st_v[kStageCap];
+    __shared__ uint8_t st_d[kStageCap];
+    __shared__ uint32_t st_off[BITS > 3 ? 256 : 1], st_ex[BITS > 3 ? 256 : 1], st_scan[kTailWaves];
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     if (t < 256) gbase[t] = cursor_cur[t];
     if (t == 0) {
@@ -287,11 +314,54 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         }
         __syncthreads();
         {
-            bool need[kIndItems];
+            bool need[kIndItems], any = false;
 #pragma unroll
-            for (int k = 0; k < kIndItems; ++k) need[k] = ok[k] && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0;
-            refill_windows<WT, kIndItems>(T, val, need, cfg, wnd);
+            for (int k = 0; k < kIndItems; ++k) any |= need[k] = ok[k] && val[k] != 0 && wnd_count<WT>(wnd[k]) == 0;
+            // (a wave without a dry window skips the block: the scatter that fed this round filled them up, kTailAhead)
+            if (__any(any ? 1 : 0)) refill_windows<WT, kIndItems>(T, val, need, cfg, wnd);
         }
+        const bool staged = BITS > 3 && (len - sub0 < kTailEntries ? len - sub0 : kTailEntries) >= kStageFrom; // uniform
+        if (staged) {
+            // first staged slot of every bucket: the buckets' counts of this round, summed up in bucket order
+            const uint32_t inc = wave_inclusive_scan<OpAdd>(cnt);
+            if (lane == kWave - 1) st_scan[w] = inc;
+            __syncthreads();
+            uint32_t ex = inc - cnt, produced = 0;
+            for (int ww = 0; ww < kTailWaves; ++ww) {
+                const uint32_t x = st_scan[ww];
+                if (ww < w) ex += x;
+                produced += x;
+            }
+            if (t < kDigits) {
+                st_ex[t & 255] = ex;
+                st_off[t & 255] = dir > 0 ? gbase[t] - ex : gbase[t] - 1u + ex; // staged slot i of bucket t lands at st_off + i (L pass) / - i (S pass)
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                live[k] = ok[k] && dig[k] == c; // appended to bucket c itself: part of the next round
+                if (ok[k]) {
+                    const uint32_t d = dig[k] & 255u;
+                    const uint32_t slot = (st_ex[d] + wcount[w][d & (uint32_t)(kDigits - 1)] + rnk[k]) & (uint32_t)(kStageCap - 1);
+                    st_v[slot] = val[k];
+                    st_w[slot] = wnd[k];
+                    st_d[slot] = (uint8_t)d;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kIndItems; ++k) {
+                const uint32_t i = (uint32_t)t + (uint32_t)k * kTailBlock;
+                if (i < produced) {
+                    const uint32_t g = st_off[st_d[i & (uint32_t)(kStageCap - 1)]];
+                    const uint32_t dst = dir > 0 ? g + i : g - i;
+                    const WT nw = st_w[i & (uint32_t)(kStageCap - 1)];
+                    SA[dst] = st_v[i & (uint32_t)(kStageCap - 1)];
+                    WN[dst] = nw;
+                    BW[dst] = wnd_symbol<WT>(nw, cfg);
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < kIndItems; ++k) {
             live[k] = ok[k] && dig[k] == c; // appended to bucket c itself: part of the next round
@@ -303,6 +373,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
                 WN[dst] = wnd[k];
                 BW[dst] = wnd_symbol<WT>(wnd[k], cfg);
             }
+        }
         }
         held = !multi; // (the entries a round of several tiles appended lie with many threads' registers' worth each: from memory)
         __syncthreads();
@@ -321,7 +392,39 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_kernel(uint32_t *SA, W
         }
         __syncthreads();
     }
-    if (t < 256) cursor_nxt[t] = gbase[t];
+    // The head of the next bucket's rounds in a pass whose other-region rounds were done up front (what bucket_begin_kernel
+    // does in a launch of its own -- 4.4 us and a launch boundary a bucket, 510 times a byte text's build --; sx_induce_wide.hpp
+    // has the bookkeeping): the cursors jump over the up-front entries of the buckets c .. next - 1 to the group starts, checked
+    // against the bigram counts' table; the first range is what lies in front of the next bucket's own group.  Not when this
+    // bucket is left unfinished (or an earlier one was): later launches then find an empty range.
+    uint32_t mine = t < 256 ? gbase[t] : 0u;
+    if (nb.c >= 0) { // uniform
+        if (t == 0) {
+            s_flag = (s_range[0] != s_range[1] || (poison && poison[0])) ? 1u : 0u;
+            for (uint32_t i = 0; i < nb.ntickets; ++i) nb.tickets[i] = 0;
+        }
+        __syncthreads();
+        const uint32_t d = (uint32_t)t, cn = (uint32_t)nb.c;
+        if (s_flag) {
+            if (t == 0) nb.range[0] = nb.range[1] = 0;
+        } else if (d < nb.nk && (dir > 0 ? d >= cn : d <= cn)) {
+            uint32_t want, have = mine;
+            if (dir > 0) {
+                want = cn == 0 ? nb.begin[d] : nb.E[(uint64_t)(cn - 1) * 256 + d];
+                for (uint32_t k = c; k < cn; ++k) have += nb.tot[(uint64_t)k * 256 + d];
+            } else {
+                want = cn + 1 >= nb.nk ? nb.begin[d + 1] : nb.E[(uint64_t)(cn + 1) * 256 + d];
+                for (uint32_t k = c; k > cn; --k) have -= nb.tot[(uint64_t)k * 256 + d];
+            }
+            if (have != want) atomicOr(nb.err, dir > 0 ? 1u : 2u);
+            mine = want;
+            if (d == cn) {
+                nb.range[0] = dir > 0 ? nb.begin[cn] : want;
+                nb.range[1] = dir > 0 ? want : nb.begin[cn + 1];
+            }
+        }
+    }
+    if (t < 256) cursor_nxt[t] = mine;
     if (t == 0) {
         range_out[0] = s_range[0];
         range_out[1] = s_range[1];

@@ -276,6 +276,10 @@ __device__ __forceinline__ void refill_windows(const uint8_t *__restrict__ T, co
     SX_SCHED_FENCE();
 }
 
+#ifndef SX_TAIL_AHEAD
+#define SX_TAIL_AHEAD 3u
+#endif
+constexpr uint32_t kTailAhead = SX_TAIL_AHEAD; // symbols a window keeps for the tail kernel's rounds (nearly every bucket ends within three); 0: off
 // LDS of one scatter workgroup (the kernels below declare it and hand it to wide_scatter_tile)
 template <int ITEMS> struct wide_scatter_lds {
     static constexpr int kSub = kWideThreads * ITEMS;
@@ -391,7 +395,11 @@ __device__ __forceinline__ void wide_scatter_tile(wide_scatter_lds<ITEMS> &L, co
         {
             bool need[ITEMS];
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) need[k] = (lpos[k] & 0x8000u) && val[k] != 0 && wnd_count<WT>(wnd[k]) <= refill_at;
+            // (an entry that goes into bucket c itself is scanned next by the bucket's tail kernel, one workgroup: its window is
+            //  filled up here, where the random reads are spread over the chip, while it still holds kTailAhead symbols)
+            for (int k = 0; k < ITEMS; ++k)
+                need[k] = (lpos[k] & 0x8000u) && val[k] != 0 &&
+                          wnd_count<WT>(wnd[k]) <= (((lpos[k] >> 16) & 0xFFu) == c && refill_at < kTailAhead ? kTailAhead : refill_at);
             refill_windows<WT, ITEMS>(T, val, need, cfg, wnd);
         }
 #pragma unroll
