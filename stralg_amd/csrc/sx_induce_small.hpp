@@ -339,6 +339,12 @@ __global__ __launch_bounds__(kBlock) void induce_scatter_small_kernel(
 // (when the range shrinks slowly: poly-A tracts and microsatellites of differing lengths, where the all-in-a-run jump
 // never applies): one set of counters per round, one prefix over threads and rounds, one scatter.
 constexpr int kTailBatch = 8;
+constexpr uint32_t kRunCap = 255; // symbols of a run the closed form looks at (a byte a length)
+#ifndef SX_TAIL_CLOSED_FROM
+#define SX_TAIL_CLOSED_FROM 256u // (the CPU test harness: 4, so that short texts' runs take this form too)
+#endif
+constexpr uint32_t kClosedFrom = SX_TAIL_CLOSED_FROM; // entries of a range from which the closed form is taken
+constexpr uint32_t kClosedEntries = 5120;             // ... and up to which: what fits the workgroup's LDS
 template <class WT>
 __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t *SA, WT *WN, uint8_t *BW,
                                                                        const uint32_t *__restrict__ range_in,
@@ -354,6 +360,15 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
     __shared__ uint32_t gbase[8];
     __shared__ uint32_t s_range[2];
     __shared__ uint32_t s_flag;
+    // the closed form of a range of runs (below): positions, run lengths, the symbol that ends each run; per run length
+    // the entries (then: where the round's entries begin), per bucket and run length the ends (then: where they begin)
+    // (the window of the position in front of each run too, so that no round goes back to the text: as many entries as that
+    //  leaves room for in 64 KiB of LDS; 32-bit windows only, which is what at most 8 buckets have)
+    constexpr uint32_t kCfEntries = sizeof(WT) == 4 ? kClosedEntries : 64u;
+    __shared__ uint32_t cf_p[kCfEntries];
+    __shared__ WT cf_w[kCfEntries];
+    __shared__ uint8_t cf_r[kCfEntries];
+    __shared__ uint32_t cf_hr[kRunCap + 1], cf_he[8][kRunCap + 1], cf_cmax[kCfEntries / kWave], cf_rmax;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     if (t < 8) gbase[t] = cursor_cur[t];
     if (t == 0) {
@@ -362,6 +377,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
     }
     __syncthreads();
     const uint32_t B = cfg.B, cmask = cfg.mask;
+    bool last_batch = false; // the last step took a batch of rounds (or the closed form)
     uint32_t val[kIndItems]; // entries t * per .. t * per + per - 1 of the range as it was loaded, in scan order
     WT wnd[kIndItems];
     uint32_t live = 0;       // bit k: entry k belongs to the current range
@@ -414,12 +430,202 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
                     s_range[1] = dir > 0 ? cur + total : cur - total + len;
                 }
                 held = false; // the range is now what the jump wrote last
+                last_batch = false;
                 ++it;
                 __syncthreads();
                 continue;
             }
         }
         prev_len = len;
+        // ---- closed form of a range that is runs of differing lengths ------------------------------------------------
+        // Thousands of poly-A tracts and microsatellites: the range loses a few entries a round for two hundred rounds,
+        // the all-in-a-run jump never applies, and the batched step below costs this one CU 20 instructions for every
+        // (entry, round) whether the entry is alive or not (a genome-like 1 GiB text: 0.35 - 0.75 ms a bucket and pass,
+        // in proportion to the bucket's runs; 3.3 of the build's 40 ms).  But the rounds of such a range are a function
+        // of the runs' lengths alone: entry i with r_i symbols c to its left is in rounds 1 .. r_i (position p_i - j in
+        // round j, behind the round's entries i' < i with r_i' >= j), and the symbol d_i that ends its run sends
+        // p_i - r_i - 1 to bucket d_i in round r_i + 1 (behind the ends of earlier rounds and of entries i' < i of the
+        // same round), if the pass's type test accepts it.  So: the run lengths (up to kRunCap) by one look at the text,
+        // their histogram -> where every round begins in bucket c and in the other buckets, and the rounds are written
+        // one to a wave, independently.  Taken when the last batch of rounds kept half of its entries.
+        if ((mode == MODE_L_FROM_L || mode == MODE_S_FROM_S) && c >= 1u && last_batch && (uint64_t)len * 2 >= last_in &&
+            len >= kClosedFrom && len <= kCfEntries) { // uniform
+            if (t <= (int)kRunCap) cf_hr[t] = 0;
+            for (uint32_t i = (uint32_t)t; i < (kRunCap + 1) * 8; i += kTailBlock) (&cf_he[0][0])[i] = 0;
+            if (t < (int)(kCfEntries / kWave)) cf_cmax[t] = 0;
+            __syncthreads();
+            const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
+            const uint32_t per2 = (len + (uint32_t)kTailBlock - 1u) / (uint32_t)kTailBlock;
+#pragma unroll 1
+            for (uint32_t k = 0; k < per2; ++k) {
+                const uint32_t i = (uint32_t)t * per2 + k;
+                if (i < len) {
+                    const uint32_t p = SA[lo + (rev ? len - 1u - i : i)];
+                    uint32_t r = 0;
+                    bool open = p != 0;
+                    for (uint32_t g = 0; g < (kRunCap + 1) / 64 && open; ++g) { // 64 symbols a look, their loads in flight together
+                        uint64_t o[4][2];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            const uint32_t done = 64u * g + 16u * u;
+                            o[u][0] = o[u][1] = ~cpat;
+                            if (p >= done + 16u) load_bytes16(T, (uint64_t)(p - done - 16u), o[u][0], o[u][1]);
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; ++u) {
+                            const uint32_t done = 64u * g + 16u * u;
+                            if (!open) {
+                            } else if (p >= done + 16u) {
+                                const uint64_t x1 = o[u][1] ^ cpat, x0 = o[u][0] ^ cpat;
+                                if (x1) r += (uint32_t)__clzll((unsigned long long)x1) >> 3, open = false;
+                                else if (x0) r += 8u + ((uint32_t)__clzll((unsigned long long)x0) >> 3), open = false;
+                                else r += 16u;
+                            } else { // fewer than 16 symbols between the text's start and here
+                                uint32_t a = p - done;
+                                while (a > 0 && T[a - 1u] == (uint8_t)c) --a, ++r;
+                                open = false;
+                            }
+                        }
+                    }
+                    if (r > kRunCap) r = kRunCap;
+                    // the window of the position in front of the run (of the last symbol looked at, for a longer run): with
+                    // it every round's window is known -- the run's symbols that are left, then these
+                    const WT wend = p > r ? wnd_fill<WT>(T, p - r, cfg) : (WT)0;
+                    cf_p[i] = p;
+                    cf_r[i] = (uint8_t)r;
+                    cf_w[i] = wend;
+                    atomicAdd(&cf_hr[r], 1u);
+                    if (r < kRunCap && p > r) { // the run ends inside the look, and not at the text's start
+                        const uint32_t d = wnd_first<WT>(wend, cfg);
+                        if (induce_accept(d, c, mode)) atomicAdd(&cf_he[d & 7u][r], 1u);
+                    }
+                    atomicMax(&cf_cmax[i >> 6], r);
+                }
+            }
+            __syncthreads();
+            // wave 0: entries per run length -> the longest run; entries alive in round u + 1 (S[u]); cf_hr[u] <- sum of S below u
+            // = where round u + 1 begins in bucket c.  waves 1 .. 8: ends per run length -> cf_he[d][u] <- ends of shorter runs
+            // = where the ends of round u + 1 begin in bucket d.
+            if (w <= 8) {
+                uint32_t *row = w == 0 ? cf_hr : cf_he[w - 1];
+                uint32_t v[4], sum = 0, top = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = row[4 * lane + q];
+                    if (v[q]) top = (uint32_t)(4 * lane + q);
+                    sum += v[q];
+                }
+                uint32_t inc = wave_inclusive_scan<OpAdd>(sum);
+                if (w == 0) {
+                    const uint32_t rmax = wave_reduce_max(top);
+                    if (lane == 0) cf_rmax = rmax;
+                    // alive after u + 1 rounds' worth of run: len - (entries with r <= u)
+                    uint32_t run = inc - sum, s4[4], ssum = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        run += v[q];
+                        s4[q] = len - run;
+                        ssum += s4[q];
+                    }
+                    const uint32_t inc2 = wave_inclusive_scan<OpAdd>(ssum);
+                    uint32_t run2 = inc2 - ssum;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        row[4 * lane + q] = run2;
+                        run2 += s4[q];
+                    }
+                } else {
+                    uint32_t run = inc - sum;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        row[4 * lane + q] = run;
+                        run += v[q];
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t rmax = cf_rmax;
+            const uint32_t J = rmax < kRunCap ? rmax + 1u : kRunCap; // rounds written here (the last one may hold ends only)
+            const uint32_t curC = gbase[c];
+            uint32_t curD[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) curD[d] = gbase[d];
+            WT crun = 0; // CW codes of symbol c: the window of an entry at least CW symbols inside its run
+            for (uint32_t i = 0; i < cfg.CW; ++i) crun = (crun << B) | (WT)(c - 1u);
+            const WT field_mask = cfg.CW * B >= 8 * sizeof(WT) ? ~(WT)0 : (((WT)1 << (cfg.CW * B)) - 1u);
+            const uint32_t nchunks = (len + (uint32_t)kWave - 1u) / (uint32_t)kWave;
+            for (uint32_t j = 1u + (uint32_t)w; j <= J; j += (uint32_t)kTailWaves) { // uniform per wave
+                uint32_t cc = cf_hr[j - 1u], cd[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) cd[d] = cf_he[d][j - 1u];
+                for (uint32_t ch = 0; ch < nchunks; ++ch) {
+                    if (cf_cmax[ch] + 1u < j) continue; // (every run of the chunk ended before this round)
+                    const uint32_t i = ch * (uint32_t)kWave + (uint32_t)lane;
+                    const bool valid = i < len;
+                    const uint32_t r = valid ? cf_r[i] : 0u, p = valid ? cf_p[i] : 0u;
+                    const WT wend = valid ? cf_w[i] : (WT)0;
+                    const uint32_t dd = wnd_first<WT>(wend, cfg); // (the symbol that ends the run, if there is one)
+                    const bool cont = valid && r >= j;
+                    const bool endf = valid && r + 1u == j && r < kRunCap && p > r && induce_accept(dd, c, mode);
+                    const uint64_t bc = __ballot(cont ? 1 : 0);
+                    if (bc) {
+                        if (cont) {
+                            const uint32_t o = cc + (uint32_t)__popcll(bc & lanemask_lt());
+                            const uint32_t dst = dir > 0 ? curC + o : curC - 1u - o, pos = p - j;
+                            // r - j symbols c, then what lies in front of the run: CW symbols of it at most
+                            const uint32_t k = r - j, have = k + wnd_count<WT>(wend);
+                            WT nw = 0;
+                            if (pos != 0) {
+                                const WT codes = k >= cfg.CW ? crun : ((crun & (((WT)1 << (k * B)) - 1u)) | ((wend >> kCntBits) << (k * B))) & field_mask;
+                                nw = (codes << kCntBits) | (WT)(have < cfg.CW ? have : cfg.CW);
+                            }
+                            SA[dst] = pos;
+                            WN[dst] = nw;
+                            BW[dst] = wnd_symbol<WT>(nw, cfg);
+                        }
+                        cc += (uint32_t)__popcll(bc);
+                    }
+                    const uint64_t be = __ballot(endf ? 1 : 0);
+                    if (be) {
+#pragma unroll
+                        for (int d = 1; d < 8; ++d) {
+                            const bool mine = endf && dd == (uint32_t)d;
+                            const uint64_t bd = __ballot(mine ? 1 : 0);
+                            if (bd) {
+                                if (mine) {
+                                    const uint32_t o = cd[d] + (uint32_t)__popcll(bd & lanemask_lt());
+                                    const uint32_t dst = dir > 0 ? curD[d] + o : curD[d] - 1u - o, pos = p - j;
+                                    const WT nw = pos == 0 ? (WT)0 : wnd_pop<WT>(wend, cfg); // (pos = p - r - 1 > 0: the window held two symbols at least)
+                                    SA[dst] = pos;
+                                    WN[dst] = nw;
+                                    BW[dst] = wnd_symbol<WT>(nw, cfg);
+                                }
+                                cd[d] += (uint32_t)__popcll(bd);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (t < 8) {
+                // everything written: the cursors behind it; what is still inside its run after kRunCap rounds is the next range
+                const uint32_t tot = (uint32_t)t == c ? cf_hr[kRunCap] : cf_he[t][kRunCap]; // (sums below the last index: a run of
+                                                                                           //  kRunCap is never an end, and round kRunCap's entries lie below cf_hr[kRunCap])
+                const uint32_t before = gbase[t];
+                gbase[t] = dir > 0 ? before + tot : before - tot;
+                if ((uint32_t)t == c) {
+                    const uint32_t from = rmax < kRunCap ? tot : cf_hr[kRunCap - 1u];
+                    s_range[0] = dir > 0 ? before + from : before - tot;
+                    s_range[1] = dir > 0 ? before + tot : before - from;
+                }
+            }
+            held = false;
+            last_batch = true;
+            last_in = len;
+            it += J;
+            __syncthreads();
+            continue;
+        }
         if (!held) { // the range's entries from memory (the first round of a launch, or after a jump)
             live = 0;
             // (a range of 1700 entries as 8 to a thread would keep four waves busy, one to a SIMD, every wait of theirs
@@ -442,6 +648,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
         // rounds of this step: eight when the last step kept at least an eighth of its entries (runs), else one
         const uint32_t nr = (uint64_t)len * 8 >= last_in ? (uint32_t)kTailBatch : 1u; // uniform
         last_in = len;
+        last_batch = nr > 1;
         if (nr > 1) { // windows that do not reach nr + 1 symbols deep are refilled first, all of a thread's refills in flight together
             WT fresh[kIndItems];
             uint32_t dry = 0;

@@ -267,6 +267,37 @@ def test_runs_of_many_lengths(emu_ctx):
         assert (_sa(emu_ctx, x, sigma) == oracle.sa_is(x, sigma)).all(), sigma
 
 
+def test_runs_closed_form(emu_ctx):
+    """runs of 1 ... 330 symbols with differing lengths alive in a bucket at once: the tail kernel's closed form (the harness
+    takes it from 4 entries on) -- in both passes, with runs beyond its 255-symbol look (those are carried on), at both
+    ends of the text, and with several entries a thread; SA and BWT against the oracle"""
+    rng = np.random.default_rng(7)
+    cases = [(5, 60000, 350), (8, 60000, 350)]
+    if os.environ.get("STRALG_EMU_ASAN") != "1":
+        cases.append((3, 60000, 200))
+    for sigma, n, k in cases:
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        starts = rng.integers(0, n - 400, size=k)
+        lens = rng.integers(1, 331, size=k)
+        syms = rng.integers(1, sigma, size=k)
+        for a, l, c in zip(starts.tolist(), lens.tolist(), syms.tolist()):
+            x[a:a + l] = c
+        x[:270] = 1
+        x[n - 300:] = sigma - 1
+        want = oracle.sa_is(x, sigma)
+        sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+        emu_ctx.sa_bwt_build_dev(x, n, sigma, sa, bw)
+        assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), sigma
+    if os.environ.get("STRALG_EMU_ASAN") != "1":
+        # 2600 runs of the largest symbol alive at once: three entries a thread
+        n = 400000
+        x = rng.integers(1, 5, size=n, dtype=np.uint8)
+        starts = np.sort(rng.choice(n // 150 - 2, size=2600, replace=False)) * 150
+        for a, l in zip(starts.tolist(), rng.integers(20, 140, size=2600).tolist()):
+            x[a:a + l] = 4
+        assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all()
+
+
 def test_both_induce_round_forms(emu_ctx):
     """large rounds (count / offsets / scatter launches; for more than 8 buckets the radix-pass form over tiles of 8192
     entries, with its one-launch and its three-launch offsets) and small rounds (one chained launch, the tail kernel)"""

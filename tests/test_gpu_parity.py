@@ -265,6 +265,30 @@ def test_runs_of_many_lengths(gpu_ctx):
         assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is(x, sigma)).all(), sigma
 
 
+def test_thousands_of_runs_closed_form(gpu_ctx):
+    """thousands of runs of 1 ... 330 symbols of every symbol alive in a bucket at once (poly-A tracts, microsatellites): the
+    tail kernel's closed form -- run lengths by one look at the text, every round's place from their histogram --, with
+    runs beyond its 255-symbol look, runs at both ends of the text, 1, 3 and 8 entries a thread; SA and BWT"""
+    import torch
+    rng = np.random.default_rng(41)
+    for sigma, n, k in ((5, 1 << 21, 900), (5, 1 << 22, 9000), (8, 1 << 21, 6000), (3, 1 << 20, 2500)):
+        x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+        starts = rng.integers(0, n - 400, size=k)
+        lens = rng.integers(1, 331, size=k)
+        syms = rng.integers(1, sigma, size=k)
+        for a, l, c in zip(starts.tolist(), lens.tolist(), syms.tolist()):
+            x[a:a + l] = c
+        x[:270] = 1
+        x[n - 300:] = sigma - 1
+        want = oracle.sa_is(x, sigma)
+        d = torch.from_numpy(x).cuda()
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+        gpu_ctx.sa_bwt_build_dev(d, n, sigma, sa, bw)
+        assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n, k)
+        assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), (sigma, n, k)
+
+
 def test_both_induce_round_forms(gpu_ctx):
     """every round through the chained launch (look-back across up to thousands of tiles), every round
     through the three-launch form, and the default mix"""
