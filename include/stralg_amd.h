@@ -91,6 +91,8 @@ typedef struct sx_build_stats {
     uint32_t recursion_levels; /* reduced strings over a byte alphabet that were sorted by the pipeline itself, one below the other */
     uint32_t sample_tied_permille; /* 0: no sample was looked at; else 1 + the tied share (per mille) of the sampled suffixes under
                                       the longest prefix key: from 300 on the prefix-key sort is not attempted */
+    uint32_t long_subbuckets; /* hybrid prefix-key sort: sub-buckets too long for a workgroup's LDS (repeat families, AT-rich
+                                 prefixes) that were ordered by HBM passes of their own */
 } sx_build_stats;
 
 /* ---- context ------------------------------------------------------------ */
@@ -135,6 +137,9 @@ enum {
     ,SX_FLAG_TEXT_KEYS_OFF = 14    /* the direct sort of all suffixes and the LMS sort of four-letter texts: 1 = a key kernel writes
                                        the keys before the first radix pass (rounds 1 - 3); 0 (default) = the first pass computes them
                                        from the text */
+    ,SX_FLAG_LONG_SUBBUCKETS_OFF = 15 /* hybrid prefix-key sort: 1 = a sub-bucket too long for a workgroup makes the whole sort fall
+                                       back to plain passes, and texts with skewed symbol counts do not try it (rounds 1 - 3); 0
+                                       (default) = such sub-buckets are listed and ordered by HBM passes of their own */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

@@ -25,7 +25,7 @@ class BuildStats(C.Structure):
                 ("doubling_rounds", C.c_uint32), ("induce_rounds", C.c_uint32),
                 ("sort_passes", C.c_uint32), ("lms_path", C.c_uint32), ("sort_local", C.c_uint32), ("refine_tiers", C.c_uint32),
                 ("ms_total", C.c_double), ("induce_redo", C.c_uint32), ("long_runs", C.c_uint32),
-                ("recursion_levels", C.c_uint32), ("sample_tied_permille", C.c_uint32)]
+                ("recursion_levels", C.c_uint32), ("sample_tied_permille", C.c_uint32), ("long_subbuckets", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

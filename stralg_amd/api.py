@@ -254,6 +254,11 @@ class Context:
         its keys from the text (default) or reads them from a key kernel's output (rounds 1 - 3)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 14, 0 if on else 1), "sx_ctx_set_flag")
 
+    def set_long_subbuckets(self, on=True):
+        """SX_FLAG_LONG_SUBBUCKETS_OFF: the hybrid prefix-key sort lists sub-buckets too long for a workgroup and orders them
+        by HBM passes of their own (default), or falls back to plain passes when it meets one (rounds 1 - 3)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 15, 0 if on else 1), "sx_ctx_set_flag")
+
     def set_recurse_min(self, symbols):
         """SX_FLAG_RECURSE_MIN: reduced strings of at most 255 names recurse from this length on (negative: default)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 11, int(symbols)), "sx_ctx_set_flag")

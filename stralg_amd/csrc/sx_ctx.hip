@@ -182,6 +182,7 @@ int sx_child_begin(sx_ctx *ctx, sx_ctx **out)
     c->induce_attended = ctx->induce_attended;
     c->induce_no_hoist = ctx->induce_no_hoist;
     c->text_keys_off = ctx->text_keys_off;
+    c->long_subbuckets_off = ctx->long_subbuckets_off;
     c->copy_text_first = ctx->copy_text_first;
     c->recurse_min = ctx->recurse_min;
     c->sample_min = ctx->sample_min;
@@ -343,6 +344,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     }
     if (flag == SX_FLAG_TEXT_KEYS_OFF) {
         ctx->text_keys_off = value ? 1 : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_LONG_SUBBUCKETS_OFF) {
+        ctx->long_subbuckets_off = value ? 1 : 0;
         return 0;
     }
     if (flag == SX_FLAG_INDUCE_NO_HOIST) {

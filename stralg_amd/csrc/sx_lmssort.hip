@@ -917,6 +917,7 @@ int sx_prefix_ties_sampled(sx_ctx *ctx, const sx_text_info &ti, sx_arena am, boo
     return 0;
 }
 
+constexpr uint32_t kLongCap = 16384; // sub-buckets too long for a workgroup that the hybrid sort lists (sx_long_subbuckets)
 size_t sx_lms_prefix_bytes(uint64_t m)
 {
     const size_t a = 256;
@@ -929,6 +930,7 @@ size_t sx_lms_prefix_bytes(uint64_t m)
     b += 3 * (cap + a);     // heads
     b += 2 * ((m / 8192 + 2) * 4 + a); // tie counts and offsets per tile of the sorted keys
     b += 3 * (size_t)(m / 4096 + 2) * 4 + a; // the same, and the owned range's start, per workgroup of the local sort
+    b += 3 * (size_t)kLongCap * 4 + a;       // starts, lengths, offsets of the sub-buckets too long for a workgroup
     return b + 4096;
 }
 
@@ -1010,6 +1012,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     uint32_t *tile_cnt = am.take<uint32_t>(tied_tiles), *tile_pos = am.take<uint32_t>(tied_tiles);
     const uint32_t ls_tiles = sx_local_sort_tiles(m);
     uint32_t *tile_lsrt = am.take<uint32_t>(3 * (size_t)ls_tiles); // start, tied members, offset of every local-sort workgroup
+    // sub-buckets too long for a workgroup (repeat families, AT-rich prefixes): their starts, lengths, offsets (sx_long_subbuckets)
+    uint32_t *long_list = ctx->long_subbuckets_off ? nullptr : am.take<uint32_t>(3 * (size_t)kLongCap);
     if (!tile_cnt || !tile_pos || !seedw || !ka || !kb || !va || !vb || !key_keep || !rk_a || !rk_b || !apos || !apos2 || !ap || !ap2 || !ap_new ||
         !agid || !ord_a || !ord_b || !gsize || !sub_t || !sub_gid || !head || !head2 || !head_new || !d_scalar)
         return sx_fail_msg(ctx, SX_E_INTERNAL, "arena: LMS prefix sort");
@@ -1115,6 +1119,15 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 for (int tb = SX_DENSE4_TOP; tb <= 24 && !dense_fits; tb += 2) {
                     const double sy = (double)tb / 2.0, mean_d = (double)m / pow(eff, sy), top_d = (double)m * pow(pmax, sy);
                     if (top_d <= 1.5 * mean_d && 4.5 * top_d * 1.5 <= 1024.0 && sx_local_sort_applies(m, kbits, tb)) cand0 = tb, dense_fits = true;
+                }
+                // Round 4: skewed symbol counts and repeat families no longer rule the hybrid sort out -- the sub-buckets that
+                // do not fit a workgroup are listed and ordered by HBM passes of their own (sx_long_subbuckets) --, so what
+                // counts is the mean sub-bucket (the genome-like 1 GiB text: 115 pairs at 22 bits, 6 % of the pairs in long
+                // sub-buckets): three HBM passes and the LDS step instead of five passes, a key kernel and the pass that marks
+                // the ties.  (A text whose long sub-buckets hold a quarter of the pairs falls back as before.)
+                for (int tb = SX_DENSE4_TOP; tb <= 24 && !dense_fits && long_list != nullptr; tb += 2) {
+                    const double mean_d = (double)m / pow(eff, (double)tb / 2.0);
+                    if (mean_d <= 256.0 && sx_local_sort_applies(m, kbits, tb)) cand0 = tb, dense_fits = true;
                 }
             }
             for (int ci = 0; ci < 2 && top_bits == 0; ++ci) {
@@ -1226,10 +1239,24 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 longest = est < 1.0 ? 1u : (est > 1e9 ? 1000000000u : (uint32_t)est);
             }
             SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, top_bits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
-                                 tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar, longest));
-            uint32_t res[2] = {0, 0};
-            SX_TRY(sx_readback(ctx, d_scalar, 2, res));
-            if (!(res[1] & 1u)) {
+                                 tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar, longest,
+                                 long_list, kLongCap));
+            uint32_t res[3] = {0, 0, 0};
+            SX_TRY(sx_readback(ctx, d_scalar, 3, res));
+            bool fits = !(res[1] & 1u);
+            ctx->stats.long_subbuckets = 0;
+            if (fits && res[2] != 0) {
+                // sub-buckets that did not fit a workgroup were left out and listed: their members are ordered by HBM passes of
+                // their own (the refinement's arrays are free until the ties are refined: a quarter of the pairs at most)
+                uint32_t tied_all = res[0], pairs = 0;
+                int done = 0;
+                SX_TRY(sx_long_subbuckets(ctx, kin, vin, m, kbits, top_bits, res[2], long_list, kLongCap, rk_a, rk_b, ord_a, ord_b, cap - 1024, vo,
+                                          embed ? seedw : nullptr, apos, ap, head, cap, res[0], d_scalar + 4, &tied_all, &pairs, &done));
+                ctx->stats.long_subbuckets = res[2];
+                fits = done != 0;
+                res[0] = done ? tied_all : res[0] + pairs; // (not done: those pairs are as good as tied -- the decision below)
+            }
+            if (fits) {
                 A = res[0];
                 vs = vo;
                 ks = nullptr; // (the sorted keys are not written by this path; nothing below reads them)

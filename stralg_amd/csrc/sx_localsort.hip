@@ -16,7 +16,11 @@
 // 13 B of the pass that looked for equal neighbours.
 //
 // A sub-bucket that does not fit a workgroup's LDS (a text with many copies of one 10-symbol
-// prefix) makes the kernel raise a flag; the caller then finishes with plain LSD passes.
+// prefix: a repeat family, an AT-rich prefix of a genome) is left out and put on a list: the
+// members of all such long sub-buckets are gathered into one array, ordered by (sub-bucket,
+// low bits) with HBM passes of their own and written to the same outputs (sx_long_subbuckets).
+// Without a list (or with more long sub-buckets than it holds) the kernel raises a flag; the
+// caller then finishes with plain LSD passes.
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
@@ -45,12 +49,13 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
     uint32_t *__restrict__ tile_cnt, uint2 *__restrict__ stage, uint8_t *__restrict__ stage_head,
-    uint32_t *__restrict__ fail, uint32_t span /* kLsSpan, or more where the sub-buckets are known to be short */)
+    uint32_t *__restrict__ fail, uint32_t span /* kLsSpan, or more where the sub-buckets are known to be short */,
+    uint32_t *__restrict__ long_list /* or null */, uint32_t *__restrict__ long_count, uint32_t long_cap)
 {
     __shared__ uint64_t K[kLsCap]; // keys; then (payload << 32 | sub-bucket rank << L | low bits); per-wave counters during a ranking
     __shared__ uint32_t V[kLsCap]; // positions
     __shared__ uint32_t bnd[kLsWords], bpre[kLsWords]; // sub-bucket starts as bits; starts before each word
-    __shared__ uint32_t s_first, s_end, s_scan[kLsWaves], s_kprev[2], s_max;
+    __shared__ uint32_t s_first, s_end, s_last, s_scan[kLsWaves], s_kprev[2], s_max;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const uint64_t g0 = (uint64_t)blockIdx.x * span;
     const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
     if (t == 0) {
         s_first = kNone;
         s_end = kNone;
+        s_last = 0;
         const uint64_t kp = g0 ? kin[g0 - 1] : 0ull;
         s_kprev[0] = (uint32_t)kp, s_kprev[1] = (uint32_t)(kp >> 32);
     }
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         const bool start = i == 0 ? (g0 == 0 || ((kprev & kmask) >> L) != idc) : ((K[i - 1] & kmask) >> L) != idc;
         if (start) {
             atomicOr(&bnd[i >> 5], 1u << (i & 31u));
-            if (i < span) atomicMin(&s_first, i);
+            if (i < span) atomicMin(&s_first, i), atomicMax(&s_last, i);
             else atomicMin(&s_end, i);
         }
     }
@@ -103,12 +109,17 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         if (t == 0) tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
         return;
     }
-    if (e == kNone) { // the sub-bucket across the span's end is longer than the reach (uniform)
+    if (e == kNone) { // the sub-bucket across the span's end -- the last one that starts in the span -- is longer than the reach (uniform)
+        const uint32_t z = s_last;
         if (t == 0) {
-            atomicOr(fail, 1u);
-            tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
+            // on the list of long sub-buckets (sx_long_subbuckets orders them); no list, or a full one: the whole sort falls back
+            const uint32_t at = long_list ? atomicAdd(long_count, 1u) : long_cap;
+            if (at < long_cap) long_list[at] = (uint32_t)(g0 + z);
+            else atomicOr(fail, 1u);
+            if (z == s) tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
         }
-        return;
+        if (z == s) return;
+        e = z; // the sub-buckets in front of it are this workgroup's as ever
     }
     const uint32_t n_loc = e - s;
     // ---- sub-bucket rank of every owned pair: starts in (s, i], from the bit array ---------------------------------
@@ -397,11 +408,136 @@ __global__ __launch_bounds__(kBlock) void local_tied_gather_kernel(const uint32_
     }
 }
 
+// ---- long sub-buckets --------------------------------------------------------------------------------------------------
+// where each listed sub-bucket ends: the pairs are ordered by their top bits, so the first pair behind `start` with other
+// top bits is found by bisection (a thread a sub-bucket)
+__global__ __launch_bounds__(kBlock) void long_ends_kernel(const uint64_t *__restrict__ kin, uint64_t m, uint32_t L, uint32_t kbits,
+                                                           const uint32_t *__restrict__ starts, uint32_t n_long,
+                                                           uint32_t *__restrict__ lens)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_long) return;
+    const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+    const uint64_t start = starts[i], id = (kin[start] & kmask) >> L;
+    uint64_t lo = start + 1, hi = m; // the end lies in [lo, hi]
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (((kin[mid] & kmask) >> L) == id) lo = mid + 1;
+        else hi = mid;
+    }
+    lens[i] = (uint32_t)(lo - start);
+}
+
+// the sub-bucket of slot e of the gathered array: the last one whose offset is <= e
+__device__ __forceinline__ uint32_t long_find(const uint32_t *__restrict__ offs, uint32_t n_long, uint32_t e)
+{
+    uint32_t lo = 0, hi = n_long; // offs[lo] <= e < offs[hi] (offs[n_long] = the total, not stored)
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offs[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// members of the long sub-buckets, one behind the other; the key's top bits (equal inside a sub-bucket) make way for the
+// sub-bucket's number on the list, so that HBM passes over (number, low bits) order every sub-bucket by its low bits
+__global__ __launch_bounds__(kBlock) void long_gather_kernel(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                             uint32_t L, uint32_t kbits, const uint32_t *__restrict__ starts,
+                                                             const uint32_t *__restrict__ offs, uint32_t n_long, uint32_t total,
+                                                             uint64_t *__restrict__ ck, uint32_t *__restrict__ cv)
+{
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= total) return;
+    const uint32_t idx = long_find(offs, n_long, e);
+    const uint64_t g = (uint64_t)starts[idx] + (e - offs[idx]);
+    const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull), lowmask = (1ull << L) - 1ull;
+    const uint64_t key = kin[g];
+    ck[e] = (key & ~kmask) | ((uint64_t)idx << L) | (key & lowmask);
+    cv[e] = vin[g];
+}
+
+// what local_sort_kernel writes for its pairs, from the gathered array in (number, low bits) order: positions, windows,
+// and the members of groups of equal keys behind the `tied0` members the workgroups listed (device_compact's functors)
+struct InLongTied {
+    const uint64_t *k;
+    uint64_t total, cmp; // cmp: the bits of (number, low bits)
+    __device__ __forceinline__ bool operator()(uint64_t i) const
+    {
+        const uint64_t x = k[i] & cmp;
+        return (i > 0 && (k[i - 1] & cmp) == x) || (i + 1 < total && (k[i + 1] & cmp) == x);
+    }
+};
+struct OutLongMember {
+    const uint64_t *k;
+    const uint32_t *v, *starts, *offs;
+    uint64_t cmp;
+    uint32_t L, kbits, idmask, tied0, cap;
+    uint32_t *vout, *seedw, *apos, *ap;
+    uint8_t *ahead;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t dst, bool tied) const
+    {
+        const uint64_t key = k[i];
+        const uint32_t idx = (uint32_t)(key >> L) & idmask, pos = v[i];
+        const uint64_t g = (uint64_t)starts[idx] + ((uint32_t)i - offs[idx]);
+        vout[g] = pos;
+        if (seedw) seedw[g] = (uint32_t)(key >> kbits);
+        if (tied) {
+            const uint64_t slot = (uint64_t)tied0 + dst;
+            if (slot < cap) {
+                apos[slot] = (uint32_t)g;
+                ap[slot] = pos;
+                ahead[slot] = (uint8_t)((i > 0 && (k[i - 1] & cmp) == (key & cmp)) ? 0u : 1u);
+            }
+        }
+    }
+};
+
 } // namespace sx
 
 using namespace sx;
 
 uint32_t sx_local_sort_tiles(uint64_t m) { return sx_div_up(m, kLsSpan); }
+
+// The long sub-buckets local_sort_kernel listed (n_long starts in long_list; long_list holds 3 * long_cap words: starts,
+// lengths, offsets).  *done = 0 when they hold more pairs than `max_pairs` (the scratch arrays' size; the caller falls back
+// to plain passes); else every output of sx_local_sort is complete, *tied_total = tied0 + their tied members.
+int sx_long_subbuckets(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t n_long,
+                       uint32_t *long_list, uint32_t long_cap, uint64_t *ck_a, uint64_t *ck_b, uint32_t *cv_a, uint32_t *cv_b,
+                       uint32_t max_pairs, uint32_t *vout, uint32_t *seedw, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
+                       uint32_t tied0, uint32_t *d_scalar2 /* two words of device scratch */, uint32_t *tied_total, uint32_t *pairs,
+                       int *done)
+{
+    *done = 0;
+    *pairs = 0;
+    *tied_total = tied0;
+    if (n_long == 0 || n_long > long_cap) return 0;
+    const uint32_t L = (uint32_t)(kbits - top_bits);
+    uint32_t *starts = long_list, *lens = long_list + long_cap, *offs = long_list + 2 * (size_t)long_cap;
+    sx_launch(ctx, SX_KC_LOCAL_SORT, (uint64_t)n_long * 256, long_ends_kernel, dim3(sx_div_up(n_long, kBlock)), dim3(kBlock), kin, m, L,
+              (uint32_t)kbits, (const uint32_t *)starts, n_long, lens);
+    SX_TRY((device_scan<OpAdd>(ctx, n_long, InU32{lens}, OutExclusive{offs}, d_scalar2, SX_KC_LOCAL_SORT, 0)));
+    uint32_t total = 0;
+    SX_TRY(sx_readback(ctx, d_scalar2, 1, &total));
+    *pairs = total;
+    if (total == 0 || total > max_pairs) return 0;
+    sx_launch(ctx, SX_KC_LOCAL_SORT, (uint64_t)total * 24, long_gather_kernel, dim3(sx_div_up(total, kBlock)), dim3(kBlock), kin, vin, L,
+              (uint32_t)kbits, (const uint32_t *)starts, (const uint32_t *)offs, n_long, total, ck_a, cv_a);
+    const int idbits = n_long > 1 ? sx_bitlen(n_long - 1) : 1;
+    int f = 0;
+    SX_TRY(sx_sort_pairs(ctx, ck_a, cv_a, ck_b, cv_b, total, 0, (int)L + idbits, &f));
+    const uint64_t *ks = f ? ck_b : ck_a;
+    const uint32_t *vs = f ? cv_b : cv_a;
+    const uint64_t cmp = (1ull << (L + (uint32_t)idbits)) - 1ull;
+    SX_TRY((device_compact(ctx, total, InLongTied{ks, total, cmp},
+                           OutLongMember{ks, vs, starts, offs, cmp, L, (uint32_t)kbits, (1u << idbits) - 1u, tied0, cap, vout, seedw, apos, ap, ahead},
+                           d_scalar2 + 1, SX_KC_LOCAL_SORT, (uint64_t)total * 28)));
+    uint32_t tied = 0;
+    SX_TRY(sx_readback(ctx, d_scalar2 + 1, 1, &tied));
+    *tied_total = tied0 + tied;
+    *done = 1;
+    return 0;
+}
 
 bool sx_local_sort_applies(uint64_t m, int kbits, int top_bits)
 {
@@ -413,8 +549,9 @@ bool sx_local_sort_applies(uint64_t m, int kbits, int top_bits)
 int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t *vout,
                   uint32_t *seedw, uint32_t *tile_start, uint32_t *tile_cnt, uint32_t *tile_off, uint2 *stage,
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
-                  uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used */,
-                  uint32_t longest_expected)
+                  uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used,
+                                                [2] <- long sub-buckets listed */,
+                  uint32_t longest_expected, uint32_t *long_list, uint32_t long_cap)
 {
     // The span: a workgroup's costs that do not depend on its pairs (zeroing and scanning 8192 counters, the barriers) are
     // spread over more pairs the longer it is (1 GiB of DNA, dense keys: span 5120 2.79 ms, 5632 2.60, 5888 2.52), but a
@@ -427,9 +564,10 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
     if (span < (uint32_t)kLsSpan) span = (uint32_t)kLsSpan;
     const uint32_t tiles = sx_div_up(m, span);
     const uint32_t L = (uint32_t)(kbits - top_bits);
-    SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, sizeof(uint32_t), ctx->stream));
+    SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, 2 * sizeof(uint32_t), ctx->stream));
     sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
-              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span);
+              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
+              d_total_and_fail + 2, long_list ? long_cap : 0u);
     SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_cnt}, OutExclusive{tile_off}, d_total_and_fail, SX_KC_NAMES, 0)));
     sx_launch(ctx, SX_KC_NAMES, 0, local_tied_gather_kernel, dim3(tiles), dim3(kBlock), (const uint32_t *)tile_start,
               (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, (const uint2 *)stage, (const uint8_t *)stage_head, apos, ap,

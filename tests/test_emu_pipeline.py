@@ -174,10 +174,31 @@ def test_hybrid_prefix_sort(emu_ctx):
         reps = 6500
         x = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=6, dtype=np.uint8)]) for _ in range(reps)])
         emu_ctx.set_prefix_symbols(17)
-        sa = _sa(emu_ctx, x, 5)
-        st = emu_ctx.last_stats()
-        assert st["sort_local"] == 0, st
-        assert (sa == oracle.sa_is(x, 5)).all()
+        want = oracle.sa_is(x, 5)
+        for long_on in (False, True):  # (rounds 1 - 3: plain passes; round 4: listed, and ordered by HBM passes of their own)
+            emu_ctx.set_long_subbuckets(long_on)
+            sa = _sa(emu_ctx, x, 5)
+            st = emu_ctx.last_stats()
+            assert (st["sort_local"] & 1, st["long_subbuckets"] > 0) == ((1, True) if long_on else (0, False)), st
+            assert (sa == want).all(), long_on
+        # 7000 copies of a 30-symbol piece scattered over a random text: a handful of sub-buckets no workgroup can hold with a
+        # tenth of the pairs -- listed by the workgroups that meet them and ordered by HBM passes of their own
+        # (sx_long_subbuckets); without the list (rounds 1 - 3) the whole sort falls back to plain passes
+        n = 1 << 20
+        x = rng.integers(1, 5, size=n, dtype=np.uint8)
+        piece = np.array([2, 4, 1, 3, 3, 1, 4, 2, 1, 2, 4, 3, 1, 1, 3, 2, 4, 4, 1, 2, 3, 1, 4, 2, 2, 3, 1, 4, 3, 2], np.uint8)
+        for a in (rng.choice(n // 32 - 2, size=7000, replace=False) * 32).tolist():
+            x[a:a + 30] = piece
+        want = oracle.sa_is(x, 5)
+        for long_on, text_keys in ((True, True), (True, False), (False, True)):
+            emu_ctx.set_long_subbuckets(long_on)
+            emu_ctx.set_text_keys(text_keys)
+            sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+            emu_ctx.sa_bwt_build_dev(x, n, 5, sa, bw)
+            st = emu_ctx.last_stats()
+            assert (st["sort_local"] & 1, st["long_subbuckets"] > 0) == ((1, True) if long_on else (0, False)), st
+            assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (long_on, text_keys)
+        emu_ctx.set_text_keys(True)
         # the direct sort of all suffixes of a wide alphabet through the same path
         x = synth(30000, 256, 5)
         x[100:112] = x[1000:1012]
@@ -192,6 +213,7 @@ def test_hybrid_prefix_sort(emu_ctx):
         emu_ctx.set_sort_mode(0)
         emu_ctx.set_prefix_symbols(0)
         emu_ctx.set_text_keys(True)
+        emu_ctx.set_long_subbuckets(True)
 
 
 def test_long_repeats_finish_by_comparison(emu_ctx):

@@ -230,9 +230,41 @@ def test_hybrid_prefix_sort(gpu_ctx):
         x = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=6, dtype=np.uint8)]) for _ in range(20000)])
         gpu_ctx.set_prefix_symbols(17)
         gpu_ctx.set_sort_mode(2)
+        want = oracle.sa_is(x, 5)
+        gpu_ctx.set_long_subbuckets(False)  # rounds 1 - 3: a sub-bucket no workgroup can hold -> plain passes
         sa = gpu_ctx.sa_build(x, 5)
         assert gpu_ctx.last_stats()["sort_local"] == 0
-        assert (sa == oracle.sa_is(x, 5)).all()
+        assert (sa == want).all()
+        gpu_ctx.set_long_subbuckets(True)   # round 4: listed, and ordered by HBM passes of their own
+        sa = gpu_ctx.sa_build(x, 5)
+        st = gpu_ctx.last_stats()
+        assert st["sort_local"] & 1 and st["long_subbuckets"] > 0, st
+        assert (sa == want).all()
+        # a repeat family and AT-rich prefixes in a random text (what a genome looks like to the sort): 20 000 copies of a
+        # 60-symbol element with 5 % of their symbols redrawn, 30 % A and T -- sub-buckets of tens of thousands of pairs beside
+        # the ordinary ones; listed, gathered, ordered by HBM passes of their own (sx_long_subbuckets), with both first passes
+        n = 1 << 24
+        x = (1 + np.searchsorted(np.array([0.3, 0.5, 0.7]), rng.random(n))).astype(np.uint8)
+        elem = rng.integers(1, 5, size=60, dtype=np.uint8)
+        for a in (rng.choice(n // 64 - 2, size=20000, replace=False) * 64).tolist():
+            c = elem.copy()
+            mut = rng.random(60) < 0.05
+            c[mut] = rng.integers(1, 5, size=int(mut.sum()), dtype=np.uint8)
+            x[a:a + 60] = c
+        want = oracle.sa_is(x, 5)
+        gpu_ctx.set_prefix_symbols(0)
+        for mode, text_keys in ((0, True), (2, False)):
+            gpu_ctx.set_sort_mode(mode)
+            gpu_ctx.set_text_keys(text_keys)
+            d = torch.from_numpy(x).cuda()
+            sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+            bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+            gpu_ctx.sa_bwt_build_dev(d, n, 5, sa, bw)
+            st = gpu_ctx.last_stats()
+            assert st["lms_path"] == 1 and st["sort_local"] & 1 and st["long_subbuckets"] > 0, (mode, st)
+            assert (sa.cpu().numpy().view(np.uint32) == want).all(), mode
+            assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), mode
+        gpu_ctx.set_text_keys(True)
         # wider digits
         gpu_ctx.set_sort_mode(1)
         x = synth(1 << 21, 5, 32)
@@ -245,6 +277,7 @@ def test_hybrid_prefix_sort(gpu_ctx):
         gpu_ctx.set_sort_mode(0)
         gpu_ctx.set_radix_digit_bits(0)
         gpu_ctx.set_text_keys(True)
+        gpu_ctx.set_long_subbuckets(True)
 
 
 def test_runs_of_many_lengths(gpu_ctx):
