@@ -14,6 +14,7 @@ from collections import defaultdict
 
 CLASS_OF = [
     # round 4's kernels (first: the first match counts)
+    ("long_ends_kernel", "local_sort"), ("long_gather_kernel", "local_sort"), ("InLongTied", "local_sort"),
     ("hoist_scatter_kernel", "induce_scatter"), ("hoist_count_kernel", "induce_gather"), ("hoist_offsets_kernel", "induce_scan"),
     ("hoist_tables_kernel", "induce_scan"), ("bucket_begin_kernel", "induce_scan"), ("bigram_kernel", "induce_gather"),
     ("widen_windows_kernel", "induce_gather"), ("radix_hist_text_kernel", "radix_hist"), ("radix_hist_lms_kernel", "radix_hist"), ("radix_scatter_lms_kernel", "keys"), ("radix_scatter_kernel<8, true, true>", "keys"), ("radix_hist_digits_kernel", "radix_hist"),
