@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         const bool start = i == 0 ? (g0 == 0 || ((kprev & kmask) >> L) != idc) : ((K[i - 1] & kmask) >> L) != idc;
         if (start) {
             atomicOr(&bnd[i >> 5], 1u << (i & 31u));
-            if (i < span) atomicMin(&s_first, i), atomicMax(&s_last, i);
+            if (i < span) atomicMin(&s_first, i);
             else atomicMin(&s_end, i);
         }
     }
@@ -110,6 +110,19 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         return;
     }
     if (e == kNone) { // the sub-bucket across the span's end -- the last one that starts in the span -- is longer than the reach (uniform)
+        if (t == 0) { // (rare: the last start below the span's end, from the bit array)
+            uint32_t zz = s;
+            for (int wd = (int)((span - 1u) >> 5); wd >= (int)(s >> 5); --wd) {
+                uint32_t bits = bnd[wd];
+                if ((uint32_t)wd == ((span - 1u) >> 5) && ((span - 1u) & 31u) != 31u) bits &= (2u << ((span - 1u) & 31u)) - 1u;
+                if (bits) {
+                    zz = (uint32_t)wd * 32u + (31u - (uint32_t)__clz(bits));
+                    break;
+                }
+            }
+            s_last = zz;
+        }
+        __syncthreads();
         const uint32_t z = s_last;
         if (t == 0) {
             // on the list of long sub-buckets (sx_long_subbuckets orders them); no list, or a full one: the whole sort falls back
