@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
     __shared__ uint32_t cf_p[kCfEntries];
     __shared__ WT cf_w[kCfEntries];
     __shared__ uint8_t cf_r[kCfEntries];
-    __shared__ uint32_t cf_hr[kRunCap + 1], cf_he[8][kRunCap + 1], cf_cmax[kCfEntries / kWave], cf_rmax;
+    __shared__ uint32_t cf_hr[kRunCap + 1], cf_he[8][kRunCap + 1], cf_scan[kTailWaves], cf_rmax;
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     if (t < 8) gbase[t] = cursor_cur[t];
     if (t == 0) {
@@ -452,7 +452,6 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
             len >= kClosedFrom && len <= kCfEntries) { // uniform
             if (t <= (int)kRunCap) cf_hr[t] = 0;
             for (uint32_t i = (uint32_t)t; i < (kRunCap + 1) * 8; i += kTailBlock) (&cf_he[0][0])[i] = 0;
-            if (t < (int)(kCfEntries / kWave)) cf_cmax[t] = 0;
             __syncthreads();
             const uint64_t cpat = 0x0101010101010101ull * (uint64_t)c;
             const uint32_t per2 = (len + (uint32_t)kTailBlock - 1u) / (uint32_t)kTailBlock;
@@ -499,7 +498,6 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
                         const uint32_t d = wnd_first<WT>(wend, cfg);
                         if (induce_accept(d, c, mode)) atomicAdd(&cf_he[d & 7u][r], 1u);
                     }
-                    atomicMax(&cf_cmax[i >> 6], r);
                 }
             }
             __syncthreads();
@@ -553,15 +551,52 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
             WT crun = 0; // CW codes of symbol c: the window of an entry at least CW symbols inside its run
             for (uint32_t i = 0; i < cfg.CW; ++i) crun = (crun << B) | (WT)(c - 1u);
             const WT field_mask = cfg.CW * B >= 8 * sizeof(WT) ? ~(WT)0 : (((WT)1 << (cfg.CW * B)) - 1u);
-            const uint32_t nchunks = (len + (uint32_t)kWave - 1u) / (uint32_t)kWave;
-            for (uint32_t j = 1u + (uint32_t)w; j <= J; j += (uint32_t)kTailWaves) { // uniform per wave
+            // Sixteen rounds (one a wave) at a time; a round looks at every entry that is left.  Entries whose runs ended before
+            // the sixteen are taken out first (in order: a round's places are ranks among the entries alive), once an
+            // eighth of them would go: with run lengths spread over 20 ... 200 the rounds see half of the entries on average.
+            uint32_t cur_len = len;
+            for (uint32_t e0 = 0; e0 < J; e0 += (uint32_t)kTailWaves) { // uniform
+            if (e0 > 0) {
+                const uint32_t alive = cf_hr[e0] - cf_hr[e0 - 1u]; // entries with r >= e0: what the rounds from e0 + 1 on need (ends: r == j - 1)
+                if ((uint64_t)alive * 8 <= (uint64_t)cur_len * 7) { // uniform
+                    constexpr uint32_t kPerC = (kCfEntries + (uint32_t)kTailBlock - 1u) / (uint32_t)kTailBlock;
+                    const uint32_t perc = (cur_len + (uint32_t)kTailBlock - 1u) / (uint32_t)kTailBlock;
+                    uint32_t kp[kPerC], kr[kPerC], keep = 0, cnt = 0;
+                    WT kw[kPerC];
+#pragma unroll
+                    for (uint32_t k = 0; k < kPerC; ++k) {
+                        const uint32_t i = (uint32_t)t * perc + k;
+                        kp[k] = 0, kr[k] = 0, kw[k] = 0;
+                        if (k < perc && i < cur_len) {
+                            kp[k] = cf_p[i], kr[k] = cf_r[i], kw[k] = cf_w[i];
+                            if (kr[k] >= e0) keep |= 1u << k, ++cnt;
+                        }
+                    }
+                    const uint32_t inc = wave_inclusive_scan<OpAdd>(cnt);
+                    if (lane == kWave - 1) cf_scan[w] = inc;
+                    __syncthreads(); // every entry is in its thread's registers
+                    uint32_t at = inc - cnt;
+                    for (int ww = 0; ww < w; ++ww) at += cf_scan[ww];
+#pragma unroll
+                    for (uint32_t k = 0; k < kPerC; ++k) {
+                        if ((keep >> k) & 1u) {
+                            cf_p[at] = kp[k], cf_r[at] = (uint8_t)kr[k], cf_w[at] = kw[k];
+                            ++at;
+                        }
+                    }
+                    cur_len = alive;
+                    __syncthreads();
+                }
+            }
+            const uint32_t nchunks = (cur_len + (uint32_t)kWave - 1u) / (uint32_t)kWave;
+            const uint32_t j = e0 + 1u + (uint32_t)w; // uniform per wave
+            if (j <= J) {
                 uint32_t cc = cf_hr[j - 1u], cd[8];
 #pragma unroll
                 for (int d = 0; d < 8; ++d) cd[d] = cf_he[d][j - 1u];
                 for (uint32_t ch = 0; ch < nchunks; ++ch) {
-                    if (cf_cmax[ch] + 1u < j) continue; // (every run of the chunk ended before this round)
                     const uint32_t i = ch * (uint32_t)kWave + (uint32_t)lane;
-                    const bool valid = i < len;
+                    const bool valid = i < cur_len;
                     const uint32_t r = valid ? cf_r[i] : 0u, p = valid ? cf_p[i] : 0u;
                     const WT wend = valid ? cf_w[i] : (WT)0;
                     const uint32_t dd = wnd_first<WT>(wend, cfg); // (the symbol that ends the run, if there is one)
@@ -606,7 +641,8 @@ __global__ __launch_bounds__(kTailBlock) void induce_tail_small_kernel(uint32_t 
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads(); // (the next sixteen may begin by moving the entries)
+            } // (sixteen rounds)
             if (t < 8) {
                 // everything written: the cursors behind it; what is still inside its run after kRunCap rounds is the next range
                 const uint32_t tot = (uint32_t)t == c ? cf_hr[kRunCap] : cf_he[t][kRunCap]; // (sums below the last index: a run of
