@@ -140,6 +140,10 @@ enum {
     ,SX_FLAG_LONG_SUBBUCKETS_OFF = 15 /* hybrid prefix-key sort: 1 = a sub-bucket too long for a workgroup makes the whole sort fall
                                        back to plain passes, and texts with skewed symbol counts do not try it (rounds 1 - 3); 0
                                        (default) = such sub-buckets are listed and ordered by HBM passes of their own */
+    ,SX_FLAG_SMALL_DIRECT_MAX = 16 /* texts of at most 16 symbols and at most this many suffixes are sorted directly (all suffixes by
+                                       prefix key, as wide alphabets are: a third of the launches of classification + LMS sort +
+                                       induced passes, which is what a short record's build consists of); 0 = never; negative: the
+                                       default */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

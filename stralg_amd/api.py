@@ -259,6 +259,11 @@ class Context:
         by HBM passes of their own (default), or falls back to plain passes when it meets one (rounds 1 - 3)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 15, 0 if on else 1), "sx_ctx_set_flag")
 
+    def set_small_direct_max(self, suffixes):
+        """SX_FLAG_SMALL_DIRECT_MAX: texts of at most 16 symbols and at most this many suffixes are sorted directly
+        (0: never; negative: default)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 16, int(suffixes)), "sx_ctx_set_flag")
+
     def set_recurse_min(self, symbols):
         """SX_FLAG_RECURSE_MIN: reduced strings of at most 255 names recurse from this length on (negative: default)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 11, int(symbols)), "sx_ctx_set_flag")

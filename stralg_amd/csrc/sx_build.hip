@@ -116,8 +116,19 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     // The copy of the text: where the classification comes first (no direct sort of all suffixes to be tried) it makes
     // the copy itself while it reads the text -- all but the last tile or two, which are copied here --; only the tail
     // needs zeroing: sentinel + padding.
+    // Short records of few symbols (round 4): classification + LMS sort + induced passes are 160 dependent launches whatever
+    // the text's length -- 0.9 ms at 2^22 symbols, 0.44 ms at eleven --, the direct sort of all suffixes a third of that,
+    // and on a short text its extra bytes cost less than the launches it saves.
+    // (one MI355X, uniform symbols, suffix array + BWT, tools/small_direct.py: four letters 2^10 0.455 -> 0.144 ms, 2^22 0.79 -> 0.39,
+    //  2^24 1.20 -> 0.78, 2^25 1.56 -> 1.47, 2^26 2.04 -> 2.75; seven letters 2^24 1.55 -> 0.74, 2^26 2.50 -> 2.46; fifteen 2^26
+    //  4.76 -> 2.43)
+#ifndef SX_SMALL_DIRECT_MAX
+#define SX_SMALL_DIRECT_MAX ((1ull << 24) + 1ull)
+#endif
+    const uint64_t small_direct_max = ctx->small_direct_max >= 0 ? (uint64_t)ctx->small_direct_max : (uint64_t)SX_SMALL_DIRECT_MAX;
+    const bool small_direct = sigma <= 16 && N <= small_direct_max && N >= 4 && !ctx->no_direct && !ctx->force_general;
     uint32_t src_tiles = 0;
-    if (!ctx->copy_text_first && sigma <= 16 && ((uintptr_t)d_text & 15u) == 0 && n >= (uint64_t)kClsTile + 64) src_tiles = (uint32_t)((n - 64) / kClsTile);
+    if (!small_direct && !ctx->copy_text_first && sigma <= 16 && ((uintptr_t)d_text & 15u) == 0 && n >= (uint64_t)kClsTile + 64) src_tiles = (uint32_t)((n - 64) / kClsTile);
     const uint64_t copied_from = (uint64_t)src_tiles * kClsTile;
     SX_CHECK(hipMemcpyAsync(T + copied_from, d_text + copied_from, n - copied_from, hipMemcpyDeviceToDevice, ctx->stream));
     SX_CHECK(hipMemsetAsync(T + n, 0, padded - n, ctx->stream));
@@ -128,7 +139,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     // tied, the suffixes are sorted directly with the machinery of the LMS sort (radix sort by prefix key, tie
     // refinement); the result is the same suffix array.  Skewed or repetitive texts fail the tie bound inside and
     // continue on the usual path.  Only symbol counts are needed to decide, so this comes before the classification.
-    if (sigma > 16 && !ctx->no_direct && !ctx->force_general) {
+    if ((sigma > 16 || small_direct) && !ctx->no_direct && !ctx->force_general) {
         sx_text_info td;
         memset(&td, 0, sizeof td);
         td.T = T;
@@ -152,7 +163,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         for (double v = eff; v < 16.0 * (double)N && need < 64; v *= eff) ++need; // <= ~6 % of the suffixes tied
         // (measured on uniform symbols, 1 GiB: the induction wins up to 16 symbols -- 4-bit window fields, 8-byte
         //  entries: 42 against 52 ms --, the direct sort from 20 symbols on: 51 ms flat against 53 ... 114 ms)
-        if (td.maxc >= 17 && (double)need * log2((double)td.maxc + 1.0) <= 40.0) {
+        if ((td.maxc >= 17 || (small_direct && td.maxc >= 2)) && (double)need * log2((double)td.maxc + 1.0) <= 40.0) {
             SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(N) + 1024));
             sx_arena am;
             am.base = (char *)ctx->slab[SX_SLAB_M].p;

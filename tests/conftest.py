@@ -271,6 +271,9 @@ def emu_ctx():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "stralg_amd", "csrc"), "emu-asan" if asan else "emu"])
     from stralg_amd.api import Context
     ctx = Context(0, lib_path=EMU_LIB.replace("_emu.so", "_emu_asan.so") if asan else EMU_LIB)
+    # (short records of few symbols are sorted directly by default -- SX_FLAG_SMALL_DIRECT_MAX --: the tests are short records
+    #  and mean the SA-IS kernels unless they say otherwise; test_short_records_direct_sort switches it back on)
+    ctx.set_small_direct_max(0)
     yield ctx
     ctx.close()
 
@@ -281,5 +284,6 @@ def gpu_ctx():
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     from stralg_amd.api import Context
     ctx = Context(0)
+    ctx.set_small_direct_max(0)  # (as in emu_ctx: the tests mean the SA-IS kernels; test_short_records_direct_sort switches it back on)
     yield ctx
     ctx.close()

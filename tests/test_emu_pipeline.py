@@ -320,6 +320,39 @@ def test_runs_closed_form(emu_ctx):
         assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all()
 
 
+def test_short_records_direct_sort(emu_ctx):
+    """SX_FLAG_SMALL_DIRECT_MAX (on by default outside the tests): texts of at most 16 symbols and 2^24 suffixes are sorted
+    directly, all suffixes by prefix key (lms_path 3) -- a third of the launches of classification + LMS sort + induced
+    passes; SA, BWT, C and O against the oracle for 3 ... 16 symbols, with repeats (tie refinement), runs, texts too
+    repetitive for it (they go on to the usual path), and the limit itself"""
+    rng = np.random.default_rng(17)
+    try:
+        emu_ctx.set_small_direct_max(-1)
+        for sigma, n in ((5, 100), (5, 70000), (3, 3000), (4, 20000), (8, 40000), (16, 30000), (12, 9000), (5, 64), (6, 200000)):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            if n > 1000:
+                x[200:260] = x[700:760]
+                x[n - 100:n - 60] = x[300:340]
+                x[n // 2:n // 2 + 300] = 1 + (sigma > 3)
+            want = oracle.sa_is(x, sigma)
+            sa, c, o = emu_ctx.build_tables(x, sigma)
+            st = emu_ctx.last_stats()
+            assert st["lms_path"] == 3, (sigma, n, st)
+            assert (sa == want).all() and (c == oracle.c_table(x, sigma)).all() and (o == oracle.o_table(x, want, sigma)).all(), (sigma, n)
+        # too repetitive for a prefix sort (a period of 2, then all equal): on to the usual path, same answer
+        for x, sigma in ((np.tile(np.array([1, 2], np.uint8), 3000), 3), (np.full(5000, 1, np.uint8), 2)):
+            assert (emu_ctx.sa_build(x, sigma) == oracle.sa_is(x, sigma)).all()
+            assert emu_ctx.last_stats()["lms_path"] != 3
+        # the limit counts suffixes (n + 1)
+        x = rng.integers(1, 5, size=4999, dtype=np.uint8)
+        for limit, path in ((5000, 3), (4999, 1), (0, 1)):
+            emu_ctx.set_small_direct_max(limit)
+            assert (emu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all()
+            assert emu_ctx.last_stats()["lms_path"] == path, limit
+    finally:
+        emu_ctx.set_small_direct_max(0)
+
+
 def test_both_induce_round_forms(emu_ctx):
     """large rounds (count / offsets / scatter launches; for more than 8 buckets the radix-pass form over tiles of 8192
     entries, with its one-launch and its three-launch offsets) and small rounds (one chained launch, the tail kernel)"""

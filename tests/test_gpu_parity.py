@@ -322,6 +322,39 @@ def test_thousands_of_runs_closed_form(gpu_ctx):
         assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), (sigma, n, k)
 
 
+def test_short_records_direct_sort(gpu_ctx):
+    """SX_FLAG_SMALL_DIRECT_MAX (on by default outside the tests): texts of at most 16 symbols and 2^24 suffixes are sorted
+    directly, all suffixes by prefix key (lms_path 3) -- a third of the launches of classification + LMS sort + induced
+    passes; SA, BWT, C and O against the oracle for 3 ... 16 symbols, with repeats (tie refinement), runs, texts too
+    repetitive for it (they go on to the usual path), and the limit itself"""
+    rng = np.random.default_rng(17)
+    try:
+        gpu_ctx.set_small_direct_max(-1)
+        for sigma, n in ((5, 100), (5, 70000), (3, 3000), (4, 1 << 20), (8, 3_000_001), (16, 1 << 22), (12, 9000), (5, 64), (5, 1 << 24), (6, 5_000_000)):
+            x = rng.integers(1, sigma, size=n, dtype=np.uint8)
+            if n > 1000:
+                x[200:260] = x[700:760]
+                x[n - 100:n - 60] = x[300:340]
+                x[n // 2:n // 2 + 300] = 1 + (sigma > 3)
+            want = oracle.sa_is(x, sigma)
+            sa, c, o = gpu_ctx.build_tables(x, sigma)
+            st = gpu_ctx.last_stats()
+            assert st["lms_path"] == 3, (sigma, n, st)
+            assert (sa == want).all() and (c == oracle.c_table(x, sigma)).all() and (o == oracle.o_table(x, want, sigma)).all(), (sigma, n)
+        # too repetitive for a prefix sort (a period of 2, then all equal): on to the usual path, same answer
+        for x, sigma in ((np.tile(np.array([1, 2], np.uint8), 3000), 3), (np.full(5000, 1, np.uint8), 2)):
+            assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is(x, sigma)).all()
+            assert gpu_ctx.last_stats()["lms_path"] != 3
+        # the limit counts suffixes (n + 1)
+        x = rng.integers(1, 5, size=4999, dtype=np.uint8)
+        for limit, path in ((5000, 3), (4999, 1), (0, 1)):
+            gpu_ctx.set_small_direct_max(limit)
+            assert (gpu_ctx.sa_build(x, 5) == oracle.sa_is(x, 5)).all()
+            assert gpu_ctx.last_stats()["lms_path"] == path, limit
+    finally:
+        gpu_ctx.set_small_direct_max(0)
+
+
 def test_both_induce_round_forms(gpu_ctx):
     """every round through the chained launch (look-back across up to thousands of tiles), every round
     through the three-launch form, and the default mix"""
