@@ -206,7 +206,8 @@ def test_bench_default_run_carries_the_other_configs(emu_ctx):
                           "--no-e2e", "--no-cpu", "--other-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert doc["verified"] is True and doc["metric"].startswith("Msuffixes/s (SA-IS + BWT C/O tables")
+    # (a record this short is sorted directly -- SX_FLAG_SMALL_DIRECT_MAX -- and the line says so; at BASELINE's sizes it reads "SA-IS + ...")
+    assert doc["verified"] is True and doc["metric"].startswith("Msuffixes/s (direct prefix sort + BWT C/O tables") and doc["build_stats"]["lms_path"] == 3
     oc = doc["other_configs"]
     assert set(oc) == {"dna_1024B", "bytes_4096B", "bytes_4096B_induced", "genome_like_4096B", "fibonacci_4096B"}
     for name, c in oc.items():
