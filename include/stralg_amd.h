@@ -143,7 +143,7 @@ enum {
     ,SX_FLAG_SMALL_DIRECT_MAX = 16 /* texts of at most 16 symbols and at most this many suffixes are sorted directly (all suffixes by
                                        prefix key, as wide alphabets are: a third of the launches of classification + LMS sort +
                                        induced passes, which is what a short record's build consists of); 0 = never; negative: the
-                                       default */
+                                       default (2^24, 2^25, 2^27 suffixes for at most 4, 7, 15 letters) */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

@@ -122,11 +122,14 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
     // (one MI355X, uniform symbols, suffix array + BWT, tools/small_direct.py: four letters 2^10 0.455 -> 0.144 ms, 2^22 0.79 -> 0.39,
     //  2^24 1.20 -> 0.78, 2^25 1.56 -> 1.47, 2^26 2.04 -> 2.75; seven letters 2^24 1.55 -> 0.74, 2^26 2.50 -> 2.46; fifteen 2^26
     //  4.76 -> 2.43)
-#ifndef SX_SMALL_DIRECT_MAX
-#define SX_SMALL_DIRECT_MAX ((1ull << 24) + 1ull)
-#endif
-    const uint64_t small_direct_max = ctx->small_direct_max >= 0 ? (uint64_t)ctx->small_direct_max : (uint64_t)SX_SMALL_DIRECT_MAX;
-    const bool small_direct = sigma <= 16 && N <= small_direct_max && N >= 4 && !ctx->no_direct && !ctx->force_general;
+    // The limit by the largest symbol, below where the two ways cross over (2^25, 2^26, beyond 2^27 for 4, 7, 11 - 15 letters:
+    // 15 letters 2^27 6.9 -> 4.5 ms; at 2^30 the induction wins up to 16 symbols, see below).
+    auto small_direct_limit = [&](uint32_t maxc) -> uint64_t {
+        if (ctx->small_direct_max >= 0) return (uint64_t)ctx->small_direct_max;
+        return (1ull << (maxc <= 4 ? 24 : (maxc <= 7 ? 25 : 27))) + 1ull;
+    };
+    // (before the symbols are counted: by the alphabet size the caller gave; checked again below with the largest symbol)
+    const bool small_direct = sigma <= 16 && N <= small_direct_limit(sigma - 1) && N >= 4 && !ctx->no_direct && !ctx->force_general;
     uint32_t src_tiles = 0;
     if (!small_direct && !ctx->copy_text_first && sigma <= 16 && ((uintptr_t)d_text & 15u) == 0 && n >= (uint64_t)kClsTile + 64) src_tiles = (uint32_t)((n - 64) / kClsTile);
     const uint64_t copied_from = (uint64_t)src_tiles * kClsTile;
@@ -163,7 +166,7 @@ int sx_sa_build_impl(sx_ctx *ctx, const uint8_t *d_text, uint64_t n, uint32_t si
         for (double v = eff; v < 16.0 * (double)N && need < 64; v *= eff) ++need; // <= ~6 % of the suffixes tied
         // (measured on uniform symbols, 1 GiB: the induction wins up to 16 symbols -- 4-bit window fields, 8-byte
         //  entries: 42 against 52 ms --, the direct sort from 20 symbols on: 51 ms flat against 53 ... 114 ms)
-        if ((td.maxc >= 17 || (small_direct && td.maxc >= 2)) && (double)need * log2((double)td.maxc + 1.0) <= 40.0) {
+        if ((td.maxc >= 17 || (small_direct && td.maxc >= 2 && N <= small_direct_limit(td.maxc))) && (double)need * log2((double)td.maxc + 1.0) <= 40.0) {
             SX_TRY(sx_slab_ensure(ctx, SX_SLAB_M, sx_lms_prefix_bytes(N) + 1024));
             sx_arena am;
             am.base = (char *)ctx->slab[SX_SLAB_M].p;
