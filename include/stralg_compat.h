@@ -179,8 +179,15 @@ int stralg_amd_set_device(int device);
 void stralg_amd_release(void);
 /* device contexts alive in this process */
 int stralg_amd_live_contexts(void);
-/* strlen(string) as build_complete_table takes it for long records -- the readable extent of the string's mapping
- * (/proc/self/maps) scanned by a few threads, 4 MiB chunks in increasing order -- and the byte values the string holds
+/* Host memory kept between calls.  Result arrays of 64 MiB and more that are freed through this library's free_* /
+ * dealloc_* functions go to a cache of the calling thread (at most 8 blocks) and come back to its next build instead
+ * of being unmapped and first-touched again.  All threads' caches together hold at most $STRALG_AMD_HOST_CACHE_GIB (default
+ * 64, never more than half of physical memory; 0: no cache); a block that does not fit is free()d.  A thread's cached
+ * blocks stay resident until it calls stralg_amd_release() or exits -- the reference's API has no such call, so a
+ * long-lived caller keeps up to the cap as RSS after its last record.  This function: bytes cached by all threads now. */
+size_t stralg_amd_host_cache_bytes(void);
+/* strlen(string) as build_complete_table takes it for long records -- one walk on the calling thread, aligned 32-byte
+ * loads, never a byte behind the terminator's own 32-byte block (as strlen) -- and the byte values the string holds
  * (present[256], filled when *have_letters comes back 1: strings of 4 MiB and more) */
 size_t stralg_amd_strlen_and_letters(const uint8_t *string, uint8_t *present, int *have_letters);
 /* Build tables for `count` independent strings over the listed devices by host threads pinned to their GPU's NUMA
@@ -204,7 +211,11 @@ int stralg_amd_bind_thread_to_device(int device);
 int stralg_amd_write_complete_bwt_info_stream(FILE *f, const uint8_t *string, bool include_reverse);
 /* The loop of bwt_readmapper.c:54-62 over a whole FASTA file: out[k] = build_complete_table of the k-th
  * record in ITERATION order (reverse file order), records farmed over the devices; returns the number of
- * records (out needs number_of_fasta_records(records) slots), or a negative value on failure. */
+ * records (out needs number_of_fasta_records(records) slots), or a negative value on failure.  A record that could not be
+ * built (more letters than a remap table holds, no memory) leaves out[k] == NULL: check every entry, or call the _ex form,
+ * which also stores the number of such records in *n_failed (may be NULL). */
+int stralg_amd_fasta_tables_batch_ex(struct fasta_records *records, bool include_reverse, const int *devices,
+                                     int n_devices, struct bwt_table **out, size_t *n_failed);
 int stralg_amd_fasta_tables_batch(struct fasta_records *records, bool include_reverse, const int *devices,
                                   int n_devices, struct bwt_table **out);
 

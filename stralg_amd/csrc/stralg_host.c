@@ -105,9 +105,12 @@ static void parallel_ranges(size_t total, void (*fn)(size_t, size_t, void *), vo
  * which is what bounds its downloads.  The free_* functions of this library now hand blocks of 64 MiB and more to the
  * calling thread's cache instead of to free(), and big_alloc takes a cached block that is large enough (and not more
  * than twice as large) before it asks malloc.  Cached blocks are ordinary malloc blocks: a caller that free()s an array
- * itself bypasses the cache, nothing else changes.  Bounds: 8 blocks and $STRALG_AMD_HOST_CACHE_GIB (default 64, never
- * more than half the machine's memory; 0 disables the cache) per thread; the cache goes with stralg_amd_release() and
- * at thread exit. */
+ * itself bypasses the cache, nothing else changes.  Bounds: 8 blocks a thread, and $STRALG_AMD_HOST_CACHE_GIB (default
+ * 64, never more than half the machine's memory; 0 disables the cache) for ALL threads' caches together (round 5: the
+ * farm hands tables to caller threads; a cap per thread let several of them hold all of the machine's memory between
+ * them) -- a block that does not fit under the process-wide cap goes to free().  A thread's cache goes with
+ * stralg_amd_release() and at thread exit; until then its blocks stay resident (the reference's API has no release call:
+ * a long-lived thread keeps up to the cap after its last record -- include/stralg_compat.h says so). */
 #include <malloc.h>
 
 #define BLOCK_CACHE_SLOTS 8
@@ -116,6 +119,7 @@ struct block_cache {
     size_t bytes[BLOCK_CACHE_SLOTS];
     size_t total;
 };
+static size_t cache_total_all = 0; /* bytes in all threads' caches (atomic) */
 static pthread_key_t cache_key;
 static pthread_once_t cache_key_once = PTHREAD_ONCE_INIT;
 static int cache_key_ok = 0;
@@ -125,6 +129,7 @@ static void block_cache_drop(void *arg)
     struct block_cache *bc = arg;
     if (!bc) return;
     for (int i = 0; i < BLOCK_CACHE_SLOTS; ++i) free(bc->p[i]);
+    __atomic_fetch_sub(&cache_total_all, bc->total, __ATOMIC_RELAXED);
     free(bc);
 }
 
@@ -142,6 +147,8 @@ static size_t block_cache_cap(void)
         if (gib > half) gib = half;
     }
     cap = gib << 30;
+    const char *bytes_env = getenv("STRALG_AMD_HOST_CACHE_BYTES"); /* (the tests: a cap that a few short records reach) */
+    if (bytes_env && atol(bytes_env) >= 0) cap = (size_t)atol(bytes_env);
     return cap;
 }
 
@@ -184,17 +191,21 @@ static void big_free(void *p)
             if (!bc->p[i]) empty = i;
             else if (smallest < 0 || bc->bytes[i] < bc->bytes[smallest]) smallest = i;
         }
-        if (empty >= 0 && bc->total + bytes <= block_cache_cap()) {
-            bc->p[empty] = p;
-            bc->bytes[empty] = bytes;
-            bc->total += bytes;
-            return;
+        if (empty >= 0) { /* reserve the bytes under the process-wide cap first; give them back if they do not fit */
+            if (__atomic_add_fetch(&cache_total_all, bytes, __ATOMIC_RELAXED) <= block_cache_cap()) {
+                bc->p[empty] = p;
+                bc->bytes[empty] = bytes;
+                bc->total += bytes;
+                return;
+            }
+            __atomic_fetch_sub(&cache_total_all, bytes, __ATOMIC_RELAXED);
         }
         /* no room: a smaller cached block makes way (a caller that went from short records to long ones: the short
          * records' blocks would otherwise sit in the slots for ever while the long ones' are unmapped every time) */
         if (smallest < 0 || bc->bytes[smallest] >= bytes) break;
         free(bc->p[smallest]);
         bc->total -= bc->bytes[smallest];
+        __atomic_fetch_sub(&cache_total_all, bc->bytes[smallest], __ATOMIC_RELAXED);
         bc->p[smallest] = NULL;
         bc->bytes[smallest] = 0;
     }
@@ -210,8 +221,12 @@ static void block_cache_release(void)
         bc->p[i] = NULL;
         bc->bytes[i] = 0;
     }
+    __atomic_fetch_sub(&cache_total_all, bc->total, __ATOMIC_RELAXED);
     bc->total = 0;
 }
+
+/* bytes held by all threads' block caches: what the multi-thread bound's test looks at */
+size_t stralg_amd_host_cache_bytes(void) { return __atomic_load_n(&cache_total_all, __ATOMIC_RELAXED); }
 
 static void *big_alloc(size_t bytes)
 {
@@ -226,6 +241,7 @@ static void *big_alloc(size_t bytes)
             if (best >= 0) {
                 void *p = bc->p[best];
                 bc->total -= bc->bytes[best];
+                __atomic_fetch_sub(&cache_total_all, bc->bytes[best], __ATOMIC_RELAXED);
                 bc->p[best] = NULL;
                 bc->bytes[best] = 0;
                 return p;
@@ -554,64 +570,24 @@ static void lut_slice(size_t lo, size_t hi, void *arg)
         for (size_t i = lo; i < hi; ++i) j->out[i] = (uint8_t)j->table[j->in[i]];
 }
 
-/* ---- the length and the letters of a long record in one parallel pass ---------------------------------------------
- * build_complete_table gets a NUL-terminated string: the reference starts with strlen (bwt.c:139, remap.c:73-77), a
- * single thread walking 1 GiB at the speed of one core's memory stream -- 100 of the 115 ms this library's host side
- * spent before the device saw the record.  A terminator cannot be looked for in parallel blindly: bytes behind it may
- * not be mapped.  But how far the mapping the string lies in is readable is no secret (/proc/self/maps), and inside that
- * extent any byte may be read.  So: the first 4 MiB by strnlen (short strings end there), then the readable extent, then
- * a few threads take 4 MiB chunks in increasing order (a ticket counter), each looking for the terminator (memchr) and
- * noting which letters its chunk holds; no chunk behind the first one with a terminator is started once that is known
- * (at most a chunk per thread is read in vain).  The letters of the chunks in front of the terminator are the record's
- * (remap.c:8-31's table follows from them). */
-static size_t readable_extent(const void *addr)
-{
-    FILE *f = fopen("/proc/self/maps", "r");
-    if (!f) return 0;
-    const uintptr_t a = (uintptr_t)addr;
-    uintptr_t end = 0;
-    char line[512];
-    while (fgets(line, sizeof line, f)) {
-        unsigned long lo, hi, off, ino;
-        char perms[8], dev[16], path[8];
-        path[0] = 0;
-        if (sscanf(line, "%lx-%lx %7s %lx %15s %lu %7s", &lo, &hi, perms, &off, dev, &ino, path) < 6) continue;
-        /* only memory that is there for sure: anonymous mappings, the heap, a stack.  A page of a file mapping behind the
-         * file's end is mapped and readable by these lines and still a SIGBUS to touch -- strlen, which stops at the
-         * terminator, would never get there; a scan that reads ahead of it could */
-        const bool safe = perms[0] == 'r' && (path[0] == 0 || path[0] == '[');
-        if (end == 0) {
-            if (a >= lo && a < hi) {
-                if (!safe) break;
-                end = hi;
-            }
-        } else if (lo == end && safe) {
-            end = hi; /* the next mapping continues this one */
-        } else if (lo >= end) {
-            break;
-        }
-    }
-    fclose(f);
-    return end > a ? (size_t)(end - a) : 0;
-}
-
+/* ---- the length and the letters of a long record in one pass ---------------------------------------------------------
+ * build_complete_table gets a NUL-terminated string: the reference starts with strlen (bwt.c:139) and walks the record
+ * again for its letters (remap.c:8-31, 73-77).  Here one walk finds both, on the calling thread, and -- like strlen --
+ * never touches a byte behind the terminator's 32-byte block: loads are 32 bytes at 32-byte-aligned addresses, so a load
+ * that holds a byte of the string lies in that byte's page.  (Round 4 scanned 4 MiB chunks of the string's mapping on
+ * several threads, ahead of the terminator: memory behind a string belongs to whoever allocated it, and another thread
+ * unmapping or protecting it between the look at /proc/self/maps and the read was a SIGSEGV this library caused.  The
+ * length of a NUL-terminated string cannot be found in parallel without reading ahead of the terminator; callers that know
+ * the length -- the batch entry points -- hand it over and get the letters by a parallel pass over [0, n) instead.) */
 #define SCAN_CHUNK ((size_t)4 << 20)
-struct scan_job {
-    const uint8_t *s;
-    size_t limit;              /* readable bytes from s on */
-    size_t nchunks;
-    size_t next;               /* ticket: the next chunk to take (atomic) */
-    size_t found;              /* the lowest chunk seen to hold a terminator (atomic; nchunks: none yet) */
-    size_t *end_in_chunk;      /* per chunk: offset of its terminator, or the chunk's length */
-    uint32_t (*letters)[8];    /* per chunk: the byte values in front of its terminator, 256 bits */
-};
 
-/* A chunk's terminator and letters in one pass.  A record has few distinct letters: 32 bytes at a time are compared with the
- * letters seen so far (up to 16 of them: a compare and an OR each), and only a block that holds a new one is walked byte
- * by byte -- a table look-up per byte ran at a byte a cycle, 1 GiB on 16 threads in 22 ms; this form is bound by memory. */
+/* A record has few distinct letters: 32 bytes at a time are compared with the letters seen so far (up to 16 of them: a
+ * compare and an OR each), and only a block that holds a new one is walked byte by byte -- a table look-up per byte ran at
+ * a byte a cycle; this form is bound by the core's memory stream. */
 #if defined(__x86_64__)
 #include <immintrin.h>
-/* one pass: returns the offset of the first NUL in p[0 .. len) (len: none), bits |= the byte values in front of it */
+/* returns the offset of the first NUL in p[0 .. len) (len: none; len = SIZE_MAX: the string is NUL-terminated), bits |= the
+ * byte values in front of it.  Reads whole aligned 32-byte blocks that hold at least one byte of p[0 .. min(len, NUL)]. */
 __attribute__((target("avx2"))) static size_t scan_block_avx2(const uint8_t *p, size_t len, uint32_t bits[8])
 {
     uint8_t known[16];
@@ -621,24 +597,34 @@ __attribute__((target("avx2"))) static size_t scan_block_avx2(const uint8_t *p, 
         if ((bits[c >> 5] >> (c & 31)) & 1u) known[nk++] = (uint8_t)c;
     const __m256i zero = _mm256_setzero_si256();
     size_t i = 0;
-    for (; i + 32 <= len; i += 32) {
-        const __m256i v = _mm256_loadu_si256((const __m256i *)(p + i));
+    /* bytes up to the first aligned address, one at a time */
+    for (; i < len && ((uintptr_t)(p + i) & 31u) != 0; ++i) {
+        if (!p[i]) return i;
+        bits[p[i] >> 5] |= 1u << (p[i] & 31);
+    }
+    for (; len - i >= 32; i += 32) {
+        const __m256i v = _mm256_load_si256((const __m256i *)(p + i));
         const uint32_t z = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, zero));
         if (!z && !many) {
             __m256i m = zero;
             for (int q = 0; q < nk; ++q) m = _mm256_or_si256(m, _mm256_cmpeq_epi8(v, _mm256_set1_epi8((char)known[q])));
             if ((uint32_t)_mm256_movemask_epi8(m) == 0xFFFFFFFFu) continue;
+            nk = 0; /* the letters seen so far, again from the bit set (a new one joins below) */
         }
         const int stop = z ? __builtin_ctz(z) : 32;
         for (int e = 0; e < stop; ++e) {
             const uint8_t b = p[i + e];
-            if (!((bits[b >> 5] >> (b & 31)) & 1u)) {
-                bits[b >> 5] |= 1u << (b & 31);
-                if (nk < 16) known[nk++] = b;
-                else many = true;
-            }
+            bits[b >> 5] |= 1u << (b & 31);
         }
         if (z) return i + (size_t)stop;
+        if (!many) {
+            for (int c = 1; c < 256 && nk <= 16; ++c)
+                if ((bits[c >> 5] >> (c & 31)) & 1u) {
+                    if (nk < 16) known[nk] = (uint8_t)c;
+                    ++nk;
+                }
+            if (nk > 16) many = true, nk = 16;
+        }
     }
     for (; i < len; ++i) {
         if (!p[i]) return i;
@@ -653,73 +639,77 @@ static size_t scan_block(const uint8_t *p, size_t len, uint32_t bits[8])
 #if defined(__x86_64__)
     if (__builtin_cpu_supports("avx2")) return scan_block_avx2(p, len, bits);
 #endif
-    const uint8_t *z = memchr(p, 0, len);
-    const size_t upto = z ? (size_t)(z - p) : len;
+    const size_t upto = len == (size_t)-1 ? strlen((const char *)p) : strnlen((const char *)p, len);
     for (size_t i = 0; i < upto; ++i) bits[p[i] >> 5] |= 1u << (p[i] & 31);
     return upto;
 }
 
-static void *scan_worker(void *arg)
+/* The walk: strnlen over 4 MiB chunks on the calling thread (libc's: the speed of one core's memory stream, 75 ms a GiB
+ * where the fused walk above takes 185), and up to three helper threads that collect the letters of chunks the walk has
+ * already found free of terminators -- behind the walk, never ahead of it. */
+struct follow_job {
+    const uint8_t *s;
+    size_t clear;  /* bytes from s on known to hold no terminator: a multiple of the chunk (atomic) */
+    int done;      /* the walk has found the terminator (atomic) */
+    size_t next;   /* ticket: the next chunk a helper takes (atomic) */
+    uint32_t bits[4][8];
+    int ids;       /* helper numbers (atomic) */
+};
+
+static void *follow_worker(void *arg)
 {
-    struct scan_job *j = arg;
+    struct follow_job *j = arg;
+    uint32_t *bits = j->bits[__atomic_fetch_add(&j->ids, 1, __ATOMIC_RELAXED)];
     for (;;) {
         const size_t k = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
-        if (k >= j->nchunks || k > __atomic_load_n(&j->found, __ATOMIC_ACQUIRE)) break;
-        const uint8_t *p = j->s + k * SCAN_CHUNK;
-        const size_t len = j->limit - k * SCAN_CHUNK < SCAN_CHUNK ? j->limit - k * SCAN_CHUNK : SCAN_CHUNK;
-        uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const size_t upto = scan_block(p, len, bits);
-        j->end_in_chunk[k] = upto;
-        memcpy(j->letters[k], bits, 32);
-        if (upto < len) {
-            size_t cur = __atomic_load_n(&j->found, __ATOMIC_RELAXED);
-            while (k < cur && !__atomic_compare_exchange_n(&j->found, &cur, k, false, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {
+        for (;;) {
+            if (__atomic_load_n(&j->clear, __ATOMIC_ACQUIRE) >= (k + 1) * SCAN_CHUNK) break;
+            if (__atomic_load_n(&j->done, __ATOMIC_ACQUIRE)) { /* (clear is final once done is set) */
+                if (__atomic_load_n(&j->clear, __ATOMIC_ACQUIRE) >= (k + 1) * SCAN_CHUNK) break;
+                return NULL; /* chunk k holds the terminator or lies behind it: the caller takes what is left */
             }
+            usleep(40);
         }
+        (void)scan_block(j->s + k * SCAN_CHUNK, SCAN_CHUNK, bits);
     }
-    return NULL;
 }
 
 /* strlen(string), and which byte values the string holds (present[256]; may be NULL); *have_letters says whether
- * `present` was filled (short strings and unreadable maps leave that to the caller) */
+ * `present` was filled (short strings leave that to the caller) */
 static size_t long_strlen(const uint8_t *string, bool *present, bool *have_letters)
 {
     *have_letters = false;
     const size_t head = strnlen((const char *)string, SCAN_CHUNK);
     if (head < SCAN_CHUNK) return head;
-    const int nt = host_threads();
-    const size_t limit = nt > 1 ? readable_extent(string) : 0;
-    if (limit <= SCAN_CHUNK) return head + strlen((const char *)string + head);
-    struct scan_job j = {string, limit, (limit + SCAN_CHUNK - 1) / SCAN_CHUNK, 1, 0, NULL, NULL}; /* (chunk 0 holds no terminator) */
-    j.found = j.nchunks;
-    j.end_in_chunk = malloc(j.nchunks * sizeof *j.end_in_chunk);
-    j.letters = malloc(j.nchunks * sizeof *j.letters);
-    if (!j.end_in_chunk || !j.letters) {
-        free(j.end_in_chunk), free(j.letters);
-        return head + strlen((const char *)string + head);
-    }
-    pthread_t th[64];
+    struct follow_job j;
+    memset(&j, 0, sizeof j);
+    j.s = string;
+    j.clear = SCAN_CHUNK;
+    pthread_t th[3];
     int started = 0;
-    for (int t = 0; t < nt && t < 64; ++t)
-        if (pthread_create(&th[started], NULL, scan_worker, &j) == 0) ++started;
-    if (started == 0) scan_worker(&j);
-    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
-    size_t n;
-    if (j.found >= j.nchunks) { /* no terminator inside the readable extent: cannot be; let strlen say (or fault) */
-        n = head + strlen((const char *)string + head);
-    } else {
-        n = j.found * SCAN_CHUNK + j.end_in_chunk[j.found];
-        if (present) {
-            uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            (void)scan_block(string, SCAN_CHUNK, bits); /* chunk 0 (it holds no terminator) */
-            for (size_t k = 1; k <= j.found; ++k)
-                for (int w = 0; w < 8; ++w) bits[w] |= j.letters[k][w];
-            for (int c = 0; c < 256; ++c) present[c] = (bits[c >> 5] >> (c & 31)) & 1u;
-            *have_letters = true;
-        }
+    const int helpers = present ? (host_threads() - 1 < 3 ? host_threads() - 1 : 3) : 0;
+    for (int t = 0; t < helpers; ++t)
+        if (pthread_create(&th[started], NULL, follow_worker, &j) == 0) ++started;
+    size_t n = SCAN_CHUNK;
+    for (;;) {
+        const size_t e = strnlen((const char *)string + n, SCAN_CHUNK);
+        n += e;
+        if (e < SCAN_CHUNK) break;
+        __atomic_store_n(&j.clear, n, __ATOMIC_RELEASE);
     }
-    free(j.end_in_chunk);
-    free(j.letters);
+    __atomic_store_n(&j.done, 1, __ATOMIC_RELEASE);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    if (present) {
+        /* what no helper took: from the first ticket nobody finished (all of it when no helper started) to the end */
+        const size_t taken = started ? __atomic_load_n(&j.next, __ATOMIC_RELAXED) - (size_t)started : 0;
+        const size_t from = taken * SCAN_CHUNK < n ? taken * SCAN_CHUNK : n - n % SCAN_CHUNK;
+        uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)scan_block(string + from, n - from, bits);
+        for (int t = 0; t < 4; ++t)
+            for (int w = 0; w < 8; ++w) bits[w] |= j.bits[t][w];
+        for (int c = 0; c < 256; ++c) present[c] = (bits[c >> 5] >> (c & 31)) & 1u;
+        *have_letters = true;
+    }
     return n;
 }
 
@@ -811,13 +801,16 @@ static void free_partial_table(struct bwt_table *table)
     free(table);
 }
 
-static int build_complete_table_try(const uint8_t *string, bool include_reverse, struct bwt_table **out)
+#define LENGTH_UNKNOWN ((size_t)-1)
+/* known_n: strlen(string) where the caller has it (the batch entry points: the letters then come from a parallel pass over
+ * [0, n)), LENGTH_UNKNOWN otherwise (one walk on this thread finds the terminator and the letters) */
+static int build_complete_table_try(const uint8_t *string, size_t known_n, bool include_reverse, struct bwt_table **out)
 {
     *out = NULL;
     const bool timing = getenv("STRALG_AMD_TIMING") != NULL;
     const double t0 = timing ? now_ms() : 0.0;
     bool letters[256], have_letters = false;
-    const size_t n = long_strlen(string, letters, &have_letters);
+    const size_t n = known_n != LENGTH_UNKNOWN ? known_n : long_strlen(string, letters, &have_letters);
     uint8_t *remapped = big_alloc(n + 1);
     if (!remapped) return SX_E_NOMEM;
     struct remap_table *remap_table = remap_record(string, n, remapped, have_letters ? letters : NULL);
@@ -902,7 +895,7 @@ static int build_complete_table_try(const uint8_t *string, bool include_reverse,
 struct bwt_table *build_complete_table(const uint8_t *string, bool include_reverse)
 {
     struct bwt_table *table = NULL;
-    const int rc = build_complete_table_try(string, include_reverse, &table);
+    const int rc = build_complete_table_try(string, LENGTH_UNKNOWN, include_reverse, &table);
     if (rc != 0) die("build_complete_table", rc, tls_ctx);
     return table;
 }
@@ -1288,6 +1281,7 @@ void dealloc_fasta_iter(struct fasta_iter *iter) { (void)iter; }
 
 struct farm_job {
     const uint8_t *const *strings;
+    const size_t *lengths; /* strlen of every record (the batch entry point has them) */
     struct bwt_table **out;
     const size_t *mine; /* indices of this worker's records, in the order it builds them */
     size_t n_mine;
@@ -1355,7 +1349,7 @@ static void *farm_worker(void *arg)
     stralg_amd_set_device(job->device);
     for (size_t k = 0; k < job->n_mine; ++k) {
         struct bwt_table *t = NULL;
-        const int rc = build_complete_table_try(job->strings[job->mine[k]], job->include_reverse, &t);
+        const int rc = build_complete_table_try(job->strings[job->mine[k]], job->lengths[job->mine[k]], job->include_reverse, &t);
         job->out[job->mine[k]] = rc == 0 ? t : NULL;
         if (rc != 0) {
             job->failed++;
@@ -1438,6 +1432,22 @@ int stralg_amd_farm_workers_per_device(const size_t *lengths, size_t count, int 
 static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count, bool include_reverse, const int *devices,
                                     int n_devices, struct bwt_table **out, const size_t *lengths_in);
 
+/* the farm over records whose lengths are known */
+static int build_tables_batch_known(const uint8_t *const *strings, const size_t *lengths, size_t count, bool include_reverse,
+                                    const int *devices, int n_devices, struct bwt_table **out)
+{
+    /* every device `workers` times in the list of lanes, worker-major (lane w * n_devices + d is worker w of device d):
+     * LPT deals the records over all of them */
+    const int workers = stralg_amd_farm_workers_per_device(lengths, count, n_devices);
+    int *lanes = malloc((size_t)n_devices * (size_t)workers * sizeof *lanes);
+    if (!lanes) return -2;
+    for (int w = 0; w < workers; ++w)
+        for (int d = 0; d < n_devices; ++d) lanes[w * n_devices + d] = devices[d];
+    const int rc = build_tables_batch_lanes(strings, count, include_reverse, lanes, n_devices * workers, out, lengths);
+    free(lanes);
+    return rc;
+}
+
 int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, bool include_reverse,
                                   const int *devices, int n_devices, struct bwt_table **out)
 {
@@ -1445,18 +1455,7 @@ int stralg_amd_build_tables_batch(const uint8_t *const *strings, size_t count, b
     size_t *lengths = malloc((count ? count : 1) * sizeof *lengths);
     if (!lengths) return -2;
     for (size_t k = 0; k < count; ++k) lengths[k] = strlen((const char *)strings[k]);
-    /* every device `workers` times in the list of lanes, worker-major (lane w * n_devices + d is worker w of device d):
-     * LPT deals the records over all of them */
-    const int workers = stralg_amd_farm_workers_per_device(lengths, count, n_devices);
-    int *lanes = malloc((size_t)n_devices * (size_t)workers * sizeof *lanes);
-    if (!lanes) {
-        free(lengths);
-        return -2;
-    }
-    for (int w = 0; w < workers; ++w)
-        for (int d = 0; d < n_devices; ++d) lanes[w * n_devices + d] = devices[d];
-    const int rc = build_tables_batch_lanes(strings, count, include_reverse, lanes, n_devices * workers, out, lengths);
-    free(lanes);
+    const int rc = build_tables_batch_known(strings, lengths, count, include_reverse, devices, n_devices, out);
     free(lengths);
     return rc;
 }
@@ -1487,7 +1486,7 @@ static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count,
                     const size_t t = order[j];
                     order[j] = order[j - 1], order[j - 1] = t;
                 }
-            jobs[d] = (struct farm_job){strings, out, order + first, at - first, include_reverse, devices[d], false, 0, 0};
+            jobs[d] = (struct farm_job){strings, lengths, out, order + first, at - first, include_reverse, devices[d], false, 0, 0};
         }
         /* a lane whose thread cannot be created (EAGAIN under a thread limit) is run by the caller after the
          * others have been started: every record is built either way, and only created threads are joined */
@@ -1512,16 +1511,35 @@ static int build_tables_batch_lanes(const uint8_t *const *strings, size_t count,
     return rc;
 }
 
+int stralg_amd_fasta_tables_batch_ex(struct fasta_records *records, bool include_reverse, const int *devices,
+                                     int n_devices, struct bwt_table **out, size_t *n_failed)
+{
+    if (n_failed) *n_failed = 0;
+    if (!records || !out || n_devices <= 0 || !devices) return -1;
+    const uint32_t n = records->recs ? records->recs->no_records : 0;
+    const uint8_t **strings = malloc((n ? n : 1) * sizeof *strings);
+    size_t *lengths = malloc((n ? n : 1) * sizeof *lengths);
+    if (!strings || !lengths) {
+        free(strings), free(lengths);
+        return -2;
+    }
+    uint32_t k = 0;
+    for (struct fasta_record_impl *rec = records->recs; rec; rec = rec->next) {
+        strings[k] = rec->seq;
+        /* (a sequence of 4 Gi letters and more does not fit the record's 32-bit length: fasta.c:18's field) */
+        lengths[k++] = rec->seq[rec->seq_len] == 0 ? rec->seq_len : strlen((const char *)rec->seq);
+    }
+    const int rc = build_tables_batch_known(strings, lengths, n, include_reverse, devices, n_devices, out);
+    free(strings);
+    free(lengths);
+    if (rc < 0) return rc;
+    if (n_failed) *n_failed = (size_t)rc;
+    return (int)n;
+}
+
+/* (the records that could not be built have out[k] == NULL: check every entry, or call the _ex form for their number) */
 int stralg_amd_fasta_tables_batch(struct fasta_records *records, bool include_reverse, const int *devices,
                                   int n_devices, struct bwt_table **out)
 {
-    if (!records || !out) return -1;
-    const uint32_t n = records->recs ? records->recs->no_records : 0;
-    const uint8_t **strings = malloc((n ? n : 1) * sizeof *strings);
-    if (!strings) return -2;
-    uint32_t k = 0;
-    for (struct fasta_record_impl *rec = records->recs; rec; rec = rec->next) strings[k++] = rec->seq;
-    const int rc = stralg_amd_build_tables_batch(strings, n, include_reverse, devices, n_devices, out);
-    free(strings);
-    return rc < 0 ? rc : (int)n; /* (records that could not be built have out[k] == NULL) */
+    return stralg_amd_fasta_tables_batch_ex(records, include_reverse, devices, n_devices, out, NULL);
 }

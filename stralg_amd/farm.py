@@ -41,7 +41,13 @@ def init_collectives(rank, world, dev=None, prefer="nccl", attempt_timeout_s=180
     all-reduce of ones that must sum to `world`); whether EVERY rank's attempt succeeded is agreed over gloo, and only
     then do the barrier and the reductions of the timed region go over RCCL -- otherwise all ranks stay on gloo and the
     reason is reported.  Nothing on the data path is collective either way.  Returns a dict for the bench line:
-    collective_backend, nccl_error, n_ranks_seen."""
+    collective_backend, nccl_error, n_ranks_seen.
+
+    Whether to attempt RCCL at all is agreed over gloo first (new_group is itself collective: ranks that disagree about
+    having a GPU would wait for each other for ever).  An attempt that RAISES falls back to gloo; an attempt that HANGS
+    (RCCL's usual failure mode on a broken fabric) is ended by torch's watchdog after attempt_timeout_s, which aborts the
+    process: the run then dies with the watchdog's message rather than going on over gloo -- STRALG_BENCH_COLLECTIVES=gloo
+    (bench.py: prefer="gloo") is the way round a fabric that hangs."""
     import datetime
     import os
     import torch
@@ -50,7 +56,12 @@ def init_collectives(rank, world, dev=None, prefer="nccl", attempt_timeout_s=180
     info = {"collective_backend": "gloo", "nccl_error": None}
     _COLL.update(group=None, device=None, backend="gloo")
     forced = os.environ.get("STRALG_BENCH_FORCE_NCCL_ATTEMPT") == "1"  # (tests: the fall-back branch on a box without GPUs)
-    if prefer == "nccl" and ((dev is not None and dev.type == "cuda") or forced):
+    mine = prefer == "nccl" and ((dev is not None and dev.type == "cuda") or forced)
+    everyone = torch.tensor([1 if mine else 0], dtype=torch.int32)
+    dist.all_reduce(everyone, op=dist.ReduceOp.MIN)  # (gloo)
+    if mine and int(everyone.item()) != 1:
+        info["nccl_error"] = "not attempted: another rank has no GPU device"
+    elif mine:
         ok, err, g = 1, None, None
         try:
             g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=attempt_timeout_s))

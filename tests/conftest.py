@@ -287,3 +287,24 @@ def gpu_ctx():
     ctx.set_small_direct_max(0)  # (as in emu_ctx: the tests mean the SA-IS kernels; test_short_records_direct_sort switches it back on)
     yield ctx
     ctx.close()
+
+
+# the session contexts above switch the direct sort of short records off, so the suites that run through
+# them exercise the SA-IS kernels and not what a caller gets by default.  Tests that take one of these fixtures run twice:
+# once as before, once with the library's default routing (short records of few symbols sorted directly).
+def _routed(ctx, request):
+    ctx.set_small_direct_max(0 if request.param == "sa_is_kernels" else -1)
+    try:
+        yield ctx
+    finally:
+        ctx.set_small_direct_max(0)
+
+
+@pytest.fixture(params=["sa_is_kernels", "default_routing"])
+def gpu_routed(gpu_ctx, request):
+    yield from _routed(gpu_ctx, request)
+
+
+@pytest.fixture(params=["sa_is_kernels", "default_routing"])
+def emu_routed(emu_ctx, request):
+    yield from _routed(emu_ctx, request)

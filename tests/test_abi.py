@@ -229,13 +229,15 @@ def test_links_next_to_a_real_libstralg(product_lib, tmp_path):
     assert inner and set(inner.values()) == {"libstralg_amd.so"}, inner
 
 
-def test_long_strlen_scans_only_what_is_mapped(product_lib):
-    import numpy as np
-    """build_complete_table's strlen of a long record: parallel over the readable extent of the string's mapping, never
-    a byte behind it.  A record that ends exactly at the end of its mapping, with an unreadable page behind (mmap +
-    mprotect), strings with the terminator in every position class, and the letters that come back."""
+def test_long_strlen_never_reads_behind_the_terminator(product_lib):
+    """build_complete_table's strlen of a long record: one walk with aligned 32-byte loads, never a byte behind the
+    terminator's own block.  A record that ends exactly at the end of its mapping, with an unreadable page behind (mmap +
+    mprotect), strings with the terminator in every position class and every alignment, the letters that come back; and
+     a second thread that keeps taking the memory right behind the string away while the scan runs."""
     import ctypes as C
     import mmap
+    import threading
+    import numpy as np
     lib = product_lib
     lib.stralg_amd_strlen_and_letters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     lib.stralg_amd_strlen_and_letters.restype = C.c_size_t
@@ -244,7 +246,7 @@ def test_long_strlen_scans_only_what_is_mapped(product_lib):
     page = mmap.PAGESIZE
     chunk = 4 << 20
     rng = np.random.default_rng(2)
-    for n in (0, 5, chunk - 1, chunk, chunk + 1, 3 * chunk + 12345, 9 * chunk):
+    for n in (0, 5, chunk - 1, chunk, chunk + 1, chunk + 31, chunk + 32, chunk + 33, 3 * chunk + 12345, 9 * chunk):
         total = ((n + 1 + page - 1) // page + 1) * page  # the string, then one guard page
         m = mmap.mmap(-1, total, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)  # (what malloc hands out for a long record)
         buf = (C.c_uint8 * total).from_buffer(m)
@@ -267,8 +269,17 @@ def test_long_strlen_scans_only_what_is_mapped(product_lib):
         libc.mprotect(base + total - page, page, 3)
         del arr, buf
         m.close()
-    # a record inside a FILE mapping is scanned by strlen itself: pages of such a mapping behind the file's end are listed
-    # as readable and are a SIGBUS to touch (Python's default mmap(-1, ...) is a shared mapping of /dev/zero: a path)
+    # more than 16 distinct letters (the block compare gives way to the byte walk), terminator at an odd offset from an odd start
+    n = chunk + 1000
+    raw = np.zeros(n + 64, dtype=np.uint8)
+    raw[7:7 + n] = rng.integers(1, 256, size=n, dtype=np.uint8)
+    raw[7 + n] = 0
+    present = (C.c_uint8 * 256)()
+    have = C.c_int(-1)
+    assert lib.stralg_amd_strlen_and_letters(raw.ctypes.data + 7, present, C.byref(have)) == n and have.value == 1
+    assert sorted(c for c in range(256) if present[c]) == sorted(set(raw[7:7 + n].tolist()))
+    # a record inside a FILE mapping: pages of such a mapping behind the file's end are listed as readable and are a
+    # SIGBUS to touch; the walk stops at the terminator like strlen (Python's default mmap(-1, ...) is a shared mapping)
     n = 2 * chunk + 77
     m = mmap.mmap(-1, n + 1)
     arr = np.frombuffer(m, dtype=np.uint8)
@@ -276,6 +287,41 @@ def test_long_strlen_scans_only_what_is_mapped(product_lib):
     arr[n] = 0
     buf = (C.c_uint8 * (n + 1)).from_buffer(m)
     have = C.c_int(-1)
-    assert lib.stralg_amd_strlen_and_letters(C.addressof(buf), None, C.byref(have)) == n and have.value == 0
+    assert lib.stralg_amd_strlen_and_letters(C.addressof(buf), None, C.byref(have)) == n
+    del arr, buf
+    m.close()
+    # the memory right behind the string is somebody else's: a second thread flips it between PROT_NONE and readable while
+    # 16 "host threads" are configured (round 4's read-ahead scan took a SIGSEGV here)
+    n = 64 << 20
+    behind = 8 << 20
+    m = mmap.mmap(-1, n + page + behind, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    buf = (C.c_uint8 * (n + page + behind)).from_buffer(m)
+    base = C.addressof(buf)
+    arr = np.frombuffer(m, dtype=np.uint8)
+    arr[:] = 67
+    start = page - 1  # the string ends with the last byte of its pages: [start, n + page)
+    arr[n + page - 1] = 0
+    stop = threading.Event()
+
+    def flip():
+        while not stop.is_set():
+            libc.mprotect(base + n + page, behind, 0)
+            libc.mprotect(base + n + page, behind, 3)
+
+    th = threading.Thread(target=flip)
+    old = os.environ.get("STRALG_AMD_HOST_THREADS")
+    os.environ["STRALG_AMD_HOST_THREADS"] = "16"
+    th.start()
+    try:
+        for _ in range(20):
+            assert lib.stralg_amd_strlen_and_letters(base + start, None, C.byref(have)) == n + page - 1 - start
+    finally:
+        stop.set()
+        th.join()
+        if old is None:
+            del os.environ["STRALG_AMD_HOST_THREADS"]
+        else:
+            os.environ["STRALG_AMD_HOST_THREADS"] = old
+    libc.mprotect(base + n + page, behind, 3)
     del arr, buf
     m.close()

@@ -15,30 +15,30 @@ def _sa(ctx, x, sigma):
     return ctx.sa_build(np.asarray(x, dtype=np.uint8), sigma)
 
 
-def test_tiny_and_edges(emu_ctx):
-    assert _sa(emu_ctx, [], 5).tolist() == [0]
-    assert _sa(emu_ctx, [3], 5).tolist() == [1, 0]
+def test_tiny_and_edges(emu_routed):
+    assert _sa(emu_routed, [], 5).tolist() == [0]
+    assert _sa(emu_routed, [3], 5).tolist() == [1, 0]
     for x in ([1, 1], [1, 2], [2, 1], [1, 2, 1], [2, 2, 1, 2], [1, 1, 2, 3]):
-        assert (_sa(emu_ctx, x, 5) == oracle.sa_is_strict(np.array(x, np.uint8), 5)).all(), x
+        assert (_sa(emu_routed, x, 5) == oracle.sa_is_strict(np.array(x, np.uint8), 5)).all(), x
     # loose alphabet_size: the true suffix array, not sort_SA's shortcut (quirk 3)
-    assert _sa(emu_ctx, [1, 1, 2, 3], 5).tolist() == [4, 0, 1, 2, 3]
+    assert _sa(emu_routed, [1, 1, 2, 3], 5).tolist() == [4, 0, 1, 2, 3]
 
 
-def test_golden_small(emu_ctx, golden):
+def test_golden_small(emu_routed, golden):
     for name, c in golden.items():
         n = c["sym"].size
         if n > 4200 or c["sigma"] > 21 or c["sigma"] == n + 1:
             continue
-        assert (_sa(emu_ctx, c["sym"], c["sigma"]) == c["sa"]).all(), name
+        assert (_sa(emu_routed, c["sym"], c["sigma"]) == c["sa"]).all(), name
 
 
-def test_random_and_tile_boundaries(emu_ctx):
+def test_random_and_tile_boundaries(emu_routed):
     rng = np.random.default_rng(3)
     for n in (4095, 4096, 4097, 9000):
         x = rng.integers(1, 5, size=n, dtype=np.uint8)
-        assert (_sa(emu_ctx, x, 5) == oracle.sa_is(x, 5)).all(), n
+        assert (_sa(emu_routed, x, 5) == oracle.sa_is(x, 5)).all(), n
     x = rng.integers(1, 256, size=600, dtype=np.uint8)
-    assert (_sa(emu_ctx, x, 256) == oracle.sa_is(x, 256)).all()
+    assert (_sa(emu_routed, x, 256) == oracle.sa_is(x, 256)).all()
 
 
 def test_both_lms_paths(emu_ctx):
@@ -397,19 +397,19 @@ def test_bwt_tables(emu_ctx, golden):
         assert (ot == oracle.o_table(x, sa, sigma)).all(), (sigma, n)
 
 
-def test_fused_build_tables(emu_ctx, golden):
+def test_fused_build_tables(emu_routed, golden):
     """sx_build_tables: the BWT handed over by the induced sort's symbol windows (incl. refills
     when a window runs dry: long runs, monotone stretches, byte alphabets)"""
     import stralg_amd
     for name in ("ref/mississippi", "struct/all-a", "struct/decreasing", "struct/runs", "ref/fasta1"):
         c = golden[name]
-        t = stralg_amd.build_complete_table(bytes(c["raw"]), True, emu_ctx)
+        t = stralg_amd.build_complete_table(bytes(c["raw"]), True, emu_routed)
         assert (t.sa.array == c["sa"]).all() and (t.c_table == c["c"]).all(), name
         assert (t.o_table == c["o"]).all() and (t.ro_table == c["ro"]).all(), name
     rng = np.random.default_rng(10)
     for sigma, n in ((5, 3000), (100, 900), (17, 1500)):
         x = rng.integers(1, sigma, size=n, dtype=np.uint8)
-        sa, ct, ot = emu_ctx.build_tables(x, sigma)
+        sa, ct, ot = emu_routed.build_tables(x, sigma)
         want = oracle.sa_is(x, sigma)
         assert (sa == want).all() and (ct == oracle.c_table(x, sigma)).all(), (sigma, n)
         assert (ot == oracle.o_table(x, want, sigma)).all(), (sigma, n)
@@ -492,22 +492,22 @@ def test_next_rows(emu_ctx, golden):
         assert got == want or (got[0] >= got[1] and want[0] >= want[1]), (k, got, want)
 
 
-def test_fasta_ingest_and_remap(emu_ctx, golden_fasta):
+def test_fasta_ingest_and_remap(emu_routed, golden_fasta):
     """FASTA packing (scan + compaction) and remap kernels against the reference's vectors"""
     from conftest import check_fasta
-    check_fasta(emu_ctx.fasta_records, golden_fasta)
+    check_fasta(emu_routed.fasta_records, golden_fasta)
     rng = np.random.default_rng(5)
     for n in (0, 1, 15, 16, 17, 4097, 70001):
         x = rng.choice(np.frombuffer(b"ACGTNRYKM-", dtype=np.uint8), size=n).astype(np.uint8)
         out = np.full(n + 1, 99, dtype=np.uint8)
-        sigma, table = emu_ctx.remap_dev(x if n else None, n, out)
+        sigma, table = emu_routed.remap_dev(x if n else None, n, out)
         want, want_sigma, want_table = oracle.remap(x) if n else (np.zeros(0, np.uint8), 1, None)
         assert sigma == want_sigma and (out[:n] == want).all() and out[n] == 0, n
         if n:
             assert (table == want_table).all()
     with pytest.raises(Exception):  # more than 127 distinct symbols (remap.h:14-18)
         x = np.arange(1, 200, dtype=np.uint8)
-        emu_ctx.remap_dev(x, x.size, np.zeros(x.size + 1, np.uint8))
+        emu_routed.remap_dev(x, x.size, np.zeros(x.size + 1, np.uint8))
 
 
 def test_wide_alphabets_direct_sort_and_induction(emu_ctx):
@@ -888,6 +888,42 @@ def test_farm_goes_on_past_a_record_it_cannot_build(emu_ctx, golden):
         lib.completely_free_bwt_table(t)
 
 
+def test_fasta_farm_reports_the_records_it_could_not_build(emu_ctx, tmp_path):
+    """stralg_amd_fasta_tables_batch_ex: the number of records that could not be built comes back through
+    *n_failed, their slots are NULL, the others are built from the record lengths the loader already has."""
+    import ctypes as C
+    _, _, BT = _c_structs()
+    lib = emu_ctx.lib
+    fa = tmp_path / "mixed.fa"
+    wide = "".join(chr(c) for c in range(48, 123) if chr(c).isalnum()) * 3  # 62 distinct letters: fine
+    fa.write_bytes(b">one\nACGTACGTTTGA\nACGT\n>two\n" + bytes(range(33, 62)) + bytes(range(63, 127)) + bytes(range(128, 200))
+                   + b"\n>three\n" + wide.encode() + b"\n>four\nmississippi\n")
+    lib.load_fasta_records.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    lib.load_fasta_records.restype = C.c_void_p
+    lib.free_fasta_records.argtypes = [C.c_void_p]
+    lib.stralg_amd_fasta_tables_batch_ex.argtypes = [C.c_void_p, C.c_bool, C.POINTER(C.c_int), C.c_int, C.POINTER(C.POINTER(BT)),
+                                                     C.POINTER(C.c_size_t)]
+    lib.stralg_amd_fasta_tables_batch_ex.restype = C.c_int
+    lib.completely_free_bwt_table.argtypes = [C.POINTER(BT)]
+    lib.completely_free_bwt_table.restype = None
+    err = C.c_int(0)
+    h = lib.load_fasta_records(str(fa).encode(), C.byref(err))
+    assert h and err.value == 0
+    out = (C.POINTER(BT) * 4)()
+    devs = (C.c_int * 1)(0)
+    failed = C.c_size_t(99)
+    assert lib.stralg_amd_fasta_tables_batch_ex(h, False, devs, 1, out, C.byref(failed)) == 4
+    assert failed.value == 1
+    built = [bool(out[k]) for k in range(4)]  # iteration order = reverse file order (bioinf/fasta.c:131-134)
+    assert built == [True, True, False, True]
+    t = out[0]
+    assert np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(12,)).tolist() == [11, 10, 7, 4, 1, 0, 9, 8, 6, 3, 5, 2]
+    for k in range(4):
+        if out[k]:
+            lib.completely_free_bwt_table(out[k])
+    lib.free_fasta_records(h)
+
+
 def test_reverse_on_the_device(emu_ctx):
     """sx_reverse_dev (the reversed copy build_complete_table sorts for the RO table, bwt.c:147-151): sizes around its
     16-byte pieces, an unaligned destination, the terminator, and the overlap check"""
@@ -947,9 +983,30 @@ again = lib.build_complete_table(text(39000), True)
 assert blocks(again) <= big_blocks, "the long record's blocks were not kept"
 lib.completely_free_bwt_table(again)
 lib.stralg_amd_release()
+lib.stralg_amd_host_cache_bytes.restype = C.c_size_t
+assert lib.stralg_amd_host_cache_bytes() == 0
+# the bound is one for ALL threads (ADVICE round 4): four threads build and free at once; together they never hold more
+# than the cap ($STRALG_AMD_HOST_CACHE_BYTES here: about one long record's arrays), and what a thread holds goes when it exits
+import threading
+cap = int(__import__("os").environ["STRALG_AMD_HOST_CACHE_BYTES"])
+seen = []
+def work(seed):
+    r = np.random.default_rng(seed)
+    for _ in range(3):
+        t = lib.build_complete_table(bytes(r.choice(np.frombuffer(b"ACGT", np.uint8), size=30000)), True)
+        lib.completely_free_bwt_table(t)
+        seen.append(lib.stralg_amd_host_cache_bytes())
+ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+[t.start() for t in ths]; [t.join() for t in ths]
+assert max(seen) <= cap and max(seen) > 0, (max(seen), cap)
+import time
+for _ in range(200):  # (Thread.join returns before the OS thread has run its key destructors)
+    if lib.stralg_amd_host_cache_bytes() == 0: break
+    time.sleep(0.01)
+assert lib.stralg_amd_host_cache_bytes() == 0, "exited threads still hold cached blocks"
 print("ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
        os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libstralg_amd_emu.so"))
-    env = dict(os.environ, STRALG_AMD_HOST_CACHE_MIN="4096")
+    env = dict(os.environ, STRALG_AMD_HOST_CACHE_MIN="4096", STRALG_AMD_HOST_CACHE_BYTES=str(3 << 20))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]

@@ -90,20 +90,20 @@ def test_classify_against_model(gpu_ctx):
 
 # ---- golden vectors and oracle ---------------------------------------------------------
 
-def test_golden_suffix_arrays(gpu_ctx, golden):
+def test_golden_suffix_arrays(gpu_routed, golden):
     for name, c in golden.items():
         if c["sigma"] == c["sym"].size + 1:
             continue
-        assert (gpu_ctx.sa_build(c["sym"], c["sigma"]) == c["sa"]).all(), name
+        assert (gpu_routed.sa_build(c["sym"], c["sigma"]) == c["sa"]).all(), name
 
 
-def test_golden_tables(gpu_ctx, golden):
+def test_golden_tables(gpu_routed, golden):
     import stralg_amd
     checked = 0
     for name, c in golden.items():
         if "o" not in c:
             continue
-        t = stralg_amd.build_complete_table(bytes(c["raw"]), True, gpu_ctx)
+        t = stralg_amd.build_complete_table(bytes(c["raw"]), True, gpu_routed)
         assert t.remap_table.alphabet_size == c["sigma"], name
         assert (t.sa.array == c["sa"]).all(), name
         assert (t.c_table == c["c"]).all(), name
@@ -127,12 +127,12 @@ def test_edges_and_errors(gpu_ctx):
     assert (gpu_ctx.sa_build(x, 256) == oracle.sa_is_strict(x, 256)).all()    # loose alphabet
 
 
-def test_random_against_oracle(gpu_ctx):
+def test_random_against_oracle(gpu_routed):
     rng = np.random.default_rng(4)
     for sigma in (2, 3, 5, 21, 128, 256):
         for n in (7, 300, 4096, 4097, 70_001):
             x = rng.integers(1, sigma, size=n, dtype=np.uint8)
-            assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), (sigma, n)
+            assert (gpu_routed.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), (sigma, n)
 
 
 def test_general_path_against_oracle(gpu_ctx):
@@ -421,7 +421,7 @@ def test_very_long_runs(gpu_ctx):
             assert (o == oracle.o_table(x, want, sigma)).all(), name
 
 
-def test_structured_against_oracle(gpu_ctx):
+def test_structured_against_oracle(gpu_routed):
     rng = np.random.default_rng(5)
     cases = {
         "all-equal": np.full(3000, 1, np.uint8),
@@ -434,7 +434,7 @@ def test_structured_against_oracle(gpu_ctx):
     }
     for name, x in cases.items():
         sigma = int(x.max()) + 1
-        assert (gpu_ctx.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), name
+        assert (gpu_routed.sa_build(x, sigma) == oracle.sa_is_strict(x, sigma)).all(), name
 
 
 @pytest.mark.parametrize("sigma,n", [(5, 1 << 24), (256, 1 << 22)])
@@ -449,7 +449,7 @@ def test_benchmark_shaped_against_oracle(gpu_ctx, sigma, n):
         assert (o == oracle.o_table(x[: 1 << 20], oracle.sa_is(x[: 1 << 20], sigma), sigma)).all()
 
 
-def test_fused_sa_bwt_tables(gpu_ctx):
+def test_fused_sa_bwt_tables(gpu_routed):
     """sx_sa_bwt_build_dev + sx_bwt_tables_from_bwt_dev (what bench.py times) and sx_build_tables"""
     import torch
     rng = np.random.default_rng(16)
@@ -460,20 +460,20 @@ def test_fused_sa_bwt_tables(gpu_ctx):
         d = torch.from_numpy(x).cuda()
         sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
         bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
-        gpu_ctx.sa_bwt_build_dev(d, n, sigma, sa, bw)
+        gpu_routed.sa_bwt_build_dev(d, n, sigma, sa, bw)
         assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, n)
         assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), (sigma, n)
         if sigma <= 128:
             c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
             o = torch.empty((n + 2) * sigma, dtype=torch.int32, device="cuda")
-            gpu_ctx.bwt_tables_from_bwt_dev(bw, n + 1, sigma, c, o)
+            gpu_routed.bwt_tables_from_bwt_dev(bw, n + 1, sigma, c, o)
             assert (c.cpu().numpy().view(np.uint32) == oracle.c_table(x, sigma)).all(), (sigma, n)
             assert (o.cpu().numpy().view(np.uint32).reshape(n + 2, sigma) == oracle.o_table(x, want, sigma)).all()
-            sa2, c2, o2 = gpu_ctx.build_tables(x, sigma)
+            sa2, c2, o2 = gpu_routed.build_tables(x, sigma)
             assert (sa2 == want).all() and (o2 == oracle.o_table(x, want, sigma)).all(), (sigma, n)
 
 
-def test_unaligned_bwt_buffer(gpu_ctx):
+def test_unaligned_bwt_buffer(gpu_routed):
     """the caller's BWT buffer is the induction's symbol-byte array: the counting launches read it in aligned
     16-byte pieces, or byte by byte when the caller's pointer is not 16-byte aligned; both round forms"""
     import torch
@@ -485,17 +485,17 @@ def test_unaligned_bwt_buffer(gpu_ctx):
             want = oracle.sa_is(x, sigma)
             d = torch.from_numpy(x).cuda()
             for chain_max in (2048, 524288):
-                gpu_ctx.set_chain_max_entries(chain_max)
+                gpu_routed.set_chain_max_entries(chain_max)
                 for off in (0, 1, 7):
                     sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
                     buf = torch.zeros(n + 1 + 16, dtype=torch.uint8, device="cuda")
                     bw = buf[off: off + n + 1]
-                    gpu_ctx.sa_bwt_build_dev(d, n, sigma, sa, bw)
+                    gpu_routed.sa_bwt_build_dev(d, n, sigma, sa, bw)
                     assert (sa.cpu().numpy().view(np.uint32) == want).all(), (sigma, chain_max, off)
                     assert (bw.cpu().numpy() == oracle.bwt(x, want)).all(), (sigma, chain_max, off)
                     assert int(buf[off + n + 1:].sum()) == 0 and int(buf[:off].sum()) == 0  # nothing outside
     finally:
-        gpu_ctx.set_chain_max_entries(-1)
+        gpu_routed.set_chain_max_entries(-1)
 
 
 def test_wide_alphabet_tables(gpu_ctx):
@@ -1020,7 +1020,7 @@ def test_production_genomes_through_the_farm(gpu_ctx, golden_genomes, tmp_path):
     check_genomes(gpu_ctx.lib, golden_genomes, tmp_path)
 
 
-def test_fasta_to_tables_on_device(gpu_ctx):
+def test_fasta_to_tables_on_device(gpu_routed):
     """a FASTA image that never leaves the GPU: pack, per record remap + suffix array + BWT + C/O, each checked
     against the oracle working from the file on the host"""
     import torch
@@ -1036,14 +1036,14 @@ def test_fasta_to_tables_on_device(gpu_ctx):
     d_file = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
     d_packed = torch.zeros(len(data) + 1, dtype=torch.uint8, device="cuda")
     d_term = torch.zeros(len(data) + 2, dtype=torch.int32, device="cuda")
-    plen, nrec = gpu_ctx.fasta_pack_dev(d_file, len(data), d_packed, d_term, d_term.numel())
+    plen, nrec = gpu_routed.fasta_pack_dev(d_file, len(data), d_packed, d_term, d_term.numel())
     assert nrec == 4 and d_packed[:plen].cpu().numpy().tobytes() == packed_want
     term = d_term[: 2 * nrec].cpu().numpy().view(np.uint32)
     for r in range(nrec):
         s0, n = int(term[2 * r]) + 1, int(term[2 * r + 1]) - int(term[2 * r]) - 1
         assert n == len(seqs[r])
         d_sym = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
-        sigma, table = gpu_ctx.remap_dev(d_packed[s0:], n, d_sym)
+        sigma, table = gpu_routed.remap_dev(d_packed[s0:], n, d_sym)
         sym_want, sigma_want, table_want = oracle.remap(np.frombuffer(seqs[r], dtype=np.uint8))
         assert sigma == sigma_want and (table == table_want).all()
         assert (d_sym[:n].cpu().numpy() == sym_want).all() and int(d_sym[n]) == 0
@@ -1052,15 +1052,15 @@ def test_fasta_to_tables_on_device(gpu_ctx):
         bw = torch.empty(N, dtype=torch.uint8, device="cuda")
         c = torch.empty(sigma, dtype=torch.int32, device="cuda")
         o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
-        gpu_ctx.sa_bwt_build_dev(d_sym, n, sigma, sa, bw)
-        gpu_ctx.bwt_tables_from_bwt_dev(bw, N, sigma, c, o)
+        gpu_routed.sa_bwt_build_dev(d_sym, n, sigma, sa, bw)
+        gpu_routed.bwt_tables_from_bwt_dev(bw, N, sigma, c, o)
         sa_want = oracle.sa_is(sym_want, sigma)
         assert (sa.cpu().numpy().view(np.uint32) == sa_want).all(), r
         assert (c.cpu().numpy().view(np.uint32) == oracle.c_table(sym_want, sigma)).all()
         assert (o.cpu().numpy().view(np.uint32) == oracle.o_table(sym_want, sa_want, sigma).ravel()).all()
 
 
-def test_fasta_record_with_reverse_against_oracle(gpu_ctx):
+def test_fasta_record_with_reverse_against_oracle(gpu_routed):
     """What the production caller asks for (bwt_readmapper.c:57: build_complete_table(rec.seq, true)) for a record that
     never leaves the GPU: farm.FastaRecordJob with include_reverse -- image -> pack -> remap -> SA + BWT + C/O, then
     sx_reverse_dev, the reversed string's suffix array and the RO table (bwt.c:147-158) -- every array against the oracle
@@ -1071,7 +1071,7 @@ def test_fasta_record_with_reverse_against_oracle(gpu_ctx):
     for n, seed in ((1 << 22, 9), (1, 3), (15, 4), (16, 5), (17, 6), (4099, 7)):
         text = torch.from_numpy(synth(n, 5, seed)).to(dev)
         image = workloads.fasta_image(text, "rec")
-        job = farm.FastaRecordJob(gpu_ctx, image.cpu().pin_memory(), dev, tables=True, include_reverse=True)
+        job = farm.FastaRecordJob(gpu_routed, image.cpu().pin_memory(), dev, tables=True, include_reverse=True)
         job.upload()
         assert job.build() == n + 1 and job.n == n
         letters = np.frombuffer(b"NACGTN", dtype=np.uint8)[text.cpu().numpy()]
