@@ -19,6 +19,11 @@ environment.  Rank 0 prints ONE JSON line.  After the timed region the last step
 verified on the device ("verified"), and outside it the line also reports the host-buffer
 (PCIe-inclusive) rates ("end_to_end"), the FASTA-ingest-inclusive rate ("fasta_record") and the
 reference's own CPU path on a bounded sample ("cpu_baseline").
+
+Layout (round 5): this file holds the argument parser, the rank launcher, the CPU-baseline leg (the one place that runs the
+reference / the oracle) and run_rank with the timed region; the other legs live in stralg_amd/benchlegs/ -- ceiling.py (the
+box's measured memory ceiling, before the timed region), pins.py (SHA-256 pins to the reference), hostpath.py (host-buffer
+rates, each entry checked), configs.py (the other BASELINE configurations), pmc.py (replayed counters).
 """
 import argparse
 import json
@@ -31,8 +36,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md, chip-level parameters)
-PMC_TRAFFIC = os.path.join("profiles", "pmc_traffic.json")
+from stralg_amd.benchlegs.configs import HBM_PEAK_GBS  # 8000 GB/s: MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)  # noqa: E402
+from stralg_amd.benchlegs.pmc import PMC_TRAFFIC, pmc_traffic, pmc_whole_step  # noqa: E402
 
 
 def parse_args(argv=None):
@@ -74,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each of the other configurations")
     ap.add_argument("--no-ro", action="store_true",
                     help="FASTA records: skip the reverse direction (build_complete_table's include_reverse: the RO table)")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the probe of the box's memory ceiling before the timed region")
+    ap.add_argument("--no-reference-scale", action="store_true",
+                    help="skip the row at the reference's published size (n = 49 000 / 65 536 through the host C API)")
     ap.add_argument("--no-egress", action="store_true",
                     help="FASTA records: skip the egress leg (the record's index leaving the GPU on every rank at once)")
     return ap.parse_args(argv)
@@ -154,28 +162,6 @@ def cpu_baseline(x, sigma, what):
     return out
 
 
-def reference_pin(sa, n, sigma, seed):
-    """Bit-exactness against the UNMODIFIED reference at this size, where tests/golden/golden_big.npz holds it (the
-    reference's sa_is_mem_construction on the same splitmix64 text, seed 42; tests/golden/make_golden_big.py): SHA-256 of
-    the device's suffix array, downloaded in chunks, against the reference's.  None when no such fixture exists."""
-    import hashlib
-    import numpy as np
-    log2n = n.bit_length() - 1
-    path = os.path.join(ROOT, "tests", "golden", "golden_big.npz")
-    if n != 1 << log2n or seed != 42 or not os.path.exists(path):
-        return None
-    z = np.load(path)
-    key = f"n{log2n}/s{sigma}/sa_sha256"
-    if key not in z.files:
-        return None
-    h = hashlib.sha256()
-    for s0 in range(0, n + 1, 1 << 26):
-        h.update(sa[s0:s0 + (1 << 26)].cpu().numpy().tobytes())
-    return {"fixture": f"tests/golden/golden_big.npz:{key}", "sha256": h.hexdigest()[:16] + "...",
-            "match": h.digest() == bytes(z[key]),
-            "what": "SHA-256 of the whole suffix array vs the reference's sa_is_mem_construction (sa_is_mem.c:471-494) on the same text"}
-
-
 def cpu_baseline_at_size(log2n, sigma, seed, sa_device=None):
     """The unmodified reference's sa_is_mem_construction (oracle/_ref) on the WHOLE record of BASELINE.json configs[1]
     (2^28 symbols; ~60-100 s on one core), next to the bounded sample above: the reference's rate falls with n
@@ -198,310 +184,86 @@ def cpu_baseline_at_size(log2n, sigma, seed, sa_device=None):
     return out
 
 
-def pmc_traffic(workload, log2n, sigma, tables, klass):
-    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
-    same command (profiles/pmc_traffic.json, made by tools/gpu_step.sh's prof step + tools/pmc_to_json.py).  PMC counters
-    cannot be read from inside the process: the figure is replayed from that file, not measured in this run
-    (roofline.traffic_source says so); None for workloads that were not profiled.  Returns (bytes, stale): stale when the
-    kernel sources have changed since the passes were collected (the file is stamped with their SHA-256)."""
-    try:
-        from stralg_amd._lib import kernel_sources_sha16
-        doc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
-        key = f"log2n={log2n} sigma={sigma} tables={int(tables)}"
-        entry = doc[key if workload == "dna" else f"workload={workload} " + key]
-        c = entry["classes"][klass]
-        return round(c["hbm_bytes_per_launch"]), entry.get("kernel_sources_sha16") != kernel_sources_sha16()
-    except (OSError, KeyError, ValueError):
-        return None, None
-
-
-def pmc_whole_step(workload, log2n, sigma, tables, launches_per_class):
-    """HBM bytes of one whole step as rocprofv3's counters saw them: the committed per-class figures (pmc_traffic above)
-    times this run's launches per class.  Returns (bytes, stale, classes the passes have no figure for) or (None, None, None)."""
-    try:
-        from stralg_amd._lib import kernel_sources_sha16
-        doc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
-        key = f"log2n={log2n} sigma={sigma} tables={int(tables)}"
-        entry = doc[key if workload == "dna" else f"workload={workload} " + key]
-        total, missing = 0.0, []
-        for klass, launches in launches_per_class.items():
-            c = entry["classes"].get(klass)
-            if c is None:
-                if launches:
-                    missing.append(klass)  # (a class without a figure counts as no traffic: the total is a lower bound)
-                continue
-            total += c["hbm_bytes_per_launch"] * launches
-        return total, entry.get("kernel_sources_sha16") != kernel_sources_sha16(), missing
-    except (OSError, KeyError, ValueError):
-        return None, None, None
-
-
-# ---- host-buffer (PCIe-inclusive) measurements, outside the timed region --------------------------------------
-
-def end_to_end(ctx, sizes, seed):
-    """What a caller of the reference API sees (stralg/bwt.c:134-161 hands over malloc'd host arrays):
-    sx_build_tables on pageable host buffers, and build_complete_table itself (remap, tables, o_indices) with and
-    without the reverse table.  Second call of each (the first pays hipMalloc of the staging slab)."""
+def reference_scale(lib, sizes=(49000, 65536), calls=50, seed=42):
+    """The reference's only published operating point (SURVEY.md section 8d "reference-scale sanity
+    row"): performance/suffix_array_construction.c:81-146,196-200 times sa_is_construction on random DNA of n <= 49 000
+    (performance/suffix_array_construction.txt:3153: 4.63 ms = 10.6 Msuffixes/s, hardware unstated).  Here: the same call
+    through libstralg_amd.so's reference-named entry point on a HOST string (context warm; strlen, H2D, the launch chain, D2H
+    into a malloc'd array: everything a stralg caller pays), median of `calls`, next to the unmodified reference (oracle/_ref)
+    -- or the oracle port -- on the same string on one host core.  Arrays compared."""
     import ctypes as C
+    import statistics
     import numpy as np
-    import psutil
+    import oracle
+    from oracle import pyoracle
+    from stralg_amd.benchlegs import cabi
     from stralg_amd.synth import synth
-    lib = ctx.lib
-    lib.build_complete_table.argtypes = [C.c_char_p, C.c_bool]
-    lib.build_complete_table.restype = C.c_void_p
-    lib.completely_free_bwt_table.argtypes = [C.c_void_p]
-    lib.completely_free_bwt_table.restype = None
-    out = {}
-    for log2n in sizes:
-        n = 1 << log2n
-        N = n + 1
-        need = (N + 1) * 5 * 4 * 2 + N * 4 + (N + 1) * 8 * 2 + 3 * n  # O + RO + SA + row pointers + strings
-        if psutil.virtual_memory().available < need * 1.25:
-            out[f"2^{log2n}"] = {"skipped": f"needs {need >> 30} GiB of free host memory"}
-            continue
-        x = synth(n, 5, seed)
-        sa = np.empty(N, dtype=np.uint32)
-        c = np.zeros(5, dtype=np.uint32)
-        o = np.empty((N + 1) * 5, dtype=np.uint32)
-        moved = n + 4 * N + 4 * 5 * (N + 1)
-        best = None
-        for _ in range(2):
+    cabi.declare(lib)
+    ref = pyoracle._Ref() if pyoracle.have_ref() else None
+    out = {"published": {"n": 49000, "ms": 4.63, "Msuffixes_per_s": 10.6, "hardware": "unstated",
+                         "source": "performance/suffix_array_construction.txt:3153 (SA-IS, random DNA)"},
+           "calls": calls, "cpu_kind": "reference" if ref else "port", "cpu_cores": 1, "rows": []}
+    for n in sizes:
+        x = np.concatenate([synth(n, 5, seed), np.zeros(1, np.uint8)])
+        a = lib.sa_is_construction(x.ctypes.data, 5)  # warm: the thread's context, its slabs, the pinned staging
+        got = np.ctypeslib.as_array(a.contents.array, shape=(n + 1,)).copy()
+        lib.free_suffix_array(a)
+        gpu = []
+        for _ in range(calls):
             t0 = time.perf_counter()
-            ctx._check(lib.sx_build_tables(ctx.h, x.ctypes.data, n, 5, sa.ctypes.data, c.ctypes.data, o.ctypes.data), "sx_build_tables")
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        del sa, o
-        letters = np.frombuffer(b"\0ACGT", dtype=np.uint8)[x].tobytes()  # NUL-terminated by bytes' own terminator
-        del x
-        res = {"sx_build_tables_ms": round(best * 1e3, 1), "pcie_GBps": round(moved / best / 1e9, 2),
-               "sx_build_tables_Msuffixes_per_s": round(N / best / 1e6, 1)}
-        for key, rev in (("build_complete_table_ms", False), ("with_ro_ms", True)):
-            best = None
-            for _ in range(2):  # (the first call of a size pays the host's first touch of 30 GiB of result arrays)
-                t0 = time.perf_counter()
-                t = lib.build_complete_table(letters, rev)
-                dt = time.perf_counter() - t0
-                lib.completely_free_bwt_table(t)
-                best = dt if best is None else min(best, dt)
-                if rev:
-                    break
-            res[key] = round(best * 1e3, 1)
-        res["build_complete_table_Msuffixes_per_s"] = round(N / (res["build_complete_table_ms"] * 1e-3) / 1e6, 1)
-        res["bytes_over_pcie"] = moved
-        if log2n == max(sizes):
-            # the production caller's loop (tools/readmappers/bwt_readmapper/bwt_readmapper.c:54-62): build_complete_table(seq,
-            # true) -> write_complete_bwt_info -> completely_free_bwt_table, record after record on one thread.  The freed
-            # arrays go to the thread's block cache (stralg_host.c) and come back for the next record: no unmapping of
-            # 52 GiB of huge pages (1.9 s a record in round 3), no first touch of as many by the next build.
-            lib.write_complete_bwt_info.argtypes = [C.c_void_p, C.c_void_p]
-            lib.write_complete_bwt_info.restype = None
-            libc = C.CDLL(None)
-            libc.fopen.restype = C.c_void_p
-            libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
-            libc.fclose.argtypes = [C.c_void_p]
-            f = libc.fopen(b"/dev/null", b"wb")
-            per, frees = [], []
-            for _ in range(4):
-                t0 = time.perf_counter()
-                t = lib.build_complete_table(letters, True)
-                lib.write_complete_bwt_info(f, t)
-                t1 = time.perf_counter()
-                lib.completely_free_bwt_table(t)
-                t2 = time.perf_counter()
-                per.append(round((t2 - t0) * 1e3, 1))
-                frees.append(round((t2 - t1) * 1e3, 1))
-            libc.fclose(f)
-            lib.stralg_amd_release()  # (the calling thread's context and its cached host blocks)
-            res["readmapper_loop"] = {"records": 4, "ms_per_record": per, "free_ms_per_record": frees,
-                                      "steady_ms_per_record": round(sum(per[1:]) / 3, 1),
-                                      "what": "build_complete_table(seq, true) + write_complete_bwt_info(/dev/null) + "
-                                              "completely_free_bwt_table, four records in a row on one thread"}
-        out[f"2^{log2n}"] = res
-    out["note"] = ("pageable malloc'd host buffers as the reference's ownership rules require; build_complete_table "
-                   "includes the host remap and the o_indices row-pointer table; with_ro_ms adds the reverse table")
-    return out
-
-
-# ---- the other BASELINE.json configurations, after the timed region ---------------------------------------------------
-
-LMS_PATHS = {0: "none", 1: "prefix-key LMS sort + induced-sort passes", 2: "general path (pieces, names, reduced string) + "
-             "induced-sort passes", 3: "direct prefix sort of all suffixes"}
-
-
-def measure_config(ctx, dev, gen, n, sigma_arg, seed, steps, tables=True, no_direct=False, cuda=True, cpu_at_size=False):
-    """`steps` timed steps of the hot path on one more text (generated on the device), one warm-up that doubles as the
-    per-class profile, results verified on the device afterwards.  Outside bench.py's timed region."""
-    import torch
-    from stralg_amd import farm, verify, workloads
-    text, sigma = workloads.make_text(ctx, gen, n, sigma_arg, seed, dev)
-    if cuda:
-        torch.cuda.synchronize()
-    N = n + 1
-    tables = tables and sigma <= 128
-    sa = torch.empty(N, dtype=torch.int32, device=dev)
-    c_tab = torch.zeros(sigma, dtype=torch.int32, device=dev) if tables else None
-    o_tab = torch.empty((N + 1) * sigma, dtype=torch.int32, device=dev) if tables else None
-    bwt = torch.empty(N, dtype=torch.uint8, device=dev) if tables else None
-
-    def step():
-        if tables:
-            ctx.sa_bwt_build_dev(text, n, sigma, sa, bwt)
-            ctx.bwt_tables_from_bwt_dev(bwt, N, sigma, c_tab, o_tab)
-        else:
-            ctx.sa_build_dev(text, n, sigma, sa)
-
-    ctx.set_no_direct_sort(no_direct)
-    try:
-        ctx.profile_reset()
-        ctx.profile_only(None)
-        ctx.profile_enable(True)
-        step()
-        if cuda:
-            torch.cuda.synchronize()
-        ctx.profile_enable(False)
-        table = ctx.profile_read()
-        elapsed = farm.timed(step, steps, 0, cuda=cuda)
-        stats = ctx.last_stats()
-    finally:
-        ctx.set_no_direct_sort(False)
-    dom = max(table, key=lambda k: table[k]["ms"])
-    d = table[dom]
-    alg_total = sum(v["alg_bytes"] for v in table.values())
-    ms = elapsed / steps * 1e3
-    out = {"n": n, "alphabet_size": sigma, "tables": tables, "steps": steps, "ms_per_step": round(ms, 3),
-           "Msuffixes_per_s": round(N / (ms * 1e-3) / 1e6, 1),
-           "lms_path": stats.get("lms_path"), "algorithm": LMS_PATHS.get(stats.get("lms_path"), "?"),
-           "induce_rounds": stats.get("induce_rounds"), "recursion_levels": stats.get("recursion_levels"),
-           "dominant_class": dom, "dominant_ms_per_step": round(d["ms"], 3),
-           "roofline_frac": round(d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d["ms"] > 0 else 0.0,
-           "whole_step_frac_of_peak": round(alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    if n == 1 << (n.bit_length() - 1):
-        # the dominant class's HBM bytes per launch from the committed rocprofv3 PMC passes of `bench.py --workload ...`
-        tr, stale = pmc_traffic(gen + ("_induced" if no_direct else ""), n.bit_length() - 1, sigma, tables, dom)
-        out["traffic"], out["traffic_stale"] = tr, stale
-    ctx.trim()
-    try:
-        verify.verify_build_on_device(text, n, sigma, sa, bwt, c_tab if tables else None, o_tab)
-        out["verified"] = True
-    except AssertionError as e:
-        out["verified"] = False
-        out["error"] = str(e)
-    if gen in ("dna", "bytes") and cuda:
-        pin = reference_pin(sa, n, sigma, seed)
-        if pin is not None:
-            out["reference_pin"] = pin
-    if cpu_at_size:
-        out["cpu_reference_whole_record"] = cpu_baseline_at_size(n.bit_length() - 1, sigma, seed, sa)
-    del text, sa, bwt, c_tab, o_tab
-    if cuda:
-        torch.cuda.empty_cache()
-    return out
-
-
-def other_configs(ctx, dev, steps, cuda=True, log2n=30, cpu_whole_record=False):
-    """BASELINE.json configs[1] and [3] and one hard text, so that the driver's line carries them too:
-    256 MiB DNA; 1 GiB of random bytes by the default path (direct prefix sort) and through the LMS sort + induced-sort
-    passes (the "wide-alphabet LDS-histogram path" configs[3] names); a genome-like 1 GiB text; a Fibonacci string
-    (every LMS substring repeats: the general path, its reduced strings sorted by the pipeline itself level below level)."""
-    out = {}
-
-    def size(n):
-        return f"{n >> 30}GiB" if n >= 1 << 30 else (f"{n >> 20}MiB" if n >= 1 << 20 else f"{n}B")
-
-    big, quarter = 1 << log2n, 1 << (log2n - 2)
-    for name, gen, n, sig, tables, no_direct in (
-            (f"dna_{size(quarter)}", "dna", quarter, 5, True, False),
-            (f"bytes_{size(big)}", "bytes", big, 256, False, False),
-            (f"bytes_{size(big)}_induced", "bytes", big, 256, False, True),
-            (f"genome_like_{size(big)}", "genome_like", big, 5, True, False),
-            (f"fibonacci_{size(big)}", "periodic", big, 3, True, False)):
-        try:
-            out[name] = measure_config(ctx, dev, gen, n, sig, 42, steps, tables, no_direct, cuda,
-                                       cpu_at_size=cpu_whole_record and gen == "dna" and n == 1 << 28)
-        except Exception as e:  # noqa: BLE001 -- an extra must not take the headline line down with it
-            out[name] = {"error": f"{type(e).__name__}: {e}"}
-    return out
-
-
-# ---- FASTA records: the index leaves the GPU (what limits configs[4]: PCIe, host memory, NUMA) -----------------------
-
-def egress_leg(ctx, local_rank, text, n, sigma, world, red_dev, cuda=True, with_ro=False):
-    """Every rank at once, between barriers: the record's whole index (suffix array, C, O: 24 bytes per base) leaves
-    the GPU -- (1) stralg_amd_write_complete_bwt_info_stream into /dev/null (stralg/serialise.c:7-18's file, streamed
-    through two pinned buffers: no host copy of the tables), (2) memory permitting, sx_build_tables into malloc'd host
-    arrays as build_complete_table's caller owns them (stralg/bwt.c:134-161).  Both start from the record on the host
-    (H2D included)."""
-    import ctypes as C
-    import numpy as np
-    import psutil
-    import torch
-    from stralg_amd import farm
-    lib = ctx.lib
-    N = n + 1
-    index_bytes = 4 * N + 4 * sigma + 4 * sigma * (N + 1)
-    # symbols 1 .. 5 -> A C G T N (bytes.translate: no index array of eight bytes a base beside the record)
-    letters = text.cpu().numpy().tobytes().translate(bytes([0]) + b"ACGTN" + b"N" * 250)  # (bytes' own terminator ends the string)
-    libc = C.CDLL(None)
-    libc.fopen.restype = C.c_void_p
-    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
-    libc.fclose.argtypes = [C.c_void_p]
-    lib.stralg_amd_write_complete_bwt_info_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_bool]
-    lib.stralg_amd_write_complete_bwt_info_stream.restype = C.c_int
-    lib.stralg_amd_set_device.argtypes = [C.c_int]
-    lib.stralg_amd_set_device(local_rank)
-    out = {"index_bytes_per_record": index_bytes}
-    f = libc.fopen(b"/dev/null", b"wb")
-
-    def stream():
-        if lib.stralg_amd_write_complete_bwt_info_stream(f, letters, False) != 0:
-            raise RuntimeError("stralg_amd_write_complete_bwt_info_stream failed")
-
-    stream()  # (the first call pays the thread context's hipMalloc and the pinned buffers)
-    t_own = farm.timed(stream, 1, 0, cuda=cuda)
-    t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
-    out.update(stream_ms_per_record=round(t_max * 1e3, 1),
-               egress_inclusive_Msuffixes_per_s=round(units / t_max / 1e6, 3),
-               d2h_GBps_per_rank=round(index_bytes / t_own / 1e9, 2),
-               d2h_GBps_all_ranks=round(index_bytes * world / t_max / 1e9, 2))
-    if with_ro:
-        # the index file bwt_readmapper -p writes: write_complete_bwt_info of build_complete_table(seq, TRUE) -- the RO
-        # table streams out behind the O table (44 bytes per base over PCIe instead of 24)
-        def stream_ro():
-            if lib.stralg_amd_write_complete_bwt_info_stream(f, letters, True) != 0:
-                raise RuntimeError("stralg_amd_write_complete_bwt_info_stream (include_reverse) failed")
-
-        t_own = farm.timed(stream_ro, 1, 0, cuda=cuda)
-        t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
-        ro_bytes = index_bytes + 4 * sigma * (N + 1)
-        out["egress_with_ro"] = {"index_bytes_per_record": ro_bytes, "stream_ms_per_record": round(t_max * 1e3, 1),
-                          "egress_inclusive_Msuffixes_per_s": round(units / t_max / 1e6, 3),
-                          "d2h_GBps_per_rank": round(ro_bytes / t_own / 1e9, 2)}
-    libc.fclose(f)
+            a = lib.sa_is_construction(x.ctypes.data, 5)
+            gpu.append(time.perf_counter() - t0)
+            lib.free_suffix_array(a)
+        cpu = []
+        for _ in range(max(5, calls // 5)):
+            t0 = time.perf_counter()
+            want = ref.sa_is(x[:n], 5) if ref else oracle.sa_is(x[:n], 5)
+            cpu.append(time.perf_counter() - t0)  # (includes the wrapper's copy of the 4(n+1)-byte array: microseconds)
+        g, c = statistics.median(gpu), statistics.median(cpu)
+        out["rows"].append({"n": n, "gpu_call_ms": round(g * 1e3, 3), "gpu_call_ms_min": round(min(gpu) * 1e3, 3),
+                            "gpu_Msuffixes_per_s": round((n + 1) / g / 1e6, 1),
+                            "cpu_ms": round(c * 1e3, 3), "cpu_Msuffixes_per_s": round((n + 1) / c / 1e6, 1),
+                            "gpu_over_cpu": round(c / g, 2), "arrays_identical": bool((got == want).all())})
     lib.stralg_amd_release()
-    # (2) into malloc'd host arrays, when every rank's 24 bytes per base fit the host
-    need = (index_bytes + n) * world
-    fits, _ = farm.reduce_scalars(0.0 if psutil.virtual_memory().available > need * 1.3 else 1.0, 0, device=red_dev)
-    if fits == 0.0:
-        x = text.cpu().numpy()
-        sa = np.empty(N, dtype=np.uint32)
-        c = np.zeros(sigma, dtype=np.uint32)
-        o = np.empty((N + 1) * sigma, dtype=np.uint32)
-
-        def host_tables():
-            ctx._check(lib.sx_build_tables(ctx.h, x.ctypes.data, n, sigma, sa.ctypes.data, c.ctypes.data, o.ctypes.data),
-                       "sx_build_tables")
-
-        host_tables()  # (first touch of the result arrays, the staging slab)
-        t_own = farm.timed(host_tables, 1, 0, cuda=cuda)
-        t_max, units = farm.reduce_scalars(t_own, N, device=red_dev)
-        out.update(host_tables_ms_per_record=round(t_max * 1e3, 1),
-                   host_tables_Msuffixes_per_s=round(units / t_max / 1e6, 3),
-                   host_tables_GBps_per_rank=round((index_bytes + n) / t_own / 1e9, 2))
-    else:
-        out["host_tables"] = f"skipped: {need >> 30} GiB of host memory needed for {world} ranks"
-    out["egress_note"] = ("all ranks at once between barriers, starting from the record on the host: remap, H2D, build, then "
-                   "SA + C + O (24 B per base) over PCIe; stream = the reference's index file into /dev/null")
+    out["what"] = ("sa_is_construction(host string, 5) through libstralg_amd.so (median of the calls, warm context: strlen, H2D, "
+                   "launch chain, D2H into a malloc'd array) next to the same call of the CPU baseline on one host core")
     return out
+
+
+def _cfg5_worker(args):
+    """one CPU process of the cfg5 row: the reference's (or the port's) construction on one record's sample"""
+    seed, log2n, sigma = args
+    import oracle
+    from oracle import pyoracle
+    from stralg_amd.synth import synth
+    x = synth(1 << log2n, sigma, seed)
+    ref = pyoracle._Ref() if pyoracle.have_ref() else None
+    t0 = time.perf_counter()
+    sa = ref.sa_is_mem(x, sigma) if ref else oracle.sa_is(x, sigma)
+    return time.perf_counter() - t0, int(sa[1])
+
+
+def cpu_cfg5_row(records, log2n, sigma=5, seed=42):
+    """SURVEY.md section 8d's CPU row for configs[4]: `records` CPU processes at once, one per record (a bounded sample of
+    each record: its first 2^log2n symbols; the reference is single-threaded, so this is what `records` cores give), next to
+    the single-thread figure.  Aggregate = all samples' suffixes / the slowest process's time."""
+    import multiprocessing as mp
+    from oracle import pyoracle
+    procs = max(1, min(records, os.cpu_count() or 1))
+    jobs = [(seed + r, log2n, sigma) for r in range(records)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(procs) as pool:  # (spawn: the children never see this process's GPU state)
+        res = pool.map(_cfg5_worker, jobs)
+    wall = time.perf_counter() - t0
+    per = [r[0] for r in res]
+    N = (1 << log2n) + 1
+    return {"records": records, "processes": procs, "host_cpus": os.cpu_count(), "kind": "reference" if pyoracle.have_ref() else "port",
+            "fn": "sa_is_mem_construction" if pyoracle.have_ref() else "oracle_sa_is", "sample": f"the first 2^{log2n} symbols of each record",
+            "seconds_per_process": [round(v, 2) for v in per],
+            "aggregate_Msuffixes_per_s": round(records * N / max(max(per), 1e-9) / 1e6, 3) if procs == records else
+            round(records * N / wall / 1e6, 3),
+            "single_thread_Msuffixes_per_s": round(N / min(per) / 1e6, 3), "unit": "Msuffixes/s",
+            "note": "suffix arrays only (the reference's O table overflows its uint32_t size beyond 204.8 Mi positions, bwt.c:50-51)"}
 
 
 # ---- one rank ----------------------------------------------------------------------------------------------
@@ -510,6 +272,10 @@ def run_rank(args):
     import torch
     import stralg_amd
     from stralg_amd import farm, workloads
+    from stralg_amd.benchlegs.ceiling import measured_ceiling
+    from stralg_amd.benchlegs.configs import other_configs
+    from stralg_amd.benchlegs.hostpath import egress_leg, end_to_end
+    from stralg_amd.benchlegs.pins import reference_pin
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -564,6 +330,21 @@ def run_rank(args):
                                                       getattr(pr, "pci_device_id", 0))
             ident["hbm_GiB"] = round(pr.total_memory / 2**30, 1)
         coll["ranks"] = farm.gather_objects(ident)
+        # N ranks must mean N GPUs: two ranks on one device (a launcher that handed out the same LOCAL_RANK, a masked
+        # HIP_VISIBLE_DEVICES) would report a batch throughput no batch of GPUs has.  Fail loudly: one JSON line with `error`
+        # from rank 0, a non-zero exit on every rank.  ($STRALG_BENCH_SHARE_GPU=1: the builder's one-GPU rehearsal.)
+        if cuda and os.environ.get("STRALG_BENCH_SHARE_GPU") != "1":
+            seen = [(r.get("pci_bus_id"), r.get("device_name")) for r in coll["ranks"]]
+            shared = sorted({p[0] for p in seen if seen.count(p) > 1})
+            if shared:
+                if rank == 0:
+                    print(json.dumps({"metric": "Msuffixes/s", "value": None, "unit": "Msuffixes/s", "n_gpus": world,
+                                      "error": f"{world} ranks but GPUs {shared} are used by more than one of them "
+                                               "(set STRALG_BENCH_SHARE_GPU=1 to rehearse on one GPU)",
+                                      "ranks": coll["ranks"]}), flush=True)
+                dist.destroy_process_group()
+                ctx.close()
+                return 3
 
     def sync():
         if cuda:
@@ -616,6 +397,8 @@ def run_rank(args):
         ctx.profile_enable(False)
         return ctx.profile_read()
 
+    # the box's measured memory ceiling, a few milliseconds before the timed region (rank 0 reports it)
+    ceiling = measured_ceiling(ctx, dev, nbytes=(1 << 20) if emu else (2 << 30)) if (rank == 0 and not args.no_ceiling) else None
     for _ in range(args.warmup):
         step()
     # one more untimed step, with events around every launch: the per-class table and the dominant class
@@ -782,6 +565,13 @@ def run_rank(args):
                                    "builder; not measured in this run") if traffic is not None else None,
                 "launches": d["launches"],
                 "avg_ms": round(d["ms"] / max(1, d["launches"]), 4),
+                # the same fraction against what THIS box streams (sx_membw_probe before the timed region): boxes of the pool
+                # differ by 12 - 14 % on unchanged kernels, a fraction of the data sheet's 8 TB/s cannot tell which moved
+                **({"peak_measured": ceiling["peak_measured"],
+                    "frac_of_measured": round(achieved / ceiling["peak_measured"], 4),
+                    "measured": {k: ceiling[k] for k in ("read", "fill", "copy", "split4")}}
+                   if ceiling and ceiling.get("peak_measured") else ({"peak_measured": None, "ceiling_error": ceiling.get("error")}
+                                                                      if ceiling else {})),
             },
             "verified": verified if bad_ranks == 0.0 else False,
             "verified_checks": checks,
@@ -797,6 +587,9 @@ def run_rank(args):
         out["whole_step"] = {"alg_GB": round(alg_total / 1e9, 2),
                              "GBps": round(alg_total / (elapsed / args.steps) / 1e9, 1),
                              "frac_of_peak": round(alg_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        if ceiling and ceiling.get("peak_measured"):
+            out["whole_step"]["frac_of_measured"] = round(alg_total / (elapsed / args.steps) / 1e9 / ceiling["peak_measured"], 4)
+            out["memory_ceiling"] = ceiling
         # the same from the hardware counters (BASELINE's target is stated on rocprof's HBM bytes): replayed like roofline.traffic
         hbm_total, hbm_stale, hbm_missing = pmc_whole_step(workload, args.log2n if args.n == 0 else -1, sigma, tables,
                                                            {k: v["launches"] for k, v in table.items()})
@@ -806,6 +599,11 @@ def run_rank(args):
                                       "hbm_frac_of_peak_pmc": round(hbm_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                                       "hbm_pmc_stale": hbm_stale, "hbm_pmc_classes_without_figure": hbm_missing})
         if fasta is not None:
+            if not args.no_cpu:
+                try:  # SURVEY.md section 8d's CPU row for configs[4]: one CPU process per record, all at once
+                    fasta["cpu_cfg5"] = cpu_cfg5_row(max(world, 1) if world > 1 else 8, min(args.cpu_log2n, args.log2n))
+                except Exception as e:  # noqa: BLE001
+                    fasta["cpu_cfg5"] = {"error": f"{type(e).__name__}: {e}"}
             out["fasta_record"] = fasta
         if coll is not None:
             # who took part: the driver can check "RCCL saw N ranks" and that N distinct GPUs did the work
@@ -814,7 +612,7 @@ def run_rank(args):
                                   "distinct_devices": len({(r.get("pci_bus_id"), r.get("device")) for r in coll["ranks"]}),
                                   "note": "no collective on the data path; this group carries the timing barrier and the "
                                           "max / sum of the bookkeeping scalars only"}
-        if world == 1 and not args.no_e2e and not emu and workload in ("dna", "fasta"):
+        if world == 1 and not args.no_e2e and workload in ("dna", "fasta"):
             del text, sa, bwt, c_tab, o_tab
             job = None
             ctx.trim()
@@ -832,13 +630,19 @@ def run_rank(args):
             if cuda:
                 torch.cuda.empty_cache()
             out["other_configs"] = other_configs(ctx, dev, max(1, args.other_steps), cuda, args.log2n,
-                                                 cpu_whole_record=not args.no_cpu and not args.no_cpu_whole_record and not emu)
+                                                 cpu_whole_record=cpu_baseline_at_size if (not args.no_cpu and not args.no_cpu_whole_record
+                                                                                           and not emu) else None)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cpu_sample, sigma, f"the first {cpu_n} symbols of the record rank 0 built")
             whole = next((c["cpu_reference_whole_record"] for c in out.get("other_configs", {}).values()
                           if isinstance(c, dict) and "cpu_reference_whole_record" in c), None)
             if whole is not None:  # the same baseline at a benchmark size: configs[1]'s whole 2^28-symbol record
                 out["cpu_baseline"]["whole_record"] = whole
+            if not args.no_reference_scale:
+                try:  # the reference's published operating point through the host C API (outside the timed region)
+                    out["cpu_baseline"]["reference_scale"] = reference_scale(ctx.lib, calls=3 if emu else 50)
+                except Exception as e:  # noqa: BLE001 -- an extra must not take the headline line down with it
+                    out["cpu_baseline"]["reference_scale"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         farm.fence(cuda)

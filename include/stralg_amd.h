@@ -243,6 +243,13 @@ int sx_last_stats(const sx_ctx *ctx, sx_build_stats *out);
  * (same stream as oracle_synth / stralg_amd.synth). */
 int sx_synth_dev(sx_ctx *ctx, uint8_t *d_out, uint64_t n, uint32_t sigma, uint64_t seed);
 
+/* The box's memory ceiling (measurement aid; SURVEY.md section 8d "confirm on the box"): four streaming shapes over two
+ * device buffers of `bytes` each (16-byte aligned; use far more than the 256 MB last-level cache), HIP-event timed on the
+ * context's stream, best of `reps` after a warm-up.  out_GBps[0] read (16 B a lane), [1] fill, [2] copy (bytes counted both
+ * ways), [3] four-way split of 4-byte entries (4 B in + 4 B out an entry: the store shape of the induced-sort scatters with
+ * no ranking work).  d_b is overwritten. */
+int sx_membw_probe(sx_ctx *ctx, void *d_a, void *d_b, uint64_t bytes, int reps, double *out_GBps /* 4 */);
+
 /* ---- primitives, exported for the kernel-level tests ---------------------- */
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit);
  * all four device buffers hold n entries; *result_in_b tells where the output is. */

@@ -81,6 +81,7 @@ def load(path=None):
         "sx_kernel_class_name": (C.c_char_p, [C.c_int]),
         "sx_last_stats": (C.c_int, [vp, C.POINTER(BuildStats)]),
         "sx_synth_dev": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint32, C.c_uint64]),
+        "sx_membw_probe": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
         "sx_prim_sort_pairs_dev": (C.c_int, [vp, u64p, u32p, u64p, u32p, C.c_uint64, C.c_int, C.c_int,
                                              C.POINTER(C.c_int)]),
         "sx_prim_exclusive_sum_dev": (C.c_int, [vp, u32p, u32p, C.c_uint64, u32p]),
@@ -105,7 +106,7 @@ EXPORTS = ["sx_device_count", "sx_device_numa_node", "sx_ctx_create", "sx_ctx_de
            "sx_bwt_tables_from_bwt_dev", "sx_build_tables", "sx_sa_inverse_dev", "sx_sa_lcp_dev", "sx_sa_inverse_lcp",
            "sx_bwt_exact_search_dev", "sx_build_tables_stream", "sx_fasta_pack_dev", "sx_fasta_pack", "sx_remap_dev", "sx_reverse_dev", "sx_profile_enable", "sx_profile_only",
            "sx_profile_reset", "sx_profile_read", "sx_kernel_class_name", "sx_last_stats",
-           "sx_synth_dev", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]
+           "sx_synth_dev", "sx_membw_probe", "sx_prim_sort_pairs_dev", "sx_prim_exclusive_sum_dev", "sx_prim_classify_dev"]
 
 
 def kernel_sources_sha16():

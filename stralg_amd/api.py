@@ -111,6 +111,12 @@ class Context:
         self._check(self.lib.sx_synth_dev(self.h, _ptr(d_out), n, sigma, seed), "sx_synth_dev")
 
     # ---- consumers of a resident suffix array / table ---------------------------------
+    def membw_probe(self, d_a, d_b, nbytes, reps=5):
+        """the box's streaming rates in GB/s over two device buffers of nbytes each: read, fill, copy, four-way split"""
+        out = (C.c_double * 4)()
+        self._check(self.lib.sx_membw_probe(self.h, _ptr(d_a), _ptr(d_b), nbytes, reps, out), "sx_membw_probe")
+        return dict(zip(("read", "fill", "copy", "split4"), (float(v) for v in out)))
+
     def inverse_lcp(self, text, sa, want_lcp=True):
         """sx_sa_inverse_lcp: (inverse, lcp or None) as compute_inverse / compute_lcp (suffix_array.c:53-85)."""
         text = np.ascontiguousarray(text, dtype=np.uint8)

@@ -217,6 +217,32 @@ def test_bench_default_run_carries_the_other_configs(emu_ctx):
     assert oc["bytes_4096B_induced"]["lms_path"] in (1, 2) and oc["bytes_4096B_induced"]["induce_rounds"] > 100
 
 
+def test_bench_line_carries_round5_legs(emu_ctx):
+    """round 5's additions to the line, over the CPU execution harness at 2^12 symbols: the measured-ceiling keys beside the
+    roofline, the row at the reference's published size through the host C API (arrays compared with the CPU baseline's), the
+    host-buffer leg, and -- FASTA line -- SURVEY 8d's CPU row for configs[4] (one CPU process per record)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["STRALG_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2n", "12", "--steps", "1", "--warmup", "0",
+                          "--e2e-log2n", "12", "--cpu-log2n", "12", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert "peak_measured" in doc["roofline"] and doc["roofline"]["peak"] == 8000.0
+    rs = doc["cpu_baseline"]["reference_scale"]
+    assert [r["n"] for r in rs["rows"]] == [49000, 65536] and all(r["arrays_identical"] for r in rs["rows"]), rs
+    assert rs["published"]["ms"] == 4.63 and all(r["gpu_call_ms"] > 0 and r["cpu_ms"] > 0 for r in rs["rows"])
+    e2e = doc["end_to_end"]["2^12"]
+    assert e2e["build_complete_table_ms"] > 0 and e2e["with_ro_ms"] > 0 and "readmapper_loop" in e2e
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "fasta", "--n", "5003", "--steps", "1", "--warmup", "0",
+                          "--cpu-log2n", "12", "--no-e2e", "--no-egress"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    row = doc["fasta_record"]["cpu_cfg5"]
+    assert row["records"] == 8 and row["aggregate_Msuffixes_per_s"] > 0 and len(row["seconds_per_process"]) == 8, row
+
+
 def test_bench_reports_a_failed_verification(emu_ctx, tmp_path):
     """the verifier is not a rubber stamp: a wrong suffix array is refused"""
     import torch

@@ -899,6 +899,87 @@ def test_full_size_properties(gpu_ctx, log2n, sigma):
         assert bool((c2 == c).all()) and bool((o2 == o).all())
 
 
+@pytest.mark.parametrize("log2n", [28, 30])
+def test_host_pointer_path_at_baseline_sizes(gpu_ctx, log2n):
+    """The drop-in call itself at BASELINE's sizes: build_complete_table(letters, true) and
+    sa_is_construction(symbols, 5) on HOST memory -- strlen + remap, the pager and the pinned slabs, more than 4 GiB of D2H,
+    the o_indices / ro_indices fill, the block cache -- checked on the arrays a stralg caller reads: sa->array against the
+    reference's SHA-256 / chunk hashes / sampled entries (golden_big.npz: the unmodified sa_is_mem_construction), c_table and
+    O(a, N) through o_indices against the reference's counts, every row of o_table and ro_table against the device path's
+    tables (themselves pinned to the reference by test_full_size_properties: stralg/bwt.c:134-161, sa_is.c:466-509)."""
+    import psutil
+    import torch
+    from stralg_amd import verify
+    from stralg_amd.benchlegs import cabi, pins
+    n, sigma = 1 << log2n, 5
+    N = n + 1
+    with_ro_bytes = (N + 1) * sigma * 4 * 2 + N * 4 + (N + 1) * 8 * 2 + 4 * n
+    fwd_bytes = (N + 1) * sigma * 4 + N * 4 + (N + 1) * 8 + 4 * n
+    avail = psutil.virtual_memory().available
+    if avail < fwd_bytes * 1.2:
+        pytest.skip(f"host has {avail >> 30} GiB free; the forward tables of 2^{log2n} symbols need {fwd_bytes >> 30} GiB")
+    include_reverse = avail >= with_ro_bytes * 1.2
+    lib = cabi.declare(gpu_ctx.lib)
+    text = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+    gpu_ctx.synth_dev(text, n, sigma, 42)
+    text[n] = 0
+    x = text.cpu().numpy()                      # symbols 1 .. 4, terminated
+    letters = np.frombuffer(b"\0ACGT", dtype=np.uint8)[x]  # the byte string a caller holds (terminated: x[n] = 0)
+    try:
+        t = lib.build_complete_table(letters.ctypes.data, include_reverse)
+        assert t.contents.remap_table.contents.alphabet_size == sigma
+        assert (np.ctypeslib.as_array(t.contents.sa.contents.string, shape=(N,)) == x).all(), "sa->string is not the remapped record"
+        pin = pins.host_table_pin(t, n)
+        assert pin is not None and pin["match"], pin
+        # every row of the host tables against the device path on the same record
+        host_o = np.ctypeslib.as_array(t.contents.o_table, shape=((N + 1) * sigma,))
+        host_ro = np.ctypeslib.as_array(t.contents.ro_table, shape=((N + 1) * sigma,)) if include_reverse else None
+        host_sa = np.ctypeslib.as_array(t.contents.sa.contents.array, shape=(N,))
+        sa = torch.empty(N, dtype=torch.int32, device="cuda")
+        bw = torch.empty(N, dtype=torch.uint8, device="cuda")
+        c = torch.zeros(sigma, dtype=torch.int32, device="cuda")
+        o = torch.empty((N + 1) * sigma, dtype=torch.int32, device="cuda")
+
+        def same(host, dev, what):
+            step = 1 << 28
+            for s0 in range(0, host.size, step):
+                up = torch.from_numpy(host[s0:s0 + step].view(np.int32)).cuda()
+                assert bool((up == dev[s0:s0 + step]).all()), f"{what}: host entries [{s0}, {s0 + step}) differ from the device path's"
+                del up
+
+        for direction, host_table in (("forward", host_o), ("reverse", host_ro)):
+            if host_table is None:
+                continue
+            d_text = text
+            if direction == "reverse":
+                d_text = torch.empty_like(text)
+                gpu_ctx.reverse_dev(text, n, d_text)
+            gpu_ctx.sa_bwt_build_dev(d_text, n, sigma, sa, bw)
+            gpu_ctx.bwt_tables_from_bwt_dev(bw, N, sigma, c, o)
+            gpu_ctx.trim()
+            assert len(verify.verify_build_on_device(d_text, n, sigma, sa, bw, c, o)) == 3
+            if direction == "forward":
+                _reference_pins(log2n, sigma, sa, bw, c, o)
+                same(host_sa, sa, "sa->array")
+            same(host_table, o, "o_table" if direction == "forward" else "ro_table")
+            if direction == "reverse":
+                del d_text
+        del sa, bw, c, o, host_o, host_ro, host_sa
+        torch.cuda.empty_cache()
+        lib.completely_free_bwt_table(t)
+        # sa_is_construction / sa_is_mem_construction on the remapped symbols in host memory (sa_is.c:466-509, sa_is_mem.c:471-494)
+        for fn in (lib.sa_is_construction,) + ((lib.sa_is_mem_construction,) if log2n <= 28 else ()):
+            a = fn(x.ctypes.data, sigma)
+            assert a.contents.length == N and C.cast(a.contents.string, C.c_void_p).value == x.ctypes.data  # borrowed, not copied
+            pin = pins.host_sa_pin(np.ctypeslib.as_array(a.contents.array, shape=(N,)), n, sigma)
+            lib.free_suffix_array(a)
+            assert pin["match"], pin
+    finally:
+        lib.stralg_amd_release()  # the calling thread's context and its cached host blocks (up to 62 GiB here)
+        gpu_ctx.trim()
+        torch.cuda.empty_cache()
+
+
 def test_wide_induction_forms_agree_at_size(gpu_ctx):
     """More than 8 buckets through the LMS sort + induced-sort passes at sizes where round 4's forms are all taken: every
     bucket's other-region round up front (bigram counts; sx_induce_wide.hpp) against a launch set per bucket
