@@ -1238,11 +1238,10 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 const double est = dense4 ? 4.5 * run : 1.2 * run + 8.0 * sqrt(run) + 16.0;
                 longest = est < 1.0 ? 1u : (est > 1e9 ? 1000000000u : (uint32_t)est);
             }
+            uint32_t res[3] = {0, 0, 0};
             SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, top_bits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
                                  tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar, longest,
-                                 long_list, kLongCap));
-            uint32_t res[3] = {0, 0, 0};
-            SX_TRY(sx_readback(ctx, d_scalar, 3, res));
+                                 long_list, kLongCap, res));
             bool fits = !(res[1] & 1u);
             ctx->stats.long_subbuckets = 0;
             if (fits && res[2] != 0) {

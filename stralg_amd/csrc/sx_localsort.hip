@@ -37,21 +37,34 @@ constexpr int kLsCap = kLsThreads * kLsItems; // pairs a workgroup can hold: 614
 #endif
 constexpr int kLsSpan = SX_LS_SPAN;           // a workgroup owns the sub-buckets that start in its span of the array
 constexpr int kLsWords = kLsCap / 32;
-constexpr int kLsBins = 8192;  // bins of the counting pass: 16 KiB of packed 16-bit counters in the (then unused) key image
-constexpr int kLsMaxBin = 16;  // a bin with more pairs than this: stable passes instead (equal keys crowd one bin)
+#ifndef SX_LS_BINS
+#define SX_LS_BINS 8192
+#endif
+constexpr int kLsBins = SX_LS_BINS;  // bins of the counting pass: 16 KiB of packed 16-bit counters in the (then unused) key image
+#ifndef SX_LS_MAXBIN
+#define SX_LS_MAXBIN 16
+#endif
+constexpr int kLsMaxBin = SX_LS_MAXBIN;  // a bin with more pairs than this: stable passes instead (equal keys crowd one bin)
 static_assert(kLsBins / 2 % kLsThreads == 0 && (kLsBins / 2 + 1) * 8 <= kLsCap * 8, "counter words per thread; both counter sets fit the key image");
 
 // One workgroup: local indices i = global index - g0, g0 = blockIdx.x * kLsSpan.
 //   s = first sub-bucket start at i >= 0, e = first sub-bucket start (or the end of the array) at i >= kLsSpan;
 //   the workgroup owns [s, e).  Every sub-bucket starts in exactly one span, so the owned ranges tile the array.
 // kin/vin: pairs ordered by (key & kmask) >> L; the key bits from kbits on are payload (the symbol window).
-__global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
+// Round 5: this is the kernel of rounds 3 and 4, kept for the workgroups whose pairs the lean kernel below cannot order
+// (crowded bins: many equal keys, a repeat's ties; more sub-buckets than bins): those leave kLsRedo in tile_start and are
+// done again here, with the stable passes, by a launch the host queues only when some workgroup asked for it.
+constexpr uint32_t kLsRedo = 0xFFFFFFFFu;
+__global__ __launch_bounds__(kLsThreads, 4) void local_sort_redo_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
     uint32_t *__restrict__ tile_cnt, uint2 *__restrict__ stage, uint8_t *__restrict__ stage_head,
     uint32_t *__restrict__ fail, uint32_t span /* kLsSpan, or more where the sub-buckets are known to be short */,
     uint32_t *__restrict__ long_list /* or null */, uint32_t *__restrict__ long_count, uint32_t long_cap)
 {
+    // (a long sub-bucket across this span's end has been listed by the lean kernel already: long_cap == 0 here means
+    //  "do not list", not "no list")
+    if (tile_start[blockIdx.x] != kLsRedo) return; // (uniform: the lean kernel finished this workgroup's pairs)
     __shared__ uint64_t K[kLsCap]; // keys; then (payload << 32 | sub-bucket rank << L | low bits); per-wave counters during a ranking
     __shared__ uint32_t V[kLsCap]; // positions
     __shared__ uint32_t bnd[kLsWords], bpre[kLsWords]; // sub-bucket starts as bits; starts before each word
@@ -126,9 +139,11 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
         const uint32_t z = s_last;
         if (t == 0) {
             // on the list of long sub-buckets (sx_long_subbuckets orders them); no list, or a full one: the whole sort falls back
-            const uint32_t at = long_list ? atomicAdd(long_count, 1u) : long_cap;
-            if (at < long_cap) long_list[at] = (uint32_t)(g0 + z);
-            else atomicOr(fail, 1u);
+            if (long_cap != 0 || !long_list) { // (see above)
+                const uint32_t at = long_list ? atomicAdd(long_count, 1u) : long_cap;
+                if (at < long_cap) long_list[at] = (uint32_t)(g0 + z);
+                else atomicOr(fail, 1u);
+            }
             if (z == s) tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
         }
         if (z == s) return;
@@ -400,6 +415,323 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_kernel(
     }
 }
 
+
+// ---- the lean kernel (round 5) ------------------------------------------------------------------------------------------
+// The same job with the pairs kept in registers from the load to the stores.  Rounds 3 and 4 wrote the keys to LDS, found
+// the sub-bucket starts there, rewrote every key as (payload, rank, low bits), read the pairs back striped, and after the
+// ranking wrote them to LDS once more to read them a last time in order: 14 barriers, ~25 LDS operations a pair, 72 KiB a
+// workgroup (two a CU, four waves a SIMD), 2.4 TB/s -- bound by the latencies between its barriers, not by instruction issue
+// (2300 vector instructions a wave) nor by memory.  Here:
+//   * a thread loads its pairs in the order it keeps them (wave w: indices w * 64 * ITEMS + k * 64 + lane), a pair's
+//     neighbour is the lane beside it: sub-bucket starts are a compare with a DPP-shifted copy, their bit array twelve ballots
+//     in scalar registers, a pair's sub-bucket rank a popcount;
+//   * one array of 16-bit counters: counts, their scan, and cursors that the drops advance -- after the drops counter b holds
+//     the end of bin b, which is the start of bin b + 1;
+//   * a pair learns its final slot from the sort fields of its bin's other pairs (R, 4 bytes a pair: the only LDS image) and
+//     whether it is tied in the same look; positions and windows go straight to their places in HBM (a wave's 64 stores land
+//     in the few sub-buckets its lanes belong to: the same cache lines as stores in order);
+//   * tied pairs (under one in a hundred) leave their position in R at their final slot and a bit in two small bit arrays, from
+//     which they are listed in order.
+// 42 KiB of LDS, 8 barriers.  A workgroup that meets a crowded bin or has more sub-buckets than bins leaves its pairs to the
+// kernel above (kLsRedo in tile_start, bit 2 of *fail: the host queues that launch).
+#ifdef SX_LS_PROBE // (diagnostic build: cycles of the lean kernel's phases, summed over the workgroups' first waves; tools/ab_macros.sh)
+__device__ unsigned long long sx_ls_probe[16];
+#define LS_PROBE(i)                                                                  \
+    do {                                                                             \
+        const unsigned long long now_ = (unsigned long long)clock64();               \
+        probe_d[i] = (unsigned)(now_ - probe_t);                                     \
+        probe_t = now_;                                                              \
+    } while (0)
+#else
+#define LS_PROBE(i) ((void)0)
+#endif
+#ifndef SX_LS2_THREADS
+#define SX_LS2_THREADS 1024
+#endif
+constexpr int kL2Threads = SX_LS2_THREADS, kL2Waves = kL2Threads / kWave, kL2Items = kLsCap / kL2Threads, kL2PerWave = kWave * kL2Items;
+constexpr int kL2MinWaves = kL2Threads >= 1024 ? 8 : 4; // (waves a SIMD the register budget is cut for)
+static_assert(kL2Threads * kL2Items == kLsCap && kLsBins / 2 % kL2Threads == 0, "the lean kernel's shape");
+__global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
+    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
+    uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
+    uint32_t *__restrict__ tile_cnt, uint2 *__restrict__ stage, uint8_t *__restrict__ stage_head,
+    uint32_t *__restrict__ fail, uint32_t span, uint32_t *__restrict__ long_list /* or null */, uint32_t *__restrict__ long_count,
+    uint32_t long_cap)
+{
+    __shared__ uint32_t cw[kLsBins / 2 + 2];  // packed 16-bit counters: counts, then first slots, then (after the drops) ends
+    __shared__ uint32_t R[kLsCap];            // sort fields in bin order; then the positions of tied pairs at their final slots
+    __shared__ uint32_t tiedb[kLsWords], headb[kLsWords], tpre[kLsWords];
+    __shared__ uint32_t s_first, s_end, s_last, s_max, s_scan[kL2Waves], s_starts[kL2Waves];
+    const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t g0 = (uint64_t)blockIdx.x * span;
+    const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+    const uint32_t avail = m - g0 < (uint64_t)kLsCap ? (uint32_t)(m - g0) : (uint32_t)kLsCap; // pairs in reach
+    const bool end_in_reach = g0 + avail == m;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const uint32_t i0 = (uint32_t)w * kL2PerWave + (uint32_t)lane; // index (from g0) of this thread's pair 0; pair k: + 64 k
+#ifdef SX_LS_PROBE
+    unsigned long long probe_t = (unsigned long long)clock64();
+    unsigned probe_d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    // ---- the pairs, and the key in front of the wave's first ----------------------------------------------------------------
+    uint64_t key[kL2Items];
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k) {
+        const uint32_t i = i0 + (uint32_t)k * kWave;
+        key[k] = i < avail ? __builtin_nontemporal_load(kin + g0 + i) : 0ull;
+    }
+    const uint64_t wave_at = g0 + (uint64_t)w * kL2PerWave;
+    const uint64_t kfront = (wave_at > 0 && wave_at <= m) ? kin[wave_at - 1] : 0ull;
+    // (while the loads are in flight: the counters and the bit arrays)
+    for (int i = t; i < kLsBins / 2 + 2; i += kL2Threads) cw[i] = 0;
+    for (int i = t; i < kLsWords; i += kL2Threads) tiedb[i] = 0, headb[i] = 0;
+    if (t == 0) s_first = kNone, s_end = kNone, s_last = 0, s_max = 0;
+    __syncthreads();
+    LS_PROBE(0);
+    // ---- sub-bucket starts: ballots ------------------------------------------------------------------------------------------
+    uint64_t sm[kL2Items]; // bit l of sm[k]: pair k of lane l opens a sub-bucket (uniform over the wave)
+    uint32_t n_starts = 0;
+    {
+        uint32_t before = (uint32_t)((kfront & kmask) >> L); // the sub-bucket of the pair in front of lane 0's
+#pragma unroll
+        for (int k = 0; k < kL2Items; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * kWave;
+            const uint32_t idc = (uint32_t)((key[k] & kmask) >> L);
+            uint32_t prev = __shfl_up(idc, 1u);
+            if (lane == 0) prev = before;
+            const bool start = i < avail && (g0 + i == 0 || prev != idc);
+            sm[k] = __ballot(start ? 1 : 0);
+            n_starts += (uint32_t)__popcll(sm[k]);
+            before = (uint32_t)__builtin_amdgcn_readlane((int)idc, kWave - 1);
+        }
+    }
+    if (lane == 0) {
+        s_starts[w] = n_starts;
+        // the first start in the span, the first at or behind the span's end (this wave's candidates)
+        uint32_t fs = kNone, fe = kNone;
+#pragma unroll
+        for (int k = 0; k < kL2Items; ++k) {
+            const uint32_t base = (uint32_t)w * kL2PerWave + (uint32_t)k * kWave;
+            uint64_t below = sm[k], above = sm[k];
+            if (base >= span) below = 0;
+            else if (span - base < 64u) below &= (1ull << (span - base)) - 1ull, above &= ~((1ull << (span - base)) - 1ull);
+            else above = 0;
+            if (below && fs == kNone) fs = base + (uint32_t)__ffsll((unsigned long long)below) - 1u;
+            if (above && fe == kNone) fe = base + (uint32_t)__ffsll((unsigned long long)above) - 1u;
+        }
+        if (fs != kNone) atomicMin(&s_first, fs);
+        if (fe != kNone) atomicMin(&s_end, fe);
+    }
+    __syncthreads();
+    LS_PROBE(1);
+    const uint32_t s = s_first;
+    uint32_t e = s_end;
+    if (e == kNone && end_in_reach) e = avail; // (a last workgroup whose reach ends inside the span)
+    if (s == kNone || s >= e) { // no sub-bucket starts in the span: nothing of its own (uniform)
+        if (t == 0) tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
+        return;
+    }
+    if (e == kNone) { // the sub-bucket across the span's end is longer than the reach (uniform; rare): the last start below the span's end
+        if (lane == 0) {
+            uint32_t z1 = 0; // 1 + the wave's last start below the span's end
+#pragma unroll
+            for (int k = 0; k < kL2Items; ++k) {
+                const uint32_t base = (uint32_t)w * kL2PerWave + (uint32_t)k * kWave;
+                uint64_t below = sm[k];
+                if (base >= span) below = 0;
+                else if (span - base < 64u) below &= (1ull << (span - base)) - 1ull;
+                if (below) z1 = base + 64u - (uint32_t)__clzll((unsigned long long)below);
+            }
+            if (z1) atomicMax(&s_last, z1);
+        }
+        __syncthreads();
+        const uint32_t z = s_last - 1u; // (s itself is such a start: s_last >= s + 1)
+        if (t == 0) {
+            // on the list of long sub-buckets (sx_long_subbuckets orders them); no list, or a full one: the whole sort falls back
+            const uint32_t at = long_list ? atomicAdd(long_count, 1u) : long_cap;
+            if (at < long_cap) long_list[at] = (uint32_t)(g0 + z);
+            else atomicOr(fail, 1u);
+            if (z == s) tile_start[blockIdx.x] = 0, tile_cnt[blockIdx.x] = 0;
+        }
+        if (z == s) return;
+        e = z; // the sub-buckets in front of it are this workgroup's as ever
+    }
+    // ---- sort fields: (sub-bucket rank, low bits); the rank of a pair = the starts up to it, less the one at s ------------------
+    uint32_t starts_before = 0, starts_all = 0;
+#pragma unroll
+    for (int ww = 0; ww < kL2Waves; ++ww) {
+        const uint32_t x = s_starts[ww];
+        if (ww < w) starts_before += x;
+        starts_all += x;
+    }
+    // (bins by the starts in the whole reach, an upper bound of the owned sub-buckets: at most a few more than those)
+    const uint32_t nseg = starts_all;
+    uint32_t bb = 0;
+    while (bb < L && ((uint64_t)nseg << (bb + 1u)) <= (uint64_t)kLsBins) ++bb;
+    const uint32_t nb = nseg << bb, bshift = L - bb;
+    if (nb > (uint32_t)kLsBins) { // more sub-buckets than bins (uniform): the other kernel's stable passes
+        if (t == 0) tile_start[blockIdx.x] = kLsRedo, tile_cnt[blockIdx.x] = 0, atomicOr(fail, 4u);
+        return;
+    }
+    const uint32_t lowmask = L >= 32 ? ~0u : ((1u << L) - 1u);
+    uint32_t f[kL2Items], pay[kL2Items], own = 0; // sort field, window, bit k: pair k is this workgroup's
+    {
+        uint32_t run = starts_before;
+#pragma unroll
+        for (int k = 0; k < kL2Items; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * kWave;
+            const uint32_t rank = run + (uint32_t)__popcll(sm[k] & lanemask_le()) - 1u;
+            f[k] = (rank << L) | ((uint32_t)key[k] & lowmask);
+            pay[k] = (uint32_t)(key[k] >> kbits);
+            if (i >= s && i < e) own |= 1u << k;
+            run += (uint32_t)__popcll(sm[k]);
+        }
+    }
+    // ---- counts -> first slots ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k)
+        if ((own >> k) & 1u) {
+            const uint32_t bin = f[k] >> bshift;
+            atomicAdd(&cw[bin >> 1], 1u << (16u * (bin & 1u)));
+        }
+    __syncthreads();
+    LS_PROBE(2);
+    {
+        constexpr int kPer = kLsBins / 2 / kL2Threads;
+        uint32_t wv[kPer], sum = 0, mx = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            wv[j] = cw[(uint32_t)t * kPer + (uint32_t)j];
+            const uint32_t lo = wv[j] & 0xFFFFu, hi = wv[j] >> 16;
+            mx = mx > lo ? mx : lo;
+            mx = mx > hi ? mx : hi;
+            sum += lo + hi;
+        }
+        const uint32_t inc = wave_inclusive_scan<OpAdd>(sum);
+        if (lane == kWave - 1) s_scan[w] = inc;
+        if (mx > (uint32_t)kLsMaxBin) atomicMax(&s_max, mx);
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int ww = 0; ww < w; ++ww) run += s_scan[ww];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const uint32_t lo = wv[j] & 0xFFFFu, hi = wv[j] >> 16;
+            cw[(uint32_t)t * kPer + (uint32_t)j] = run | ((run + lo) << 16);
+            run += lo + hi;
+        }
+    }
+    __syncthreads();
+    LS_PROBE(3);
+    if (s_max > (uint32_t)kLsMaxBin) { // a crowded bin: equal keys, a repeat's ties (uniform)
+        if (t == 0) tile_start[blockIdx.x] = kLsRedo, tile_cnt[blockIdx.x] = 0, atomicOr(fail, 4u);
+        return;
+    }
+    // ---- the pairs drop into their bins (any order) ------------------------------------------------------------------------
+    uint32_t sf[kL2Items]; // where the pair was dropped | its final slot << 16 (a workgroup holds < 2^16 pairs)
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k) {
+        sf[k] = 0;
+        if ((own >> k) & 1u) {
+            const uint32_t bin = f[k] >> bshift, sh = 16u * (bin & 1u);
+            sf[k] = (atomicAdd(&cw[bin >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k)
+        if ((own >> k) & 1u) R[sf[k]] = f[k];
+    __syncthreads();
+    LS_PROBE(4);
+    // (the positions are asked for now -- a third of the bytes, needed for the stores only: they arrive while the slots are found)
+    uint32_t val[kL2Items];
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k) {
+        const uint32_t i = i0 + (uint32_t)k * kWave;
+        val[k] = ((own >> k) & 1u) ? __builtin_nontemporal_load(vin + g0 + i) : 0u;
+    }
+    // ---- a pair's final slot: the first slot of its bin + the pairs of the bin that sort before it (equal fields: by slot) ----
+    uint32_t bspan[kL2Items], tied = 0, nothead = 0; // the pair's bin: first slot | pairs << 16
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k) {
+        bspan[k] = 0;
+        if ((own >> k) & 1u) {
+            const uint32_t bin = f[k] >> bshift;
+            const uint32_t end = (cw[bin >> 1] >> (16u * (bin & 1u))) & 0xFFFFu; // (the cursor has reached the bin's end)
+            const uint32_t first = bin ? (cw[(bin - 1u) >> 1] >> (16u * ((bin - 1u) & 1u))) & 0xFFFFu : 0u;
+            bspan[k] = first | ((end - first) << 16);
+            sf[k] |= first << 16;
+        }
+    }
+#pragma unroll 1
+    for (uint32_t step = 0; step < (uint32_t)kLsMaxBin; ++step) {
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < kL2Items; ++k) {
+            const uint32_t len = bspan[k] >> 16;
+            if (step < len) {
+                const uint32_t j = (bspan[k] & 0xFFFFu) + step, r2 = R[j], dropped = sf[k] & 0xFFFFu;
+                const bool eq = r2 == f[k];
+                sf[k] += (r2 < f[k] || (eq && j < dropped)) ? 0x10000u : 0u;
+                if (eq && j != dropped) tied |= 1u << k;
+                if (eq && j < dropped) nothead |= 1u << k;
+                more = more || step + 1u < len;
+            }
+        }
+        if (!__any(more ? 1 : 0)) break;
+    }
+    LS_PROBE(5);
+    // ---- out: positions and windows to their places --------------------------------------------------------------------------
+    const uint64_t gs = g0 + s;
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k)
+        if ((own >> k) & 1u) {
+            vout[gs + (sf[k] >> 16)] = val[k];
+            if (seedw) seedw[gs + (sf[k] >> 16)] = pay[k];
+        }
+    // ---- the members of groups of equal keys, listed in order ------------------------------------------------------------------
+    __syncthreads(); // (every wave has read the sort fields it needs: R is free)
+    LS_PROBE(6);
+#pragma unroll
+    for (int k = 0; k < kL2Items; ++k)
+        if ((tied >> k) & 1u) {
+            const uint32_t fin = sf[k] >> 16;
+            R[fin] = val[k];
+            atomicOr(&tiedb[fin >> 5], 1u << (fin & 31u));
+            if (!((nothead >> k) & 1u)) atomicOr(&headb[fin >> 5], 1u << (fin & 31u));
+        }
+    __syncthreads();
+    if (w == 0) { // tied members before each word: one wave scans the kLsWords word counts
+        uint32_t run = 0;
+        for (int c0 = 0; c0 < kLsWords; c0 += kWave) {
+            const int i = c0 + lane;
+            const uint32_t cnt = i < kLsWords ? (uint32_t)__popc(tiedb[i]) : 0u;
+            const uint32_t inc = wave_inclusive_scan<OpAdd>(cnt);
+            if (i < kLsWords) tpre[i] = run + inc - cnt;
+            run += __shfl(inc, kWave - 1, kWave);
+        }
+        if (lane == 0) tile_start[blockIdx.x] = (uint32_t)gs, tile_cnt[blockIdx.x] = run;
+    }
+    __syncthreads();
+    for (int wd = t; wd < kLsWords; wd += kL2Threads) {
+        uint32_t bits = tiedb[wd], at = tpre[wd];
+        const uint32_t heads = headb[wd];
+        while (bits) {
+            const uint32_t b = (uint32_t)__ffs(bits) - 1u, q = (uint32_t)wd * 32u + b;
+            bits &= bits - 1u;
+            uint2 ent;
+            ent.x = (uint32_t)(gs + q), ent.y = R[q];
+            stage[gs + at] = ent;
+            stage_head[gs + at] = (uint8_t)((heads >> b) & 1u);
+            ++at;
+        }
+    }
+    LS_PROBE(7);
+#ifdef SX_LS_PROBE
+    if (t == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&sx_ls_probe[i], (unsigned long long)probe_d[i]);
+#endif
+}
+
 // every workgroup's tied members -> their place in the global list (the offsets are a scan of tile_cnt)
 __global__ __launch_bounds__(kBlock) void local_tied_gather_kernel(const uint32_t *__restrict__ tile_start,
                                                                    const uint32_t *__restrict__ tile_cnt,
@@ -564,7 +896,7 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
                   uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used,
                                                 [2] <- long sub-buckets listed */,
-                  uint32_t longest_expected, uint32_t *long_list, uint32_t long_cap)
+                  uint32_t longest_expected, uint32_t *long_list, uint32_t long_cap, uint32_t res[3])
 {
     // The span: a workgroup's costs that do not depend on its pairs (zeroing and scanning 8192 counters, the barriers) are
     // spread over more pairs the longer it is (1 GiB of DNA, dense keys: span 5120 2.79 ms, 5632 2.60, 5888 2.52), but a
@@ -577,13 +909,41 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
     if (span < (uint32_t)kLsSpan) span = (uint32_t)kLsSpan;
     const uint32_t tiles = sx_div_up(m, span);
     const uint32_t L = (uint32_t)(kbits - top_bits);
+    uint32_t res_local[3];
+    if (!res) res = res_local;
     SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, 2 * sizeof(uint32_t), ctx->stream));
-    sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
+#ifdef SX_LS_LEAN_OFF // (A/B: rounds 3 and 4's kernel for every workgroup)
+    SX_CHECK(hipMemsetAsync(tile_start, 0xFF, (size_t)tiles * sizeof(uint32_t), ctx->stream));
+    sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_redo_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
               (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
               d_total_and_fail + 2, long_list ? long_cap : 0u);
-    SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_cnt}, OutExclusive{tile_off}, d_total_and_fail, SX_KC_NAMES, 0)));
-    sx_launch(ctx, SX_KC_NAMES, 0, local_tied_gather_kernel, dim3(tiles), dim3(kBlock), (const uint32_t *)tile_start,
-              (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, (const uint2 *)stage, (const uint8_t *)stage_head, apos, ap,
-              ahead, cap);
+#else
+    sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kL2Threads), kin, vin, m, L,
+              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
+              d_total_and_fail + 2, long_list ? long_cap : 0u);
+#endif
+#ifdef SX_LS_PROBE
+    {
+        unsigned long long h[16];
+        SX_CHECK(hipStreamSynchronize(ctx->stream));
+        SX_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(sx_ls_probe), sizeof h));
+        fprintf(stderr, "local_sort phases (cycles a workgroup, %u workgroups): load+zero %llu starts %llu count %llu scan %llu drop %llu insert %llu stores %llu list %llu\n",
+                tiles, h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[5] / tiles, h[6] / tiles, h[7] / tiles);
+        memset(h, 0, sizeof h);
+        SX_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sx_ls_probe), h, sizeof h));
+    }
+#endif
+    for (int again = 0; again < 2; ++again) {
+        SX_TRY((device_scan<OpAdd>(ctx, tiles, InU32{tile_cnt}, OutExclusive{tile_off}, d_total_and_fail, SX_KC_NAMES, 0)));
+        sx_launch(ctx, SX_KC_NAMES, 0, local_tied_gather_kernel, dim3(tiles), dim3(kBlock), (const uint32_t *)tile_start,
+                  (const uint32_t *)tile_cnt, (const uint32_t *)tile_off, (const uint2 *)stage, (const uint8_t *)stage_head, apos, ap,
+                  ahead, cap);
+        SX_TRY(sx_readback(ctx, d_total_and_fail, 3, res));
+        if (again || !(res[1] & 4u) || (res[1] & 1u)) break;
+        // some workgroups left their pairs to the kernel with the stable passes (crowded bins: a repeat's ties): that launch,
+        // then the list of tied members once more, now with theirs
+        sx_launch(ctx, SX_KC_LOCAL_SORT, 0, local_sort_redo_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L, (uint32_t)kbits, vout,
+                  seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list, d_total_and_fail + 2, 0u);
+    }
     return 0;
 }

@@ -512,15 +512,22 @@ __global__ __launch_bounds__(kRT, SX_RADIX_MINWAVES) void radix_scatter_kernel(
 #if SX_RADIX_THREADS == 1024 && SX_RADIX_ITEMS == 8
 #define SX_RADIX_LMS_PASS 1
 // Tiles of the pass: the text in blocks of kLmsBlockCls classification tiles.  Four of them (16 384 positions) hold at most a
-// radix tile's 8192 LMS suffixes -- no two are neighbours --, 5 000 on uniform DNA.  (SX_LMS_BLOCK_CLS 6, measured: 24 576
-// positions, 7 500 LMS suffixes of uniform DNA, a tile nearly as full as any other pass's; a block with more than a radix
-// tile holds is then taken as two halves, so every block owns two rows of the tile table, the second one empty unless the
-// block is split, and a workgroup has to look the block's counts up before it can ask for its text: the pass took 2.8
-// instead of 2.1 ms.)
+// radix tile's 8192 LMS suffixes -- no two are neighbours --, but only 5 000 on uniform DNA: a tile 61 % full, every
+// per-slot step of the ranking paid for 8192.  Round 5: six (24 576 positions, 7 500 LMS suffixes of uniform DNA: a tile
+// nearly as full as any other pass's).  A block may then hold more than a radix tile does (an LMS suffix at every other
+// position), so every block owns TWO rows of the tile table: the second one stays empty unless the block is taken as two
+// halves.  Whether it is, the workgroup sees from the LMS bits it has just counted -- round 4 looked the block's counts up
+// in the classification's tile table before it asked for its text (one more dependent trip to memory a workgroup: 2.8
+// against 2.1 ms); now the whole block's bits and text are asked for at once, and the rare split block is done again by
+// halves.
 #ifndef SX_LMS_BLOCK_CLS
-#define SX_LMS_BLOCK_CLS 4
+#define SX_LMS_BLOCK_CLS 6
 #endif
 constexpr int kLmsBlockCls = SX_LMS_BLOCK_CLS;
+#ifndef SX_LMS_SPLIT_GRID
+#define SX_LMS_SPLIT_GRID 256u // (the CPU test harness: 2)
+#endif
+constexpr uint32_t kLmsSplitGrid = SX_LMS_SPLIT_GRID; // workgroups of the launch that takes the listed (split) blocks by halves
 constexpr int kLmsRows = kLmsBlockCls * (kClsTile / 2) > kRadixTile ? 2 : 1; // rows of the tile table a block owns
 constexpr int kLmsBlock = kLmsBlockCls * kClsTile; // text positions of a block
 constexpr int kLmsPerThread = kLmsBlock / kRT;     // positions whose LMS bits a thread lists
@@ -540,27 +547,17 @@ static_assert(kLmsPosAt + 2 * (size_t)kRadixTile <= sizeof(uint64_t) * kRadixTil
 struct lms_span {
     uint32_t pos0, npos; // first text position, positions (a multiple of kClsTile; 0: the row is empty)
 };
-// what row `slot` of the pass's tile table stands for
-__device__ __forceinline__ lms_span lms_slot_span(const sx_lmskey &lk, uint32_t slot)
+// block b of the text: all of it (half < 0), or its first / second half (a split block's two rows)
+__device__ __forceinline__ lms_span lms_block_span(const sx_lmskey &lk, uint32_t block, int half)
 {
     lms_span sp = {0, 0};
-    if (kLmsRows == 1) { // (static) no look-up: a block is a row
-        const uint32_t c0 = slot * kLmsBlockCls;
-        if (c0 < lk.cls_tiles) sp = {c0 * (uint32_t)kClsTile, (c0 + kLmsBlockCls < lk.cls_tiles ? (uint32_t)kLmsBlockCls : lk.cls_tiles - c0) * (uint32_t)kClsTile};
-        return sp;
-    }
-    const uint32_t c0 = (slot >> 1) * kLmsBlockCls;
+    const uint32_t c0 = block * kLmsBlockCls;
+    if (c0 >= lk.cls_tiles) return sp;
     const uint32_t c1 = c0 + kLmsBlockCls < lk.cls_tiles ? c0 + kLmsBlockCls : lk.cls_tiles;
     const uint32_t cm = c0 + kLmsBlockCls / 2 < lk.cls_tiles ? c0 + kLmsBlockCls / 2 : lk.cls_tiles;
-    if (c0 >= lk.cls_tiles) return sp;
-    const uint32_t o0 = lk.tile_off[c0], o1 = c1 < lk.cls_tiles ? lk.tile_off[c1] : lk.m;
-    if (o1 - o0 <= (uint32_t)kRadixTile) {
-        if (!(slot & 1u)) sp = {c0 * (uint32_t)kClsTile, (c1 - c0) * (uint32_t)kClsTile};
-    } else if (slot & 1u) {
-        sp = {cm * (uint32_t)kClsTile, (c1 - cm) * (uint32_t)kClsTile};
-    } else {
-        sp = {c0 * (uint32_t)kClsTile, (cm - c0) * (uint32_t)kClsTile};
-    }
+    if (half < 0) sp = {c0 * (uint32_t)kClsTile, (c1 - c0) * (uint32_t)kClsTile};
+    else if (half == 0) sp = {c0 * (uint32_t)kClsTile, (cm - c0) * (uint32_t)kClsTile};
+    else sp = {cm * (uint32_t)kClsTile, (c1 - cm) * (uint32_t)kClsTile};
     return sp;
 }
 
@@ -629,7 +626,8 @@ __device__ __forceinline__ uint64_t lms_key_packed(const uint32_t *pk, uint32_t 
 
 // Lists the span's LMS suffixes and computes the keys of this thread's slots (slot i of the tile: wave w, item k, lane l
 // <-> i = 512 w + 64 k + l, radix_scatter_tile's order); pos16[k / 2] holds the offsets of items k, k + 1 inside the span.
-// Returns their number.  Ends behind a barrier; scan_lds is free again.
+// Returns their number -- when that is more than a radix tile holds, nothing else has been done.  Ends behind a barrier;
+// scan_lds is free again.
 template <int CS, int WS, int BS>
 __device__ __forceinline__ uint32_t lms_tile_keys(const sx_lmskey &lk, const lms_span &sp, uint32_t *pk, uint16_t *spos, uint32_t *scan_lds,
                                                   uint64_t (&key)[kRadixItems], uint32_t (&pos16)[kRadixItems / 2])
@@ -659,7 +657,10 @@ __device__ __forceinline__ uint32_t lms_tile_keys(const sx_lmskey &lk, const lms
         if (ww < w) at += x;
         cnt += x;
     }
-    if (cnt > (uint32_t)kRadixTile) cnt = (uint32_t)kRadixTile; // (cannot be: a row's span holds at most that many, or the block was split)
+    if (cnt > (uint32_t)kRadixTile) { // (uniform) a whole block with more LMS suffixes than a radix tile holds: the caller takes it by halves
+        __syncthreads();
+        return cnt;
+    }
     while (bits) {
         const int i = __ffs(bits) - 1;
         bits &= bits - 1u;
@@ -684,21 +685,20 @@ __device__ __forceinline__ uint32_t lms_tile_keys(const sx_lmskey &lk, const lms
 // takes the LMS positions of its own 64 (96) positions.
 constexpr int kLmsHistThreads = 256;
 template <int CS, int WS, int BS>
-__global__ __launch_bounds__(kLmsHistThreads) void radix_hist_lms_kernel(sx_lmskey lk, int shift, uint32_t mask, uint32_t *__restrict__ hist, uint32_t ntiles)
+__global__ __launch_bounds__(kLmsHistThreads) void radix_hist_lms_kernel(sx_lmskey lk, int shift, uint32_t mask, uint32_t *__restrict__ hist, uint32_t nblocks)
 {
     constexpr int ND = 256, kCopies = 4, kPer = kLmsBlock / kLmsHistThreads, kWords = kPer / 32; // words of the bit array a thread
     static_assert(kPer % 32 == 0 && ND == kLmsHistThreads, "a thread per digit, whole 32-bit words of LMS bits a thread");
+    static_assert(kLmsRows == 1 || (kLmsBlock / 2) % kPer == 0, "a thread's positions lie in one half of the block");
     __shared__ uint32_t pk[kLmsPackWords];
-    __shared__ uint32_t hh[kCopies][ND];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= ntiles) return; // uniform
+    __shared__ uint32_t hh[kLmsRows][kCopies][ND];
+    __shared__ uint32_t s_cnt;
+    const uint32_t block = blockIdx.x;
+    if (block >= nblocks) return; // uniform
     const int t = (int)threadIdx.x;
-    const lms_span sp = lms_slot_span(lk, tile);
-    if (sp.npos == 0) { // (an unsplit block's second row)
-        hist[(uint64_t)tile * ND + t] = 0;
-        return;
-    }
-    for (int i = t; i < kCopies * ND; i += kLmsHistThreads) (&hh[0][0])[i] = 0;
+    const lms_span sp = lms_block_span(lk, block, -1);
+    for (int i = t; i < kLmsRows * kCopies * ND; i += kLmsHistThreads) (&hh[0][0][0])[i] = 0;
+    if (t == 0) s_cnt = 0;
     uint32_t bits[kWords];
 #pragma unroll
     for (int j = 0; j < kWords; ++j) bits[j] = 0;
@@ -713,7 +713,16 @@ __global__ __launch_bounds__(kLmsHistThreads) void radix_hist_lms_kernel(sx_lmsk
     }
     lms_tile_pack<kLmsHistThreads, true>(lk, sp, pk);
     __syncthreads();
-    uint32_t *h = hh[t & (kCopies - 1)];
+    uint32_t *h = hh[0][t & (kCopies - 1)];
+    if (kLmsRows == 2) { // (static) more LMS suffixes than a radix tile holds: the block is two rows, its halves
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) mine += (uint32_t)__popc(bits[j]);
+        const uint32_t inc = wave_inclusive_scan<OpAdd>(mine);
+        if (lane_id() == kWave - 1) atomicAdd(&s_cnt, inc);
+        __syncthreads();
+        if (s_cnt > (uint32_t)kRadixTile && (uint32_t)t * kPer >= (uint32_t)(kLmsBlock / 2)) h = hh[kLmsRows - 1][t & (kCopies - 1)];
+    }
     // A digit that lies inside the key's symbol fields is eight bits of the stream, 2 C - 8 - (shift - lenbits) bits behind
     // the suffix's first symbol, whatever the suffix (the codes behind the end of the text are 0, as in the key): the four
     // words that hold them for 32 positions stay in registers, and a suffix costs a select, a shift and the add -- no LDS
@@ -747,36 +756,34 @@ __global__ __launch_bounds__(kLmsHistThreads) void radix_hist_lms_kernel(sx_lmsk
         }
     }
     __syncthreads();
-    uint32_t sum = 0;
 #pragma unroll
-    for (int cpy = 0; cpy < kCopies; ++cpy) sum += hh[cpy][t];
-    hist[(uint64_t)tile * ND + t] = sum;
+    for (int r = 0; r < kLmsRows; ++r) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int cpy = 0; cpy < kCopies; ++cpy) sum += hh[r][cpy][t];
+        hist[((uint64_t)block * kLmsRows + (uint32_t)r) * ND + t] = sum;
+    }
 }
 
+// One row of the pass's tile table: the LMS suffixes of span sp, listed, keyed, ranked and written to their places.  false
+// (and nothing written): the span holds more of them than a radix tile does.
 template <int CS, int WS, int BS>
-__global__ __launch_bounds__(kRT) SX_WAVES_PER_EU(8) void radix_scatter_lms_kernel(
-    sx_lmskey lk, uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
-    uint32_t ntiles, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift, uint32_t next_mask)
+__device__ __forceinline__ bool lms_scatter_row(const sx_lmskey &lk, const lms_span &sp, uint32_t row, uint64_t *skey, uint32_t *goff,
+                                                uint32_t *scan_lds, uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int shift,
+                                                uint32_t mask, const uint32_t *__restrict__ offs, uint8_t *__restrict__ dig_out,
+                                                int next_shift, uint32_t next_mask)
 {
     constexpr int ND = 256;
-    __shared__ uint64_t skey[kRadixTile]; // counters, text, positions; then the tile in digit order: keys, then values
-    __shared__ uint32_t goff[ND];
-    __shared__ uint32_t scan_lds[kRW];
-    static_assert(radix_alias<8>::value, "the per-wave counters live in the key image");
     uint32_t *wcount = reinterpret_cast<uint32_t *>(skey);
     uint32_t *pk = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(skey) + kLmsImgAt);
     uint16_t *spos = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(skey) + kLmsPosAt);
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint32_t per_xcd = (ntiles + 7u) / 8u; // (tile order: see radix_scatter_kernel)
-    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles) return; // uniform
-    const lms_span sp = lms_slot_span(lk, tile);
-    if (sp.npos == 0) return; // uniform (an unsplit block's second row)
     for (int i = t; i < kRW * ND; i += kRT) wcount[i] = 0;
-    const uint32_t first_out = t < ND ? offs[(uint64_t)tile * ND + t] : 0u; // asked for now, needed after the ranking
+    const uint32_t first_out = t < ND ? offs[(uint64_t)row * ND + t] : 0u; // asked for now, needed after the ranking
     uint64_t key[kRadixItems];
     uint32_t pos16[kRadixItems / 2];
     const uint32_t cnt = lms_tile_keys<CS, WS, BS>(lk, sp, pk, spos, scan_lds, key, pos16);
+    if (cnt > (uint32_t)kRadixTile) return false; // uniform: a whole block with more LMS suffixes than a radix tile holds
     const uint32_t wave0 = (uint32_t)w * (kWave * kRadixItems);
     uint32_t lpos[kRadixItems]; // [12:0] rank within (wave, digit), then slot in the tile's digit order; [31:16] digit
 #pragma unroll
@@ -843,6 +850,47 @@ __global__ __launch_bounds__(kRT) SX_WAVES_PER_EU(8) void radix_scatter_lms_kern
         const uint32_t i = (uint32_t)t + (uint32_t)k * kRT;
         if (i < cnt) vout[dstv[k]] = sval[i];
     }
+    return true;
+}
+
+// split_list: [0] the number of blocks that hold more LMS suffixes than a radix tile (an LMS suffix at every other position:
+// never on random text), [1 ...] those blocks.  HALVES false: a workgroup a block, the whole block as row kLmsRows * block of
+// the tile table; a block that turns out too full is put on the list and left alone.  HALVES true (a few workgroups, queued
+// behind: they find the list empty): the listed blocks as their two halves, two rows each.
+template <int CS, int WS, int BS, bool HALVES>
+__global__ __launch_bounds__(kRT) SX_WAVES_PER_EU(8) void radix_scatter_lms_kernel(
+    sx_lmskey lk, uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int shift, uint32_t mask, const uint32_t *__restrict__ offs,
+    uint32_t nblocks, uint8_t *__restrict__ dig_out /* digits of the NEXT pass, or null */, int next_shift, uint32_t next_mask,
+    uint32_t *__restrict__ split_list)
+{
+    constexpr int ND = 256;
+    __shared__ uint64_t skey[kRadixTile]; // counters, text, positions; then the tile in digit order: keys, then values
+    __shared__ uint32_t goff[ND];
+    __shared__ uint32_t scan_lds[kRW];
+    static_assert(radix_alias<8>::value, "the per-wave counters live in the key image");
+    if (!HALVES) {
+        const uint32_t per_xcd = (nblocks + 7u) / 8u; // (tile order: see radix_scatter_kernel)
+        const uint32_t block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        if (block >= nblocks) return; // uniform
+        const lms_span sp = lms_block_span(lk, block, -1);
+        if (sp.npos == 0) return;
+        if (!lms_scatter_row<CS, WS, BS>(lk, sp, block * (uint32_t)kLmsRows, skey, goff, scan_lds, kout, vout, shift, mask, offs, dig_out,
+                                         next_shift, next_mask)) {
+            if (threadIdx.x == 0) split_list[1u + atomicAdd(&split_list[0], 1u)] = block;
+        }
+    } else {
+        const uint32_t n_split = split_list[0];
+        for (uint32_t i = blockIdx.x; i < n_split; i += gridDim.x) { // uniform
+            const uint32_t block = split_list[1u + i];
+            for (int h = 0; h < 2; ++h) {
+                const lms_span sp = lms_block_span(lk, block, h);
+                if (sp.npos)
+                    (void)lms_scatter_row<CS, WS, BS>(lk, sp, block * (uint32_t)kLmsRows + (uint32_t)h, skey, goff, scan_lds, kout, vout, shift,
+                                                      mask, offs, dig_out, next_shift, next_mask);
+                __syncthreads(); // (the image is read by the row's last stores and written by the next row)
+            }
+        }
+    }
 }
 #else
 #define SX_RADIX_LMS_PASS 0
@@ -880,7 +928,7 @@ bool sx_sort_lms_keys_applies(uint64_t m, uint32_t cls_tiles, uint32_t shape)
 {
 #if SX_RADIX_LMS_PASS
     const uint64_t ntiles1 = (uint64_t)kLmsRows * sx_div_up(cls_tiles, kLmsBlockCls), nchunks1 = sx_div_up(ntiles1, kRadixChunk);
-    if ((ntiles1 + nchunks1 + 1) * 256 * sizeof(uint32_t) > m * sizeof(uint64_t)) return false;
+    if ((ntiles1 + nchunks1 + 1) * 256 * sizeof(uint32_t) + (ntiles1 / kLmsRows + 2) * sizeof(uint32_t) > m * sizeof(uint64_t)) return false; // (+ the list of split blocks)
     switch (shape) {
     case lms_key_shape(15, 12, 2):
     case lms_key_shape(16, 11, 2):
@@ -921,15 +969,18 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
         if (shift == begin_bit && lms_keys) {
             if constexpr (DB == 8) {
                 const sx_lmskey &lk = *lms_keys;
-                const uint32_t ntiles1 = (uint32_t)kLmsRows * sx_div_up(lk.cls_tiles, kLmsBlockCls), nchunks1 = sx_div_up(ntiles1, kRadixChunk);
+                const uint32_t nblocks1 = sx_div_up(lk.cls_tiles, kLmsBlockCls);
+                const uint32_t ntiles1 = (uint32_t)kLmsRows * nblocks1, nchunks1 = sx_div_up(ntiles1, kRadixChunk);
                 if (!sx_sort_lms_keys_applies(n, lk.cls_tiles, lk.shape) || lk.m != n) return sx_fail_msg(ctx, SX_E_INTERNAL, "sort: LMS-keyed first pass");
                 uint32_t *hist1 = (uint32_t *)ka, *sums1 = hist1 + (size_t)ntiles1 * ND, *base1 = sums1 + (size_t)nchunks1 * ND;
+                uint32_t *split1 = base1 + ND; // the list of blocks taken by halves: a count, then at most nblocks1 blocks
+                SX_CHECK(hipMemsetAsync(split1, 0, sizeof(uint32_t), ctx->stream));
                 const uint64_t text_bytes = (uint64_t)lk.cls_tiles * (kClsTile + kClsTile / 8);
                 const uint8_t next_mask8 = has_next ? (uint8_t)((1u << next_bits) - 1u) : 0;
 #define SX_LMS_PASS(CS, WS, BS)                                                                                                          \
     case lms_key_shape(CS, WS, BS):                                                                                                      \
-        sx_launch(ctx, SX_KC_RADIX_HIST, text_bytes, radix_hist_lms_kernel<CS, WS, BS>, dim3(ntiles1), dim3(kLmsHistThreads), lk, shift, mask, hist1, \
-                  ntiles1);                                                                                                              \
+        sx_launch(ctx, SX_KC_RADIX_HIST, text_bytes, radix_hist_lms_kernel<CS, WS, BS>, dim3(nblocks1), dim3(kLmsHistThreads), lk, shift, mask, hist1, \
+                  nblocks1);                                                                                                             \
         break;
                 switch (lk.shape) {
                     SX_LMS_PASS(15, 12, 2)
@@ -949,9 +1000,13 @@ static int sort_pairs_db(sx_ctx *ctx, uint64_t *ka, uint32_t *va, uint64_t *kb, 
                 }
 #define SX_LMS_PASS(CS, WS, BS)                                                                                                          \
     case lms_key_shape(CS, WS, BS):                                                                                                      \
-        sx_launch(ctx, SX_KC_KEYS, text_bytes + n * (12 + (has_next ? 1 : 0)), radix_scatter_lms_kernel<CS, WS, BS>,                     \
-                  dim3(((ntiles1 + 7) / 8) * 8), dim3(kRT), lk, kout, vout, shift, mask, (const uint32_t *)hist1, ntiles1,                \
-                  has_next ? (uint8_t *)dig : (uint8_t *)nullptr, next_shift & 63, (uint32_t)next_mask8);                                 \
+        sx_launch(ctx, SX_KC_KEYS, text_bytes + n * (12 + (has_next ? 1 : 0)), radix_scatter_lms_kernel<CS, WS, BS, false>,              \
+                  dim3(((nblocks1 + 7) / 8) * 8), dim3(kRT), lk, kout, vout, shift, mask, (const uint32_t *)hist1, nblocks1,              \
+                  has_next ? (uint8_t *)dig : (uint8_t *)nullptr, next_shift & 63, (uint32_t)next_mask8, split1);                         \
+        if (kLmsRows == 2)                                                                                                               \
+            sx_launch(ctx, SX_KC_KEYS, 0, radix_scatter_lms_kernel<CS, WS, BS, true>, dim3(kLmsSplitGrid), dim3(kRT), lk, kout, vout,    \
+                      shift, mask, (const uint32_t *)hist1, nblocks1, has_next ? (uint8_t *)dig : (uint8_t *)nullptr, next_shift & 63,   \
+                      (uint32_t)next_mask8, split1);                                                                                     \
         break;
                 switch (lk.shape) {
                     SX_LMS_PASS(15, 12, 2)

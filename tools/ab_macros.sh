@@ -1,11 +1,11 @@
 #!/bin/bash
-# same-box A/B of compile-time variants of one source file: tools/ab_macros.sh FILE.hip "BENCH ARGS" CLASS "" "-DX=1" "-DY=2" ...
+# same-box A/B of compile-time variants of source files: tools/ab_macros.sh FILE.hip[,FILE2.hip] "BENCH ARGS" CLASS "" "-DX=1" "-DY=2" ...
 cd "${GRAFT_REPO_ROOT:-.}"
 file=$1; args=$2; cls=$3; shift 3
 base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
 for round in 1 2; do
 for v in "$@"; do
-  touch stralg_amd/csrc/$file
+  for f in ${file//,/ }; do touch stralg_amd/csrc/$f; done
   make -s -C stralg_amd/csrc -j16 HIPFLAGS="$base $v" 2>&1 | grep -E "error" | head -3
   echo "== [$v]"
   timeout 300 python bench.py --no-e2e --no-cpu --no-other-configs --no-egress $args 2>/dev/null | python3 -c "
@@ -13,5 +13,5 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('verified'), {k:v['ms_per_step'] for k,v in d['kernels'].items() if k in '$cls'.split(',')})"
 done
 done
-touch stralg_amd/csrc/$file
+for f in ${file//,/ }; do touch stralg_amd/csrc/$f; done
 make -s -C stralg_amd/csrc -j16 2>&1 | grep -E "error" | head -3
