@@ -144,6 +144,10 @@ enum {
                                        prefix key, as wide alphabets are: a third of the launches of classification + LMS sort +
                                        induced passes, which is what a short record's build consists of); 0 = never; negative: the
                                        default (2^24, 2^25, 2^27 suffixes for at most 4, 7, 15 letters) */
+    ,SX_FLAG_LOCAL_SORT_LEAN_OFF = 17 /* hybrid prefix-key sort, the step that orders the sub-buckets in LDS: 1 = every workgroup
+                                       takes the kernel of rounds 3 and 4 (pairs through LDS, stable passes where equal keys
+                                       crowd a bin); 0 (default) = the lean kernel of round 5, which leaves only the workgroups it
+                                       cannot finish to that one */
 };
 int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value);
 

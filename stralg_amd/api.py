@@ -265,6 +265,11 @@ class Context:
         by HBM passes of their own (default), or falls back to plain passes when it meets one (rounds 1 - 3)"""
         self._check(self.lib.sx_ctx_set_flag(self.h, 15, 0 if on else 1), "sx_ctx_set_flag")
 
+    def set_local_sort_lean(self, on=True):
+        """SX_FLAG_LOCAL_SORT_LEAN_OFF: the hybrid sort's LDS step by the lean kernel of round 5 (default), or every workgroup by
+        the kernel of rounds 3 and 4 (the one the lean kernel leaves its crowded workgroups to)"""
+        self._check(self.lib.sx_ctx_set_flag(self.h, 17, 0 if on else 1), "sx_ctx_set_flag")
+
     def set_small_direct_max(self, suffixes):
         """SX_FLAG_SMALL_DIRECT_MAX: texts of at most 16 symbols and at most this many suffixes are sorted directly
         (0: never; negative: default)"""

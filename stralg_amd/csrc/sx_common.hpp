@@ -83,6 +83,7 @@ struct sx_ctx {
     int induce_no_hoist = 0;  // SX_FLAG_INDUCE_NO_HOIST
     int text_keys_off = 0;    // SX_FLAG_TEXT_KEYS_OFF
     int long_subbuckets_off = 0; // SX_FLAG_LONG_SUBBUCKETS_OFF
+    int local_sort_lean_off = 0; // SX_FLAG_LOCAL_SORT_LEAN_OFF
     int64_t small_direct_max = -1; // SX_FLAG_SMALL_DIRECT_MAX; -1 = the default
     int copy_text_first = 0;  // SX_FLAG_COPY_TEXT_FIRST
     int64_t sample_min = -1;  // SX_FLAG_SAMPLE_MIN; -1 = texts of 2^20 suffixes and more get the look at a sample

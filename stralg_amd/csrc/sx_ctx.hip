@@ -183,6 +183,7 @@ int sx_child_begin(sx_ctx *ctx, sx_ctx **out)
     c->induce_no_hoist = ctx->induce_no_hoist;
     c->text_keys_off = ctx->text_keys_off;
     c->long_subbuckets_off = ctx->long_subbuckets_off;
+    c->local_sort_lean_off = ctx->local_sort_lean_off;
     c->small_direct_max = ctx->small_direct_max;
     c->copy_text_first = ctx->copy_text_first;
     c->recurse_min = ctx->recurse_min;
@@ -353,6 +354,10 @@ int sx_ctx_set_flag(sx_ctx *ctx, int flag, int value)
     }
     if (flag == SX_FLAG_LONG_SUBBUCKETS_OFF) {
         ctx->long_subbuckets_off = value ? 1 : 0;
+        return 0;
+    }
+    if (flag == SX_FLAG_LOCAL_SORT_LEAN_OFF) {
+        ctx->local_sort_lean_off = value ? 1 : 0;
         return 0;
     }
     if (flag == SX_FLAG_INDUCE_NO_HOIST) {

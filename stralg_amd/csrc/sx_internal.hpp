@@ -120,7 +120,9 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
                   uint32_t *long_list = nullptr /* 3 * long_cap words: sub-buckets too long for a workgroup are listed (d_total_and_fail[2]
                                                    <- their number) instead of failing the sort; sx_long_subbuckets finishes them */,
                   uint32_t long_cap = 0, uint32_t res[3] = nullptr /* d_total_and_fail[0 .. 3), read back (round 5: the host looks at bit 2 of
-                                                                     [1] -- workgroups that asked for the stable-pass kernel -- anyway) */);
+                                                                     [1] -- workgroups that asked for the stable-pass kernel -- anyway) */,
+                  bool crowded_expected = false /* skewed symbol counts: many workgroups would be left to the stable-pass kernel, which then
+                                                   takes all of them at once */);
 int sx_long_subbuckets(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t m, int kbits, int top_bits, uint32_t n_long,
                        uint32_t *long_list, uint32_t long_cap, uint64_t *ck_a, uint64_t *ck_b, uint32_t *cv_a, uint32_t *cv_b,
                        uint32_t max_pairs, uint32_t *vout, uint32_t *seedw, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,

@@ -21,6 +21,8 @@
 // O(n log n) whatever the input.  Either way the order is the unique one.
 #include <math.h>
 
+#include <chrono>
+#include <cstdlib>
 #include "sx_common.hpp"
 #include "sx_device.hpp"
 #include "sx_scan.hpp"
@@ -1044,6 +1046,8 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         bool dense4 = SX_DENSE4 && !all_suffixes && base == 5 && ctx->sort_mode != 1 && 2 * C + lenbits <= 60;
         wnd_cfg wcfg;
         int sort_db = 8, top_bits = 0; // top_bits: of the hybrid sort; 0: plain passes over all key bits
+        bool ls_skewed = false;        // the hybrid sort was chosen by the mean sub-bucket of skewed symbol counts (a genome's: repeat
+                                       // families crowd the LDS step's bins, whose workgroups the kernel of rounds 3 and 4 takes at once)
         uint8_t *dig0 = nullptr;
         for (;;) {
         {
@@ -1127,7 +1131,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                 // the ties.  (A text whose long sub-buckets hold a quarter of the pairs falls back as before.)
                 for (int tb = SX_DENSE4_TOP; tb <= 24 && !dense_fits && long_list != nullptr; tb += 2) {
                     const double mean_d = (double)m / pow(eff, (double)tb / 2.0);
-                    if (mean_d <= 256.0 && sx_local_sort_applies(m, kbits, tb)) cand0 = tb, dense_fits = true;
+                    if (mean_d <= 256.0 && sx_local_sort_applies(m, kbits, tb)) cand0 = tb, dense_fits = true, ls_skewed = true;
                 }
             }
             for (int ci = 0; ci < 2 && top_bits == 0; ++ci) {
@@ -1241,7 +1245,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
             uint32_t res[3] = {0, 0, 0};
             SX_TRY(sx_local_sort(ctx, kin, vin, m, kbits, top_bits, vo, embed ? seedw : nullptr, tile_lsrt, tile_lsrt + ls_tiles,
                                  tile_lsrt + 2 * (size_t)ls_tiles, (uint2 *)(in_b ? ka : kb), dig0, apos, ap, head, cap, d_scalar, longest,
-                                 long_list, kLongCap, res));
+                                 long_list, kLongCap, res, ls_skewed));
             bool fits = !(res[1] & 1u);
             ctx->stats.long_subbuckets = 0;
             if (fits && res[2] != 0) {
@@ -1375,7 +1379,15 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                   (const uint64_t *)key_keep, (uint64_t)A3, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
         return 0;
     };
+    const bool trace = getenv("STRALG_AMD_TRACE_REFINE") != nullptr; // (diagnostic: members and time of every refinement round)
     for (int round = 1; A > 0; ++round) {
+        const auto trace_t0 = std::chrono::steady_clock::now();
+        const uint32_t trace_A = A;
+        struct trace_end {
+            bool on; int round; uint32_t a0; const uint32_t &a1; std::chrono::steady_clock::time_point t0;
+            ~trace_end() { if (on) fprintf(stderr, "stralg_amd refine: round %d  %u -> %u tied members  %.3f ms\n", round, a0, a1,
+                                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+        } trace_guard{trace, round, trace_A, A, trace_t0};
         // Few survivors are repeats proper: they get more rounds (each costs little) and, from the third round on,
         // small groups are finished by comparing the suffixes themselves.  Many survivors after four rounds, or any
         // after 32: repetitive text, general path.

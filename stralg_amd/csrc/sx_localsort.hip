@@ -896,7 +896,7 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
                   uint8_t *stage_head, uint32_t *apos, uint32_t *ap, uint8_t *ahead, uint32_t cap,
                   uint32_t *d_total_and_fail /* [0] <- tied members, [1] <- bit 0: a sub-bucket did not fit, bit 1: stable passes were used,
                                                 [2] <- long sub-buckets listed */,
-                  uint32_t longest_expected, uint32_t *long_list, uint32_t long_cap, uint32_t res[3])
+                  uint32_t longest_expected, uint32_t *long_list, uint32_t long_cap, uint32_t res[3], bool crowded_expected)
 {
     // The span: a workgroup's costs that do not depend on its pairs (zeroing and scanning 8192 counters, the barriers) are
     // spread over more pairs the longer it is (1 GiB of DNA, dense keys: span 5120 2.79 ms, 5632 2.60, 5888 2.52), but a
@@ -912,16 +912,17 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
     uint32_t res_local[3];
     if (!res) res = res_local;
     SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, 2 * sizeof(uint32_t), ctx->stream));
-#ifdef SX_LS_LEAN_OFF // (A/B: rounds 3 and 4's kernel for every workgroup)
-    SX_CHECK(hipMemsetAsync(tile_start, 0xFF, (size_t)tiles * sizeof(uint32_t), ctx->stream));
-    sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_redo_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
-              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
-              d_total_and_fail + 2, long_list ? long_cap : 0u);
-#else
-    sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kL2Threads), kin, vin, m, L,
-              (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
-              d_total_and_fail + 2, long_list ? long_cap : 0u);
-#endif
+    // (genome-like 1 GiB: the lean kernel + the workgroups it leaves 4.44 ms, the other kernel for all 4.11; uniform DNA 1.86 against 2.59)
+    if (ctx->local_sort_lean_off || crowded_expected) { // SX_FLAG_LOCAL_SORT_LEAN_OFF (tests, A/B), skewed symbol counts: rounds 3 and 4's kernel for every workgroup
+        SX_CHECK(hipMemsetAsync(tile_start, 0xFF, (size_t)tiles * sizeof(uint32_t), ctx->stream));
+        sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_redo_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
+                  (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
+                  d_total_and_fail + 2, long_list ? long_cap : 0u);
+    } else {
+        sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_kernel, dim3(tiles), dim3(kL2Threads), kin, vin, m, L,
+                  (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
+                  d_total_and_fail + 2, long_list ? long_cap : 0u);
+    }
 #ifdef SX_LS_PROBE
     {
         unsigned long long h[16];

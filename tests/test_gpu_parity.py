@@ -222,8 +222,27 @@ def test_hybrid_prefix_sort(gpu_ctx):
             x[300 + 4000 * i:360 + 4000 * i] = x[100:160]
         gpu_ctx.set_prefix_symbols(17)
         gpu_ctx.set_sort_mode(2)
+        want = oracle.sa_is(x, 5)
+        # (round 5: the lean kernel leaves a workgroup with a crowded bin to the kernel of rounds 3 and 4, whose stable passes
+        #  set bit 1; SX_FLAG_LOCAL_SORT_LEAN_OFF: that kernel for every workgroup)
+        for lean in (True, False):
+            gpu_ctx.set_local_sort_lean(lean)
+            sa = gpu_ctx.sa_build(x, 5)
+            assert gpu_ctx.last_stats()["sort_local"] & 7 == 3, (lean, gpu_ctx.last_stats())
+            assert (sa == want).all(), lean
+        gpu_ctx.set_local_sort_lean(True)
+        # 60 variants of the piece that differ in the key's last three symbols, 30 copies each: crowded bins with many values
+        x = synth(1 << 20, 5, 34)
+        rng2 = np.random.default_rng(5)
+        variants = rng2.choice(64, size=60, replace=False)
+        at = 300
+        for v in variants.tolist():
+            piece = x[100:160].copy()
+            for _ in range(30):
+                x[at:at + 60] = piece
+                x[at + 14:at + 17] = np.array([1 + (v >> 4 & 3), 1 + (v >> 2 & 3), 1 + (v & 3)], np.uint8)
+                at += 500
         sa = gpu_ctx.sa_build(x, 5)
-        assert gpu_ctx.last_stats()["sort_local"] & 7 == 3, gpu_ctx.last_stats()
         assert (sa == oracle.sa_is(x, 5)).all()
         # one 14-symbol prefix in front of tens of thousands of LMS suffixes
         unit = np.array([1, 3, 2, 4, 4, 2, 3, 1, 1, 3, 2, 4, 2, 1], np.uint8)
