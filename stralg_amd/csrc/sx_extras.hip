@@ -46,6 +46,7 @@ constexpr int kInvThreads = 512, kInvItems = 16, kInvTile = kInvThreads * kInvIt
 #endif
 constexpr uint32_t kInvWindowBits = SX_INV_WINDOW_BITS, kInvMaxParts = 8192; // N <= 2^32: at most 8192 partitions of 2^19
 __global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ values /* or null: the index */,
+                                                                         uint32_t values_back /* 1: entry i carries values[i - 1] (entry 0: 0xFFFFFFFF) */,
                                                                          uint64_t N, uint32_t nparts, uint32_t wbits,
                                                                          uint32_t *__restrict__ cursor /* entries dealt into each partition so far */,
                                                                          uint2 *__restrict__ pairs, uint32_t *__restrict__ bad)
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kInvThreads) void inverse_partition_kernel(const ui
                 const uint32_t base = cnt[p[k] >> wbits];
                 if (base != 0xFFFFFFFFu) {
                     uint2 e;
-                    e.x = p[k], e.y = values ? values[i] : (uint32_t)i;
+                    e.x = p[k], e.y = values ? (values_back ? (i ? values[i - 1] : 0xFFFFFFFFu) : values[i]) : (uint32_t)i;
                     pairs[(uint64_t)base + r[k]] = e;
                 }
             }
@@ -327,6 +328,87 @@ __global__ __launch_bounds__(kBlock) void lcp_kernel(const uint8_t *__restrict__
     }
 }
 
+// ---- round 5: LCP through Phi -------------------------------------------------------------------------------------
+// Kasai's loop above pays three random accesses a position: sa[inv[i] - 1], the text behind it, lcp[inv[i]] (24 ms at 2^28,
+// the chip's random-sector rate).  Two of them are permutations and can be streamed: phi[sa[j]] = sa[j - 1] (the suffix in
+// front of every text position's own, Karkkainen / Manzini / Puglisi's Phi array) is one permutation scatter -- the
+// inverse's three passes with sa[j - 1] as the value --, the loop then reads phi[i] and writes plcp[i] in text order (one
+// random access left: the text behind phi[i]), and lcp[inv[i]] = plcp[i] is a second scatter.  Same chunks, same samples,
+// same invariant (plcp[i + 1] >= plcp[i] - 1).
+constexpr uint32_t kNoPhi = 0xFFFFFFFFu;
+__global__ __launch_bounds__(kBlock) void plcp_samples_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ phi, uint64_t chunks,
+                                                              uint64_t first, uint64_t step, uint64_t back, uint32_t *__restrict__ plcp)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t c = first + k * step;
+    if (c >= chunks) return;
+    const uint64_t i = c * kLcpChunk;
+    const uint32_t pred = phi[i];
+    uint32_t l = 0;
+    if (pred != kNoPhi) {
+        if (back) {
+            const uint64_t known = plcp[c - back], dist = back * kLcpChunk;
+            l = known > dist ? (uint32_t)(known - dist) : 0u;
+        }
+        l = extend_match(T, (uint32_t)i, pred, l);
+    }
+    plcp[c] = l;
+}
+
+// First a look at the first kPlcpHead symbols behind every position and its predecessor, all positions at once (nothing
+// depends on the position before: every load of a wave is in flight together, the random-sector rate instead of a chain of
+// dependent misses per thread -- 13 ms of the Phi form's 20 at 2^28 were that chain); min(common prefix, kPlcpHead) goes to
+// plcp[i].  On ordinary text that IS the value nearly everywhere; the chunked loop below then walks only the positions that
+// matched to the end of the head, carrying Kasai's invariant as before.
+constexpr uint32_t kPlcpHead = 32;
+__global__ __launch_bounds__(kBlock) void plcp_head_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ phi, uint64_t N,
+                                                           uint32_t *__restrict__ plcp)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t pred = phi[i];
+    uint32_t l = 0;
+    if (pred != kNoPhi) {
+        uint64_t a[4], b[4];
+        load_bytes32(T, i, a);
+        load_bytes32(T, (uint64_t)pred, b);
+        l = kPlcpHead;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const uint64_t x = a[k] ^ b[k];
+            if (x) l = 8u * (uint32_t)k + (uint32_t)((__ffsll((unsigned long long)x) - 1) >> 3);
+        }
+    }
+    plcp[i] = l;
+}
+
+__global__ __launch_bounds__(kBlock) void plcp_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ phi, uint64_t N,
+                                                      const uint32_t *__restrict__ plcp_samples, uint32_t *__restrict__ plcp)
+{
+    const uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t i0 = chunk * kLcpChunk;
+    if (i0 >= N) return;
+    const uint64_t i1 = i0 + kLcpChunk < N ? i0 + kLcpChunk : N;
+    uint32_t carry = plcp_samples[chunk]; // a lower bound of the value at the next position (the chunk's first: the value itself)
+    constexpr int kAhead = 8;
+    for (uint64_t b = i0; b < i1; b += kAhead) {
+        uint32_t kk[kAhead], head[kAhead];
+#pragma unroll
+        for (int e = 0; e < kAhead; ++e) kk[e] = b + e < i1 ? phi[b + e] : kNoPhi, head[e] = b + e < i1 ? plcp[b + e] : 0u;
+#pragma unroll
+        for (int e = 0; e < kAhead; ++e) {
+            const uint64_t i = b + e;
+            if (i >= i1) break;
+            uint32_t l = head[e]; // (the sentinel suffix has no predecessor: the head kernel left 0, suffix_array.c:74-75)
+            if (l >= kPlcpHead) { // the head matched to its end: on from there, or from what the position before promises
+                l = extend_match(T, (uint32_t)i, kk[e], carry > kPlcpHead ? carry : kPlcpHead);
+                plcp[i] = l;
+            }
+            carry = l > 0 ? l - 1 : 0;
+        }
+    }
+}
+
 // One thread per pattern.  Every step is a dependent look-up in a table of gigabytes: the first eight steps touch
 // at most 4^8 rows (1.3 MB for DNA: L2-resident whatever the order of the patterns), from step 14 on (256 Mi
 // positions) every step is a random 64-byte sector.  10^7 patterns x 30 symbols: 6.9 ms = 87 G look-ups/s = 5.5 TB/s
@@ -402,7 +484,7 @@ int sx_scatter_permutation(sx_ctx *ctx, const uint32_t *targets, const uint32_t 
     SX_CHECK(hipMemsetAsync(cursor, 0, (size_t)nparts * 4, ctx->stream));
     uint32_t grid = sx_div_up(N, kInvTile);
     if (grid > 4096) grid = 4096;
-    sx_launch(ctx, kclass, N * (values ? 16 : 12), inverse_partition_kernel, dim3(grid), dim3(kInvThreads), targets, values, N, nparts, wbits,
+    sx_launch(ctx, kclass, N * (values ? 16 : 12), inverse_partition_kernel, dim3(grid), dim3(kInvThreads), targets, values, 0u, N, nparts, wbits,
               cursor, pairs, bad);
     const uint64_t chunks = (N + (uint64_t)kBlock * 8 - 1) / ((uint64_t)kBlock * 8);
     sx_launch(ctx, kclass, N * 12, inverse_apply_kernel, dim3((uint32_t)(((chunks + 7) / 8) * 8)), dim3(kBlock), (const uint2 *)pairs, N, out,
@@ -410,7 +492,19 @@ int sx_scatter_permutation(sx_ctx *ctx, const uint32_t *targets, const uint32_t 
     return 0;
 }
 
-static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv)
+// whether an array of N entries takes the three-pass form (the fine windows a tile's pairs can fall into must fit the refine
+// kernel's counters), and the bits of its coarse windows
+static bool permute_three_passes(uint64_t N, uint32_t &wbits)
+{
+    wbits = kInvFineBits + 6u;
+    while (((N + (1ull << wbits) - 1) >> wbits) > 128u) ++wbits;
+    return sx_scatter_permutation_applies(N) && wbits >= kInvFineBits &&
+           ((((uint64_t)kInvTile >> wbits) + 2) << (wbits - kInvFineBits)) <= kInvFineMax;
+}
+
+// out[targets[i]] = i (values null), values[i], or values[i - 1] (values_back; entry 0: 0xFFFFFFFF) for a permutation `targets`
+// of [0, N); an array that is no permutation is reported (SX_E_ARG) without a store leaving `out`
+static int permute_dev(sx_ctx *ctx, const uint32_t *d_sa, const uint32_t *values, uint32_t values_back, uint64_t N, uint32_t *d_inv)
 {
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, 4096));
     uint32_t *bad = (uint32_t *)ctx->slab[SX_SLAB_BWT].p;
@@ -420,8 +514,8 @@ static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *
         // chosen so that BOTH dealing passes write long runs: at most 128 of them (a tile of 8192 entries leaves 64-pair,
         // 512-byte runs; with the two-pass form's 512 windows of 2^19 targets the first pass wrote 128-byte runs at
         // arbitrary offsets and took 3.1 of the inverse's 4.5 ms for a third of its traffic), each of at least 64 fine ones
-        uint32_t wbits = kInvFineBits + 6u;
-        while (((N + (1ull << wbits) - 1) >> wbits) > 128u) ++wbits;
+        uint32_t wbits = 0;
+        const bool three = permute_three_passes(N, wbits);
         const uint32_t nparts = (uint32_t)((N + (1ull << wbits) - 1) >> wbits);
         const uint64_t nfine = (N + (1ull << kInvFineBits) - 1) >> kInvFineBits;
         const size_t pairs_b = (N * sizeof(uint2) + 255) & ~(size_t)255, cur_b = ((size_t)kInvMaxParts * 4 + 255) & ~(size_t)255,
@@ -431,22 +525,24 @@ static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *
         uint32_t *cursor = (uint32_t *)base, *fine_cursor = (uint32_t *)(base + cur_b);
         uint2 *pairs = (uint2 *)(base + cur_b + fine_b), *pairs2 = (uint2 *)(base + cur_b + fine_b + pairs_b);
         // (the fine windows a tile's pairs can fall into must fit the refine kernel's counters)
-        if (wbits >= kInvFineBits && ((((uint64_t)kInvTile >> wbits) + 2) << (wbits - kInvFineBits)) <= kInvFineMax) {
+        if (three) {
             SX_CHECK(hipMemsetAsync(cursor, 0, (size_t)nparts * 4, ctx->stream));
             SX_CHECK(hipMemsetAsync(fine_cursor, 0, (size_t)nfine * 4, ctx->stream));
             uint32_t grid = sx_div_up(N, kInvTile);
             if (grid > 4096) grid = 4096;
-            sx_launch(ctx, SX_KC_LCP, N * 12, inverse_partition_kernel, dim3(grid), dim3(kInvThreads), d_sa, (const uint32_t *)nullptr, N, nparts,
-                      wbits, cursor, pairs, bad);
+            sx_launch(ctx, SX_KC_LCP, N * (values ? 16 : 12), inverse_partition_kernel, dim3(grid), dim3(kInvThreads), d_sa, values, values_back, N,
+                      nparts, wbits, cursor, pairs, bad);
             sx_launch(ctx, SX_KC_LCP, N * 16, inverse_refine_kernel, dim3(grid), dim3(kInvThreads), (const uint2 *)pairs, N, wbits, fine_cursor,
                       pairs2, bad);
             uint32_t wgrid = (uint32_t)(nfine < 65536 ? nfine : 65536);
             sx_launch(ctx, SX_KC_LCP, N * 12, inverse_window_kernel, dim3(wgrid), dim3(kInvWinThreads), (const uint2 *)pairs2, N, d_inv,
                       (const uint32_t *)bad);
         } else {
-            SX_TRY(sx_scatter_permutation(ctx, d_sa, nullptr, N, d_inv, pairs, cursor, bad, SX_KC_LCP));
+            if (values_back) return sx_fail_msg(ctx, SX_E_INTERNAL, "permute: the two-pass form takes no shifted values");
+            SX_TRY(sx_scatter_permutation(ctx, d_sa, values, N, d_inv, pairs, cursor, bad, SX_KC_LCP));
         }
     } else {
+        if (values) return sx_fail_msg(ctx, SX_E_INTERNAL, "permute: short arrays take the plain kernel");
         sx_launch(ctx, SX_KC_LCP, N * 8, inverse_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), d_sa, N, d_inv, bad);
     }
     uint32_t h_bad = 0;
@@ -455,33 +551,56 @@ static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *
     return 0;
 }
 
+static int inverse_dev(sx_ctx *ctx, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv) { return permute_dev(ctx, d_sa, nullptr, 0u, N, d_inv); }
+
 static int lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint64_t N, uint32_t *d_inv_opt,
                    uint32_t *d_lcp)
 {
     const uint64_t n = N - 1;
-    const size_t text_b = (n + 128 + 255) & ~(size_t)255;
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, text_b + (d_inv_opt ? 0 : N * 4 + 256) + 256));
+    const size_t text_b = (n + 128 + 255) & ~(size_t)255, arr_b = ((size_t)N * 4 + 255) & ~(size_t)255;
+    uint32_t wbits_unused = 0;
+    // Phi form (round 5): arrays that take the three-pass scatter, up to 2^31 entries (its scratch: two more arrays of N words)
+    const bool by_phi = permute_three_passes(N, wbits_unused) && N <= (1ull << 31);
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_N, text_b + (d_inv_opt ? 0 : arr_b) + (by_phi ? 2 * arr_b : 0) + 256));
     uint8_t *T = (uint8_t *)ctx->slab[SX_SLAB_N].p; // padded copy: text[n] = 0 and zeros behind it
     uint32_t *inv = d_inv_opt ? d_inv_opt : (uint32_t *)((char *)ctx->slab[SX_SLAB_N].p + text_b);
+    uint32_t *phi = (uint32_t *)((char *)ctx->slab[SX_SLAB_N].p + text_b + (d_inv_opt ? 0 : arr_b)), *plcp_full = (uint32_t *)((char *)phi + arr_b);
     if (n) SX_CHECK(hipMemcpyAsync(T, d_text, n, hipMemcpyDeviceToDevice, ctx->stream));
     SX_CHECK(hipMemsetAsync(T + n, 0, text_b - n, ctx->stream));
     SX_TRY(inverse_dev(ctx, d_sa, N, inv));
+    if (by_phi) SX_TRY(permute_dev(ctx, d_sa, d_sa, 1u, N, phi)); // phi[sa[j]] = sa[j - 1]
     const uint64_t chunks = (N + kLcpChunk - 1) / kLcpChunk;
     // samples: chunk 0 from scratch, then the chunks at odd multiples of S, S halving, each from the sample S to its left
     SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, chunks * 4 + 4096));
     uint32_t *plcp = (uint32_t *)((char *)ctx->slab[SX_SLAB_BWT].p + 4096); // (the first page holds inverse_dev's counter)
-    sx_launch(ctx, SX_KC_LCP, 64, lcp_samples_kernel, dim3(1), dim3(kBlock), (const uint8_t *)T, d_sa, (const uint32_t *)inv, (uint64_t)1,
-              (uint64_t)0, (uint64_t)1, (uint64_t)0, plcp);
+    if (by_phi)
+        sx_launch(ctx, SX_KC_LCP, 64, plcp_samples_kernel, dim3(1), dim3(kBlock), (const uint8_t *)T, (const uint32_t *)phi, (uint64_t)1, (uint64_t)0,
+                  (uint64_t)1, (uint64_t)0, plcp);
+    else
+        sx_launch(ctx, SX_KC_LCP, 64, lcp_samples_kernel, dim3(1), dim3(kBlock), (const uint8_t *)T, d_sa, (const uint32_t *)inv, (uint64_t)1,
+                  (uint64_t)0, (uint64_t)1, (uint64_t)0, plcp);
     uint64_t S = 1;
     while (S * 2 < chunks) S *= 2;
     for (; S >= 1; S /= 2) {
         const uint64_t count = chunks > S ? (chunks - S + 2 * S - 1) / (2 * S) : 0; // chunks S, 3S, 5S, ... below `chunks`
-        if (count)
+        if (!count) continue;
+        if (by_phi)
+            sx_launch(ctx, SX_KC_LCP, count * 80, plcp_samples_kernel, dim3(sx_div_up(count, kBlock)), dim3(kBlock), (const uint8_t *)T,
+                      (const uint32_t *)phi, chunks, S, 2 * S, S, plcp);
+        else
             sx_launch(ctx, SX_KC_LCP, count * 80, lcp_samples_kernel, dim3(sx_div_up(count, kBlock)), dim3(kBlock), (const uint8_t *)T,
                       d_sa, (const uint32_t *)inv, chunks, S, 2 * S, S, plcp);
     }
-    sx_launch(ctx, SX_KC_LCP, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
-              (const uint32_t *)inv, N, (const uint32_t *)plcp, d_lcp);
+    if (by_phi) {
+        sx_launch(ctx, SX_KC_LCP, N * (8 + 64), plcp_head_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), (const uint8_t *)T, (const uint32_t *)phi, N,
+                  plcp_full);
+        sx_launch(ctx, SX_KC_LCP, N * 12, plcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, (const uint32_t *)phi, N,
+                  (const uint32_t *)plcp, plcp_full);
+        SX_TRY(permute_dev(ctx, inv, plcp_full, 0u, N, d_lcp)); // lcp[inv[i]] = plcp[i]
+    } else {
+        sx_launch(ctx, SX_KC_LCP, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
+                  (const uint32_t *)inv, N, (const uint32_t *)plcp, d_lcp);
+    }
     return 0;
 }
 

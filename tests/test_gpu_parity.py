@@ -627,6 +627,13 @@ def test_next_rows_inverse_lcp_search(gpu_ctx, golden):
     y = np.tile(synth(3000, 5, 6), 40)  # repetitive: long common prefixes
     sa = gpu_ctx.sa_build(y, 5)
     assert (gpu_ctx.inverse_lcp(y, sa)[1] == oracle.lcp(y, sa)).all()
+    # from 2^23 entries on the inverse takes three passes and (round 5) the LCP goes through Phi: phi[sa[j]] = sa[j - 1] by a
+    # permutation scatter, PLCP in text order, lcp[inv[i]] = plcp[i] by a second scatter -- random DNA, a text with long repeats
+    # (the samples' invariant over many chunks), and a length that is no multiple of anything
+    for x in (synth((1 << 24) + 12345, 5, 7), np.tile(synth(70_001, 5, 8), 130)):
+        sa = gpu_ctx.sa_build(x, 5)
+        inv, lcp = gpu_ctx.inverse_lcp(x, sa)
+        assert (inv == oracle.inverse(sa)).all() and (lcp == oracle.lcp(x, sa)).all()
 
 
 def test_c_batch_farm(gpu_ctx, golden):

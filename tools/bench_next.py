@@ -24,7 +24,7 @@ print(json.dumps({"row": "inverse (suffix_array.c:53-60)", "N": N, "ms": round(d
 print(json.dumps({"row": "LCP (suffix_array.c:62-85), after the inverse", "N": N, "ms": round((dt - di) * 1e3, 2),
                   "alg_GB": round((12 + 3 * 64) * N / 1e9, 2), "GBps": round((12 + 3 * 64) * N / (dt - di) / 1e9),
                   "frac_of_8TBps": round((12 + 3 * 64) * N / (dt - di) / 8e12, 3),
-                  "note": "three random accesses a position (sa[j-1], the suffix's text, lcp[j]) booked as 64-byte sectors"}))
+                  "note": "algorithmic bytes as Kasai's loop has them: three random accesses a position (sa[j-1], the suffix's text, lcp[j]) booked as 64-byte sectors; round 5 runs it through Phi (two permutation scatters, one random access a position, a parallel first look at 32 symbols)"}))
 ns = 1 << 24
 xs = stralg_amd.synth(ns, sigma, 42); sas = oracle.sa_is(xs, sigma)
 t0 = time.perf_counter(); oracle.lcp(xs, sas); dt = time.perf_counter() - t0
