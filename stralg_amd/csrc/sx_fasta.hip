@@ -28,11 +28,20 @@ __device__ __forceinline__ bool fasta_space(uint32_t c) { return c == ' ' || (c 
 // ---- packing: three passes over tiles of 4096 bytes, 16 bytes per thread in registers ------------------------
 constexpr int kFaPer = 16, kFaTile = kBlock * kFaPer;
 
-// the thread's 16 bytes (zero beyond `end`: position `end` itself is the terminating NUL of the reference's buffer)
-__device__ __forceinline__ void fasta_load16(const uint8_t *__restrict__ file, uint64_t i0, uint64_t end, uint32_t (&b)[kFaPer])
+// the thread's 16 bytes (zero beyond `end`: position `end` itself is the terminating NUL of the reference's buffer).  In two
+// steps, so that a workgroup can ask for the bytes of several tiles before it looks at the first (round 5): fasta_fetch16
+// issues the load where one aligned 16-byte load does (everywhere but at the image's end), fasta_unpack16 spreads the bytes
+// -- or reads them one by one.
+__device__ __forceinline__ bool fasta_fetch16(const uint8_t *__restrict__ file, uint64_t i0, uint64_t end, uint4 &v)
 {
-    if (i0 + kFaPer <= end && ((uintptr_t)(file + i0) & 15u) == 0) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(file + i0);
+    const bool fast = i0 + kFaPer <= end && ((uintptr_t)(file + i0) & 15u) == 0;
+    if (fast) v = *reinterpret_cast<const uint4 *>(file + i0);
+    return fast;
+}
+__device__ __forceinline__ void fasta_unpack16(const uint8_t *__restrict__ file, uint64_t i0, uint64_t end, bool fast, const uint4 &v,
+                                               uint32_t (&b)[kFaPer])
+{
+    if (fast) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < kFaPer; ++k) b[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
@@ -41,6 +50,14 @@ __device__ __forceinline__ void fasta_load16(const uint8_t *__restrict__ file, u
         for (int k = 0; k < kFaPer; ++k) b[k] = i0 + k < end ? (uint32_t)file[i0 + k] : 0u;
     }
 }
+// tiles a workgroup takes, one after the other, all of their loads in flight from the start.  Measured (round 5, 1 GiB image):
+// 1, 2, 4 tiles a workgroup 2.2 ms each, 8: 2.4 -- the two kernels are not waiting for their loads: a tile costs each of its
+// four waves some 600 vector instructions (the walk in both states, five block-wide reductions), 4 KiB per 1200 cycles of a
+// CU = 2.1 TB/s, which is what they run at.  Left at one tile.
+#ifndef SX_FASTA_SUB
+#define SX_FASTA_SUB 1
+#endif
+constexpr int kFaSub = SX_FASTA_SUB;
 
 // (position + 1, kind) of the last '\n' (kind 1: a sequence follows) or '>' (kind 0: a header follows) among the bytes
 __device__ __forceinline__ uint32_t fasta_last_special(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end)
@@ -111,12 +128,23 @@ __device__ __forceinline__ fa_chunk fasta_walk(const uint32_t (&b)[kFaPer], uint
 // the tiles behind it are never used.
 __global__ __launch_bounds__(kBlock) void fasta_scan_kernel(const uint8_t *__restrict__ file, uint64_t end,
                                                             uint32_t *__restrict__ tile_last, uint32_t *__restrict__ tile_cnt /* [3][tiles] */,
-                                                            uint32_t tiles_stride, uint32_t *__restrict__ scal /* [0] first NUL, [2] first newline */)
+                                                            uint32_t tiles_stride, uint32_t *__restrict__ scal /* [0] first NUL, [2] first newline */, uint32_t tiles)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
-    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
+    uint4 raw[kFaSub];
+    bool fast[kFaSub];
+#pragma unroll
+    for (int sub = 0; sub < kFaSub; ++sub) {
+        raw[sub] = {0, 0, 0, 0};
+        fast[sub] = fasta_fetch16(file, (((uint64_t)blockIdx.x * kFaSub + sub) * kBlock + threadIdx.x) * kFaPer, end, raw[sub]);
+    }
+#pragma unroll
+    for (int sub = 0; sub < kFaSub; ++sub) {
+    const uint32_t tile = blockIdx.x * (uint32_t)kFaSub + (uint32_t)sub;
+    if (tile >= tiles) break; // uniform
+    const uint64_t i0 = ((uint64_t)tile * kBlock + threadIdx.x) * kFaPer;
     uint32_t b[kFaPer];
-    fasta_load16(file, i0, end, b);
+    fasta_unpack16(file, i0, end, fast[sub], raw[sub], b);
     uint32_t zero_at = kFaPer, nl_at = kFaPer;
 #pragma unroll
     for (int k = kFaPer - 1; k >= 0; --k) {
@@ -147,10 +175,12 @@ __global__ __launch_bounds__(kBlock) void fasta_scan_kernel(const uint8_t *__res
     const uint32_t s_seq = block_reduce<OpAdd>(known ? 0u : mine, lds);
     const uint32_t s_hdr = block_reduce<OpAdd>(other, lds);
     if (threadIdx.x == 0) {
-        tile_last[blockIdx.x] = tot_last;
-        tile_cnt[blockIdx.x] = s_known;
-        tile_cnt[(uint64_t)tiles_stride + blockIdx.x] = s_seq;
-        tile_cnt[2ull * tiles_stride + blockIdx.x] = s_hdr;
+        tile_last[tile] = tot_last;
+        tile_cnt[tile] = s_known;
+        tile_cnt[(uint64_t)tiles_stride + tile] = s_seq;
+        tile_cnt[2ull * tiles_stride + tile] = s_hdr;
+    }
+    __syncthreads(); // (`lds` is the next tile's)
     }
 }
 
@@ -185,21 +215,33 @@ __global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__re
                                                              const uint32_t *__restrict__ tile_eoff,
                                                              const uint32_t *__restrict__ tile_toff, uint8_t *__restrict__ packed,
                                                              uint32_t *__restrict__ term_out, uint64_t term_cap,
-                                                             uint32_t *__restrict__ scal /* [1] <- malformed; [2] first header end -> [0] its packed position */)
+                                                             uint32_t *__restrict__ scal /* [1] <- malformed; [2] first header end -> [0] its packed position */,
+                                                             uint32_t tiles)
 {
     __shared__ uint32_t lds[kWavesPerBlock];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kFaTile + 48];
-    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * kFaPer;
+    uint4 raw[kFaSub];
+    bool fast[kFaSub];
+#pragma unroll
+    for (int sub = 0; sub < kFaSub; ++sub) {
+        raw[sub] = {0, 0, 0, 0};
+        fast[sub] = fasta_fetch16(file, (((uint64_t)blockIdx.x * kFaSub + sub) * kBlock + threadIdx.x) * kFaPer, end, raw[sub]);
+    }
+#pragma unroll
+    for (int sub = 0; sub < kFaSub; ++sub) {
+    const uint32_t tile = blockIdx.x * (uint32_t)kFaSub + (uint32_t)sub;
+    if (tile >= tiles) break; // uniform
+    const uint64_t i0 = ((uint64_t)tile * kBlock + threadIdx.x) * kFaPer;
     uint32_t b[kFaPer];
-    fasta_load16(file, i0, end, b);
-    const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[blockIdx.x], lds);
+    fasta_unpack16(file, i0, end, fast[sub], raw[sub], b);
+    const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[tile], lds);
     const fa_chunk c = fasta_walk(b, i0, end, in_seq);
     if (c.eof_in_name) atomicOr(&scal[1], 1u);
     uint32_t tot;
     const uint32_t ex = block_exclusive_scan<OpAdd>((uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16), lds, tot);
-    const uint32_t eoff = tile_eoff[blockIdx.x];
+    const uint32_t eoff = tile_eoff[tile];
     const uint32_t sh = (uint32_t)((uintptr_t)(packed + eoff) & 15u); // the tile's first byte inside its 16-byte piece
-    uint32_t at = sh + (ex & 0xFFFFu), out = eoff + (ex & 0xFFFFu), tq = tile_toff[blockIdx.x] + (ex >> 16);
+    uint32_t at = sh + (ex & 0xFFFFu), out = eoff + (ex & 0xFFFFu), tq = tile_toff[tile] + (ex >> 16);
     const uint32_t first_end = scal[2];
 #pragma unroll
     for (int k = 0; k < kFaPer; ++k) {
@@ -225,6 +267,8 @@ __global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__re
         } else {
             for (uint32_t e = lo < sh ? sh : lo; e < hi && e < last; ++e) dst[e] = stage[e];
         }
+    }
+    __syncthreads(); // (`stage` and `lds` are the next tile's)
     }
 }
 
@@ -330,14 +374,14 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
     uint32_t first_nul = 0xFFFFFFFFu;
     const uint32_t tiles_file = sx_div_up(file_len ? file_len : 1, kFaTile);
     if (file_len) {
-        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_scan_kernel, dim3(tiles_file), dim3(kBlock), d_file, file_len, tile_last, tile_cnt,
-                  tiles_max, scal);
+        sx_launch(ctx, SX_KC_FASTA, file_len, fasta_scan_kernel, dim3(sx_div_up(tiles_file, kFaSub)), dim3(kBlock), d_file, file_len, tile_last,
+                  tile_cnt, tiles_max, scal, tiles_file);
         SX_TRY(sx_readback(ctx, scal, 1, &first_nul));
     }
     const uint64_t end = first_nul < file_len ? first_nul : file_len;
     const uint64_t span = end + 1; // with the terminating NUL of the reference's buffer
     const uint32_t tiles = sx_div_up(span, kFaTile);
-    const dim3 grid(tiles), block(kBlock);
+    const dim3 grid(sx_div_up(tiles, kFaSub)), block(kBlock);
     if (!file_len || tiles > tiles_file) {
         // the span's last tile lies behind the image: it holds the terminator of the reference's buffer only -- a sequence's
         // terminator when the tile is entered in sequence state, nothing to emit in a header (MALFORMED, found by pass 2)
@@ -354,7 +398,7 @@ int sx_fasta_pack_dev(sx_ctx *ctx, const uint8_t *d_file, uint64_t file_len, uin
     SX_TRY((device_scan<OpAdd>(ctx, tiles, InFaTileCount{tile_cnt, tile_carry, tiles_max, 0u}, OutExclusive{tile_eoff}, scal + 3, SX_KC_FASTA, 0)));
     SX_TRY((device_scan<OpAdd>(ctx, tiles, InFaTileCount{tile_cnt, tile_carry, tiles_max, 16u}, OutExclusive{tile_toff}, scal + 4, SX_KC_FASTA, 0)));
     sx_launch(ctx, SX_KC_FASTA, span * 2, fasta_write_kernel, grid, block, d_file, end, (const uint32_t *)tile_carry,
-              (const uint32_t *)tile_eoff, (const uint32_t *)tile_toff, d_packed_out, d_term_out, d_term_out ? term_cap : 0, scal);
+              (const uint32_t *)tile_eoff, (const uint32_t *)tile_toff, d_packed_out, d_term_out, d_term_out ? term_cap : 0, scal, tiles);
     uint32_t h[5];
     SX_TRY(sx_readback(ctx, scal, 5, h));
     *packed_len_out = h[3];
