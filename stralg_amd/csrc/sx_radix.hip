@@ -36,6 +36,9 @@ namespace sx {
 #define SX_RADIX_ITEMS 8
 #endif
 constexpr int kRadixItems = SX_RADIX_ITEMS;
+#ifndef SX_LMS_RANK_INORDER
+#define SX_LMS_RANK_INORDER 0 // 1: the keyed first passes rank their pairs in order inside a wave too (rounds 1 - 4; A/B)
+#endif
 #ifndef SX_HIST_GRID
 #define SX_HIST_GRID 8192u // (workgroups of the digit histogram; one per tile: 0.435 ms for the three passes of 1 GiB of DNA, this: 0.40)
 #endif
@@ -388,7 +391,9 @@ __device__ __forceinline__ void radix_scatter_tile(const sx_textkey &tk, const u
     for (int k = 0; k < kRadixItems; ++k) {
         const uint64_t i = wave0 + (uint64_t)k * kWave + lane;
         const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-        lpos[k] = wave_rank_inorder<DB, FULL>(d, FULL || i < n, wcount + w * ND) | (d << 16);
+        // (TEXT: the first pass of its sort -- pairs of one digit may leave a wave in any order, see lms_scatter_row)
+        if (TEXT && !SX_LMS_RANK_INORDER) lpos[k] = ((FULL || i < n) ? atomicAdd(&wcount[w * ND + d], 1u) : 0u) | (d << 16);
+        else lpos[k] = wave_rank_inorder<DB, FULL>(d, FULL || i < n, wcount + w * ND) | (d << 16);
     }
     __syncthreads();
     {
@@ -786,11 +791,16 @@ __device__ __forceinline__ bool lms_scatter_row(const sx_lmskey &lk, const lms_s
     if (cnt > (uint32_t)kRadixTile) return false; // uniform: a whole block with more LMS suffixes than a radix tile holds
     const uint32_t wave0 = (uint32_t)w * (kWave * kRadixItems);
     uint32_t lpos[kRadixItems]; // [12:0] rank within (wave, digit), then slot in the tile's digit order; [31:16] digit
+    // This is the sort's FIRST pass: nothing it is handed has an order that a later pass relies on, so pairs of one digit may
+    // leave a wave in any order (later passes are stable with respect to THIS pass's output; equal keys are ties whatever
+    // their order) -- a pair's rank within (wave, digit) is the counter's value at its atomic add, one LDS operation where the
+    // in-order ranking costs some fifty vector instructions a pair (round 5: SX_LMS_RANK_INORDER=1 keeps those, A/B).
 #pragma unroll
     for (int k = 0; k < kRadixItems; ++k) {
         const uint32_t i = wave0 + (uint32_t)k * kWave + (uint32_t)lane;
         const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-        lpos[k] = wave_rank_inorder<8, false>(d, i < cnt, wcount + w * ND) | (d << 16);
+        if (SX_LMS_RANK_INORDER) lpos[k] = wave_rank_inorder<8, false>(d, i < cnt, wcount + w * ND) | (d << 16);
+        else lpos[k] = (i < cnt ? atomicAdd(&wcount[w * ND + d], 1u) : 0u) | (d << 16);
     }
     __syncthreads();
     {
