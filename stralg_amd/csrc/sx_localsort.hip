@@ -682,48 +682,8 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     LS_PROBE(5);
     // ---- out: positions and windows to their places --------------------------------------------------------------------------
     const uint64_t gs = g0 + s;
-#ifndef SX_LS_STAGE_OUT
-#define SX_LS_STAGE_OUT 1
-#endif
-#if SX_LS_STAGE_OUT
-    // through LDS, so that the workgroup's range of each array leaves as whole 16-byte pieces in order (round 5: straight
-    // from the registers every wave's 64 four-byte stores landed in a handful of lines, and this phase was a third of the kernel)
-    const uint32_t n_own = e - s;
-    auto copy_out = [&](uint32_t *__restrict__ dst) { // R[0 .. n_own) -> dst[gs ...): the unaligned ends by words, the rest by 16 bytes
-        const uint32_t head = (uint32_t)((4u - (uint32_t)(gs & 3u)) & 3u) < n_own ? (uint32_t)((4u - (uint32_t)(gs & 3u)) & 3u) : n_own;
-        if ((uint32_t)t < head) dst[gs + (uint32_t)t] = R[t];
-        const uint32_t quads = (n_own - head) / 4u;
-        for (uint32_t q = (uint32_t)t; q < quads; q += kL2Threads) {
-            uint4 v;
-            v.x = R[head + 4u * q], v.y = R[head + 4u * q + 1u], v.z = R[head + 4u * q + 2u], v.w = R[head + 4u * q + 3u];
-            *reinterpret_cast<uint4 *>(dst + gs + head + 4u * q) = v;
-        }
-        const uint32_t done = head + 4u * quads;
-        if (done + (uint32_t)t < n_own) dst[gs + done + (uint32_t)t] = R[done + (uint32_t)t];
-    };
-    __syncthreads(); // (every wave has read the sort fields it needs: R is free)
-    LS_PROBE(6);
-    if (seedw) { // (uniform) the windows first: the positions stay in R for the list of tied members below
-#pragma unroll
-        for (int k = 0; k < kL2Items; ++k)
-            if ((own >> k) & 1u) R[sf[k] >> 16] = pay[k];
-        __syncthreads();
-        copy_out(seedw);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < kL2Items; ++k)
-        if ((own >> k) & 1u) {
-            const uint32_t fin = sf[k] >> 16;
-            R[fin] = val[k];
-            if ((tied >> k) & 1u) {
-                atomicOr(&tiedb[fin >> 5], 1u << (fin & 31u));
-                if (!((nothead >> k) & 1u)) atomicOr(&headb[fin >> 5], 1u << (fin & 31u));
-            }
-        }
-    __syncthreads();
-    copy_out(vout);
-#else
+    // (Measured and dropped: both arrays staged through LDS and stored as whole 16-byte pieces in order -- 2.04 against 1.84 ms;
+    //  the positions' loads issued before the counting instead of before the placing -- 2.15: a spill, and the counting waits.)
 #pragma unroll
     for (int k = 0; k < kL2Items; ++k)
         if ((own >> k) & 1u) {
@@ -742,7 +702,6 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
             if (!((nothead >> k) & 1u)) atomicOr(&headb[fin >> 5], 1u << (fin & 31u));
         }
     __syncthreads();
-#endif
     if (w == 0) { // tied members before each word: one wave scans the kLsWords word counts
         uint32_t run = 0;
         for (int c0 = 0; c0 < kLsWords; c0 += kWave) {
