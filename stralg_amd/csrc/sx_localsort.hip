@@ -32,10 +32,6 @@ constexpr int kLsThreads = 512, kLsWaves = kLsThreads / kWave, kLsItems = 12;
 constexpr int kLsCap = kLsThreads * kLsItems; // pairs a workgroup can hold: 6144 (72 KiB of LDS, two workgroups a CU)
 // (span 3584: 4.10 ms, 4096: 3.88, 4608: 3.64, 5120: 3.40 at 1 GiB of DNA: the per-workgroup costs -- zeroing and
 // scanning the 8192 counters -- are spread over more pairs; what is left of the reach bounds the sub-bucket that fits)
-#ifndef SX_LS_SPAN
-#define SX_LS_SPAN 5120
-#endif
-constexpr int kLsSpan = SX_LS_SPAN;           // a workgroup owns the sub-buckets that start in its span of the array
 constexpr int kLsWords = kLsCap / 32;
 #ifndef SX_LS_BINS
 #define SX_LS_BINS 8192
@@ -448,9 +444,19 @@ __device__ unsigned long long sx_ls_probe[16];
 #ifndef SX_LS2_THREADS
 #define SX_LS2_THREADS 1024
 #endif
-constexpr int kL2Threads = SX_LS2_THREADS, kL2Waves = kL2Threads / kWave, kL2Items = kLsCap / kL2Threads, kL2PerWave = kWave * kL2Items;
-constexpr int kL2MinWaves = kL2Threads >= 1024 ? 8 : 4; // (waves a SIMD the register budget is cut for)
-static_assert(kL2Threads * kL2Items == kLsCap && kLsBins / 2 % kL2Threads == 0, "the lean kernel's shape");
+#ifndef SX_LS2_CAP
+#define SX_LS2_CAP 6144 // pairs in a workgroup's reach (A/B: 3072 with 512 threads and 4096 bins -- four workgroups a CU)
+#endif
+#ifndef SX_LS2_BINS
+#define SX_LS2_BINS SX_LS_BINS
+#endif
+constexpr int kL2Cap = SX_LS2_CAP, kL2Words = kL2Cap / 32, kL2Bins = SX_LS2_BINS;
+constexpr int kL2Threads = SX_LS2_THREADS, kL2Waves = kL2Threads / kWave, kL2Items = kL2Cap / kL2Threads, kL2PerWave = kWave * kL2Items;
+#ifndef SX_LS2_MINWAVES
+#define SX_LS2_MINWAVES (SX_LS2_THREADS >= 1024 ? 8 : 4)
+#endif
+constexpr int kL2MinWaves = SX_LS2_MINWAVES; // (waves a SIMD the register budget is cut for)
+static_assert(kL2Threads * kL2Items == kL2Cap && kL2Bins / 2 % kL2Threads == 0 && kL2Cap <= kLsCap, "the lean kernel's shape");
 __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
@@ -458,14 +464,14 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     uint32_t *__restrict__ fail, uint32_t span, uint32_t *__restrict__ long_list /* or null */, uint32_t *__restrict__ long_count,
     uint32_t long_cap)
 {
-    __shared__ uint32_t cw[kLsBins / 2 + 2];  // packed 16-bit counters: counts, then first slots, then (after the drops) ends
-    __shared__ uint32_t R[kLsCap];            // sort fields in bin order; then the positions of tied pairs at their final slots
-    __shared__ uint32_t tiedb[kLsWords], headb[kLsWords], tpre[kLsWords];
+    __shared__ uint32_t cw[kL2Bins / 2 + 2];  // packed 16-bit counters: counts, then first slots, then (after the drops) ends
+    __shared__ uint32_t R[kL2Cap];            // sort fields in bin order; then the positions of tied pairs at their final slots
+    __shared__ uint32_t tiedb[kL2Words], headb[kL2Words], tpre[kL2Words];
     __shared__ uint32_t s_first, s_end, s_last, s_max, s_scan[kL2Waves], s_starts[kL2Waves];
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const uint64_t g0 = (uint64_t)blockIdx.x * span;
     const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
-    const uint32_t avail = m - g0 < (uint64_t)kLsCap ? (uint32_t)(m - g0) : (uint32_t)kLsCap; // pairs in reach
+    const uint32_t avail = m - g0 < (uint64_t)kL2Cap ? (uint32_t)(m - g0) : (uint32_t)kL2Cap; // pairs in reach
     const bool end_in_reach = g0 + avail == m;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t i0 = (uint32_t)w * kL2PerWave + (uint32_t)lane; // index (from g0) of this thread's pair 0; pair k: + 64 k
@@ -484,8 +490,8 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     const uint64_t wave_at = g0 + (uint64_t)w * kL2PerWave;
     const uint64_t kfront = (wave_at > 0 && wave_at <= m) ? kin[wave_at - 1] : 0ull;
     // (while the loads are in flight: the counters and the bit arrays)
-    for (int i = t; i < kLsBins / 2 + 2; i += kL2Threads) cw[i] = 0;
-    for (int i = t; i < kLsWords; i += kL2Threads) tiedb[i] = 0, headb[i] = 0;
+    for (int i = t; i < kL2Bins / 2 + 2; i += kL2Threads) cw[i] = 0;
+    for (int i = t; i < kL2Words; i += kL2Threads) tiedb[i] = 0, headb[i] = 0;
     if (t == 0) s_first = kNone, s_end = kNone, s_last = 0, s_max = 0;
     __syncthreads();
     LS_PROBE(0);
@@ -568,9 +574,9 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     // (bins by the starts in the whole reach, an upper bound of the owned sub-buckets: at most a few more than those)
     const uint32_t nseg = starts_all;
     uint32_t bb = 0;
-    while (bb < L && ((uint64_t)nseg << (bb + 1u)) <= (uint64_t)kLsBins) ++bb;
+    while (bb < L && ((uint64_t)nseg << (bb + 1u)) <= (uint64_t)kL2Bins) ++bb;
     const uint32_t nb = nseg << bb, bshift = L - bb;
-    if (nb > (uint32_t)kLsBins) { // more sub-buckets than bins (uniform): the other kernel's stable passes
+    if (nb > (uint32_t)kL2Bins) { // more sub-buckets than bins (uniform): the other kernel's stable passes
         if (t == 0) tile_start[blockIdx.x] = kLsRedo, tile_cnt[blockIdx.x] = 0, atomicOr(fail, 4u);
         return;
     }
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     __syncthreads();
     LS_PROBE(2);
     {
-        constexpr int kPer = kLsBins / 2 / kL2Threads;
+        constexpr int kPer = kL2Bins / 2 / kL2Threads;
         uint32_t wv[kPer], sum = 0, mx = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -702,19 +708,19 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
             if (!((nothead >> k) & 1u)) atomicOr(&headb[fin >> 5], 1u << (fin & 31u));
         }
     __syncthreads();
-    if (w == 0) { // tied members before each word: one wave scans the kLsWords word counts
+    if (w == 0) { // tied members before each word: one wave scans the kL2Words word counts
         uint32_t run = 0;
-        for (int c0 = 0; c0 < kLsWords; c0 += kWave) {
+        for (int c0 = 0; c0 < kL2Words; c0 += kWave) {
             const int i = c0 + lane;
-            const uint32_t cnt = i < kLsWords ? (uint32_t)__popc(tiedb[i]) : 0u;
+            const uint32_t cnt = i < kL2Words ? (uint32_t)__popc(tiedb[i]) : 0u;
             const uint32_t inc = wave_inclusive_scan<OpAdd>(cnt);
-            if (i < kLsWords) tpre[i] = run + inc - cnt;
+            if (i < kL2Words) tpre[i] = run + inc - cnt;
             run += __shfl(inc, kWave - 1, kWave);
         }
         if (lane == 0) tile_start[blockIdx.x] = (uint32_t)gs, tile_cnt[blockIdx.x] = run;
     }
     __syncthreads();
-    for (int wd = t; wd < kLsWords; wd += kL2Threads) {
+    for (int wd = t; wd < kL2Words; wd += kL2Threads) {
         uint32_t bits = tiedb[wd], at = tpre[wd];
         const uint32_t heads = headb[wd];
         while (bits) {
@@ -844,7 +850,7 @@ struct OutLongMember {
 
 using namespace sx;
 
-uint32_t sx_local_sort_tiles(uint64_t m) { return sx_div_up(m, kLsSpan); }
+uint32_t sx_local_sort_tiles(uint64_t m) { return sx_div_up(m, kL2Cap - 1024); } // (the shortest span a launch may take)
 
 // The long sub-buckets local_sort_kernel listed (n_long starts in long_list; long_list holds 3 * long_cap words: starts,
 // lengths, offsets).  *done = 0 when they hold more pairs than `max_pairs` (the scratch arrays' size; the caller falls back
@@ -905,10 +911,11 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
     // sub-bucket that starts at the span's last pair must end within the reach of kLsCap pairs, or the whole sort falls back
     // to plain passes.  So the span grows only where the caller knows how long sub-buckets get (four-letter texts with
     // dense keys: uniform symbols at a known rate; longest_expected = 0: not known), with a factor of safety.
-    uint32_t span = (uint32_t)kLsSpan;
-    if (longest_expected > 0 && 3 * (uint64_t)longest_expected <= 2 * ((uint64_t)kLsCap - 5632u)) span = 5632u;
-    else if (longest_expected > 0 && 3 * (uint64_t)longest_expected <= 2 * ((uint64_t)kLsCap - 5376u)) span = 5376u;
-    if (span < (uint32_t)kLsSpan) span = (uint32_t)kLsSpan;
+    // (a span is the lean kernel's reach less a margin of 1024, 768 or 512 pairs; the other kernel, whose reach is at least
+    //  as long, takes the same tiling)
+    uint32_t span = (uint32_t)kL2Cap - 1024u;
+    if (longest_expected > 0 && 3 * (uint64_t)longest_expected <= 2 * 512u) span = (uint32_t)kL2Cap - 512u;
+    else if (longest_expected > 0 && 3 * (uint64_t)longest_expected <= 2 * 768u) span = (uint32_t)kL2Cap - 768u;
     const uint32_t tiles = sx_div_up(m, span);
     const uint32_t L = (uint32_t)(kbits - top_bits);
     uint32_t res_local[3];
