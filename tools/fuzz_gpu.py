@@ -68,6 +68,7 @@ for k in range(cases):
     ctx.set_text_keys(bool(rng.integers(0, 4)))
     ctx.set_small_direct_max(int(rng.choice([0, 0, -1, 1 << 30])))  # short records of few symbols sorted directly, or through SA-IS
     ctx.set_long_subbuckets(bool(rng.integers(0, 4)))  # (the hybrid sort lists sub-buckets too long for a workgroup, or falls back)
+    ctx.set_local_sort_lean(bool(rng.integers(0, 4)))  # round 5: the LDS step's lean kernel (+ the other one for crowded workgroups), or the other one for all
     # (alphabet_size == n + 1 with repeated symbols: the reference's shortcut leaves garbage)
     want = oracle.sa_is_strict(x, sigma) if sigma == n + 1 else oracle.sa_is(x, sigma)
     sa = np.zeros(n + 1, np.uint32)
@@ -86,5 +87,5 @@ for k in range(cases):
 ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(-1); ctx.set_prefix_symbols(0)
 ctx.set_sort_mode(0); ctx.set_radix_digit_bits(0)
 ctx.set_induce_batch_min(-1); ctx.set_induce_batch(True); ctx.set_induce_attended(0); ctx.set_copy_text_first(False); ctx.set_recurse_min(-1); ctx.set_sample_min(-1)
-ctx.set_induce_hoist(True); ctx.set_text_keys(True); ctx.set_long_subbuckets(True); ctx.set_small_direct_max(-1)
+ctx.set_induce_hoist(True); ctx.set_text_keys(True); ctx.set_long_subbuckets(True); ctx.set_small_direct_max(-1); ctx.set_local_sort_lean(True)
 print(f"{cases} cases ok in {time.time()-t0:.0f} s; paths taken: {paths}")
