@@ -362,11 +362,11 @@ __global__ __launch_bounds__(kBlock) void plcp_samples_kernel(const uint8_t *__r
 // matched to the end of the head, carrying Kasai's invariant as before.
 constexpr uint32_t kPlcpHead = 32;
 __global__ __launch_bounds__(kBlock) void plcp_head_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ phi, uint64_t N,
-                                                           uint32_t *__restrict__ plcp)
+                                                           uint32_t *__restrict__ plcp, uint8_t *__restrict__ chunk_long)
 {
+    static_assert(kLcpChunk == kWave, "a wave looks at one chunk of the loop below: its ballot is the chunk's flag");
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t pred = phi[i];
+    const uint32_t pred = i < N ? phi[i] : kNoPhi;
     uint32_t l = 0;
     if (pred != kNoPhi) {
         uint64_t a[4], b[4];
@@ -379,15 +379,20 @@ __global__ __launch_bounds__(kBlock) void plcp_head_kernel(const uint8_t *__rest
             if (x) l = 8u * (uint32_t)k + (uint32_t)((__ffsll((unsigned long long)x) - 1) >> 3);
         }
     }
-    plcp[i] = l;
+    if (i < N) plcp[i] = l;
+    // whether the chunk holds a position the loop below has to walk on from (on ordinary text next to none does: its threads
+    // then leave at once instead of reading 64 positions' phi and plcp at a stride of 256 bytes a lane -- 2.5 ms at 2^28)
+    const uint64_t any_long = __ballot((i < N && l >= kPlcpHead) ? 1 : 0);
+    if (lane_id() == 0 && i < N) chunk_long[i / kLcpChunk] = any_long ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void plcp_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ phi, uint64_t N,
-                                                      const uint32_t *__restrict__ plcp_samples, uint32_t *__restrict__ plcp)
+                                                      const uint32_t *__restrict__ plcp_samples, uint32_t *__restrict__ plcp,
+                                                      const uint8_t *__restrict__ chunk_long)
 {
     const uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t i0 = chunk * kLcpChunk;
-    if (i0 >= N) return;
+    if (i0 >= N || !chunk_long[chunk]) return; // (no position of the chunk matched its head to the end: the head kernel's values stand)
     const uint64_t i1 = i0 + kLcpChunk < N ? i0 + kLcpChunk : N;
     uint32_t carry = plcp_samples[chunk]; // a lower bound of the value at the next position (the chunk's first: the value itself)
     constexpr int kAhead = 8;
@@ -571,8 +576,9 @@ static int lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uin
     if (by_phi) SX_TRY(permute_dev(ctx, d_sa, d_sa, 1u, N, phi)); // phi[sa[j]] = sa[j - 1]
     const uint64_t chunks = (N + kLcpChunk - 1) / kLcpChunk;
     // samples: chunk 0 from scratch, then the chunks at odd multiples of S, S halving, each from the sample S to its left
-    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, chunks * 4 + 4096));
+    SX_TRY(sx_slab_ensure(ctx, SX_SLAB_BWT, chunks * 5 + 4096 + 256));
     uint32_t *plcp = (uint32_t *)((char *)ctx->slab[SX_SLAB_BWT].p + 4096); // (the first page holds inverse_dev's counter)
+    uint8_t *chunk_long = (uint8_t *)(plcp + chunks);                        // a flag a chunk: some position matched its 32-symbol head
     if (by_phi)
         sx_launch(ctx, SX_KC_LCP, 64, plcp_samples_kernel, dim3(1), dim3(kBlock), (const uint8_t *)T, (const uint32_t *)phi, (uint64_t)1, (uint64_t)0,
                   (uint64_t)1, (uint64_t)0, plcp);
@@ -593,9 +599,9 @@ static int lcp_dev(sx_ctx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uin
     }
     if (by_phi) {
         sx_launch(ctx, SX_KC_LCP, N * (8 + 64), plcp_head_kernel, dim3(sx_div_up(N, kBlock)), dim3(kBlock), (const uint8_t *)T, (const uint32_t *)phi, N,
-                  plcp_full);
+                  plcp_full, chunk_long);
         sx_launch(ctx, SX_KC_LCP, N * 12, plcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, (const uint32_t *)phi, N,
-                  (const uint32_t *)plcp, plcp_full);
+                  (const uint32_t *)plcp, plcp_full, (const uint8_t *)chunk_long);
         SX_TRY(permute_dev(ctx, inv, plcp_full, 0u, N, d_lcp)); // lcp[inv[i]] = plcp[i]
     } else {
         sx_launch(ctx, SX_KC_LCP, N * 14, lcp_kernel, dim3(sx_div_up(chunks, kBlock)), dim3(kBlock), (const uint8_t *)T, d_sa,
