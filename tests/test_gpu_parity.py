@@ -771,6 +771,35 @@ def test_c_batch_farm_many_short_records(gpu_ctx):
             os.environ["STRALG_AMD_FARM_WORKERS"] = old
 
 
+def test_bench_refuses_two_ranks_on_one_gpu():
+    """Two ranks of `bench.py --gpus 2` that end up on ONE device (both with LOCAL_RANK 0 here: what a launcher that hands
+    out the same local rank, or a masked HIP_VISIBLE_DEVICES, does to a driver): N ranks must mean N GPUs, so rank 0 prints
+    ONE JSON line that carries `error` and every rank exits non-zero -- unless the builder's
+    rehearsal switch STRALG_BENCH_SHARE_GPU=1 says that sharing is meant."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = {k: v for k, v in os.environ.items() if k != "STRALG_BENCH_SHARE_GPU"}
+    procs = []
+    for r in range(2):
+        env = dict(base, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   STRALG_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "200000", "--steps", "1",
+                                       "--warmup", "0", "--no-e2e", "--no-cpu", "--no-egress", "--no-ro"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode != 0 for p in procs), [(p.returncode, o[1][-500:]) for p, o in zip(procs, outs)]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    doc = json.loads(lines[0])
+    assert "error" in doc and doc["value"] is None and doc["n_gpus"] == 2 and "more than one" in doc["error"], doc
+
+
 def test_c_harness_runs(tmp_path):
     """a plain C caller of the reference-named API (restated performance/suffix_array_construction.c)"""
     import subprocess
