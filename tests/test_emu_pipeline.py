@@ -519,7 +519,7 @@ def test_fasta_ingest_and_remap(emu_routed, golden_fasta):
 def test_wide_alphabets_direct_sort_and_induction(emu_ctx):
     """alphabets of 16+ symbols: the direct prefix sort of all suffixes (lms_path 3) and, with it switched off, the
     LMS sort + induction over many buckets; suffix array and BWT from both"""
-    for sigma, n in ((256, 30000), (21, 20000), (100, 5000), (128, 3000), (18, 5000)):
+    for sigma, n in ((256, 12000), (21, 9000), (100, 5000), (128, 3000), (18, 5000)):
         x = synth(n, sigma, 3)
         x[100:112] = x[1000:1012]
         x[5:17] = x[1000:1012]  # ties beyond the first key: refinement rounds
