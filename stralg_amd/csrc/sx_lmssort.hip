@@ -1365,6 +1365,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         uint32_t n_long = 0;
         SX_TRY(sx_readback(ctx, d_scalar + 3, 1, &n_long));
         const uint32_t gbits = n_long > 1 ? (uint32_t)sx_bitlen(n_long - 1) : 1u;
+        if (getenv("STRALG_AMD_TRACE_REFINE")) fprintf(stderr, "stralg_amd refine:   %u members of %u groups too long for the LDS tier\n", A3, n_long);
         // order by (group, next key), LSD: stable sort by next key, then stable sort by group
         int f = 0;
         SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A3, 0, kbits_r, &f));

@@ -428,10 +428,12 @@ __global__ __launch_bounds__(kLsThreads, 4) void local_sort_redo_kernel(
 //     in the few sub-buckets its lanes belong to: the same cache lines as stores in order);
 //   * tied pairs (under one in a hundred) leave their position in R at their final slot and a bit in two small bit arrays, from
 //     which they are listed in order.
-// 42 KiB of LDS, 8 barriers.  A workgroup that meets a crowded bin or has more sub-buckets than bins leaves its pairs to the
-// kernel above (kLsRedo in tile_start, bit 2 of *fail: the host queues that launch).
+//   * a crowded bin (more than kLsMaxBin pairs: a repeat's equal and nearly equal keys) is ordered by waves, 64 of its pairs
+//     each, counting per distinct value through ballots (below) -- a genome's repeat families put one into four workgroups of ten.
+// 56 KiB of LDS, 8 barriers (9 with crowded bins).  A workgroup that meets a bin of more than SX_LS2_TEAM_MAX pairs or has more
+// sub-buckets than bins leaves its pairs to the kernel above (kLsRedo in tile_start, bit 2 of *fail: the host queues that launch).
 #ifdef SX_LS_PROBE // (diagnostic build: cycles of the lean kernel's phases, summed over the workgroups' first waves; tools/ab_macros.sh)
-__device__ unsigned long long sx_ls_probe[16];
+__device__ unsigned long long sx_ls_probe[24];
 #define LS_PROBE(i)                                                                  \
     do {                                                                             \
         const unsigned long long now_ = (unsigned long long)clock64();               \
@@ -450,7 +452,14 @@ __device__ unsigned long long sx_ls_probe[16];
 #ifndef SX_LS2_BINS
 #define SX_LS2_BINS SX_LS_BINS
 #endif
-constexpr int kL2Cap = SX_LS2_CAP, kL2Words = kL2Cap / 32, kL2Bins = SX_LS2_BINS;
+#ifndef SX_LS2_UNROLL
+#define SX_LS2_UNROLL 2 // bin members an owner compares itself with a step (1 GiB of DNA: one 1.87 ms, two 1.75, four 1.77)
+#endif
+#ifndef SX_LS2_TEAM_MAX
+#define SX_LS2_TEAM_MAX 512 // the fullest bin a workgroup orders itself (by waves, below); beyond: left to the other kernel
+#endif
+constexpr int kL2Cap = SX_LS2_CAP, kL2Words = kL2Cap / 32, kL2Bins = SX_LS2_BINS, kL2Unroll = SX_LS2_UNROLL;
+constexpr int kL2TeamMax = SX_LS2_TEAM_MAX, kL2Jobs = kL2Cap / (kLsMaxBin + 1) + kL2Cap / kWave + 1; // (a job: 64 members of a crowded bin)
 constexpr int kL2Threads = SX_LS2_THREADS, kL2Waves = kL2Threads / kWave, kL2Items = kL2Cap / kL2Threads, kL2PerWave = kWave * kL2Items;
 #ifndef SX_LS2_MINWAVES
 #define SX_LS2_MINWAVES (SX_LS2_THREADS >= 1024 ? 8 : 4)
@@ -465,7 +474,9 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     uint32_t long_cap)
 {
     __shared__ uint32_t cw[kL2Bins / 2 + 2];  // packed 16-bit counters: counts, then first slots, then (after the drops) ends
-    __shared__ uint32_t R[kL2Cap];            // sort fields in bin order; then the positions of tied pairs at their final slots
+    __shared__ uint32_t R[kL2Cap + kL2Unroll]; // sort fields in bin order; then the positions of tied pairs at their final slots
+    __shared__ uint16_t team_fin[kL2Cap];     // crowded bins: final slot | tied << 13 | not the group's head << 14, by the slot a pair dropped into
+    __shared__ uint32_t jobs[kL2Jobs], s_jobs; // crowded bins in pieces of 64 members: first slot | members << 13 | piece << 26
     __shared__ uint32_t tiedb[kL2Words], headb[kL2Words], tpre[kL2Words];
     __shared__ uint32_t s_first, s_end, s_last, s_max, s_scan[kL2Waves], s_starts[kL2Waves];
     const int t = (int)threadIdx.x, lane = lane_id(), w = wave_id();
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     // (while the loads are in flight: the counters and the bit arrays)
     for (int i = t; i < kL2Bins / 2 + 2; i += kL2Threads) cw[i] = 0;
     for (int i = t; i < kL2Words; i += kL2Threads) tiedb[i] = 0, headb[i] = 0;
-    if (t == 0) s_first = kNone, s_end = kNone, s_last = 0, s_max = 0;
+    if (t == 0) s_first = kNone, s_end = kNone, s_last = 0, s_max = 0, s_jobs = 0;
     __syncthreads();
     LS_PROBE(0);
     // ---- sub-bucket starts: ballots ------------------------------------------------------------------------------------------
@@ -578,6 +589,9 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     const uint32_t nb = nseg << bb, bshift = L - bb;
     if (nb > (uint32_t)kL2Bins) { // more sub-buckets than bins (uniform): the other kernel's stable passes
         if (t == 0) tile_start[blockIdx.x] = kLsRedo, tile_cnt[blockIdx.x] = 0, atomicOr(fail, 4u);
+#ifdef SX_LS_PROBE
+        if (t == 0) atomicAdd(&sx_ls_probe[8], 1ull);
+#endif
         return;
     }
     const uint32_t lowmask = L >= 32 ? ~0u : ((1u << L) - 1u);
@@ -624,13 +638,29 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
         for (int j = 0; j < kPer; ++j) {
             const uint32_t lo = wv[j] & 0xFFFFu, hi = wv[j] >> 16;
             cw[(uint32_t)t * kPer + (uint32_t)j] = run | ((run + lo) << 16);
+            if (mx > (uint32_t)kLsMaxBin) { // (rare) crowded bins: equal keys, a repeat's ties -- jobs for the waves, 64 members each
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t len = h ? hi : lo, first = h ? run + lo : run;
+                    if (len > (uint32_t)kLsMaxBin) {
+                        const uint32_t pieces = (len + kWave - 1u) / kWave, at = atomicAdd(&s_jobs, pieces);
+#ifdef SX_LS_PROBE
+                        atomicAdd(&sx_ls_probe[len <= 32 ? 11 : len <= 64 ? 12 : len <= 128 ? 13 : len <= 256 ? 14 : 15], (unsigned long long)len | (1ull << 40));
+#endif
+                        for (uint32_t pc = 0; pc < pieces && at + pc < (uint32_t)kL2Jobs; ++pc) jobs[at + pc] = first | (len << 13) | (pc << 26);
+                    }
+                }
+            }
             run += lo + hi;
         }
     }
     __syncthreads();
     LS_PROBE(3);
-    if (s_max > (uint32_t)kLsMaxBin) { // a crowded bin: equal keys, a repeat's ties (uniform)
+    if (s_max > (uint32_t)kL2TeamMax) { // a bin too crowded for that too: the other kernel's stable passes (uniform)
         if (t == 0) tile_start[blockIdx.x] = kLsRedo, tile_cnt[blockIdx.x] = 0, atomicOr(fail, 4u);
+#ifdef SX_LS_PROBE
+        if (t == 0) atomicAdd(&sx_ls_probe[9], 1ull), atomicMax(&sx_ls_probe[10], (unsigned long long)s_max);
+#endif
         return;
     }
     // ---- the pairs drop into their bins (any order) ------------------------------------------------------------------------
@@ -656,7 +686,7 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
         val[k] = ((own >> k) & 1u) ? __builtin_nontemporal_load(vin + g0 + i) : 0u;
     }
     // ---- a pair's final slot: the first slot of its bin + the pairs of the bin that sort before it (equal fields: by slot) ----
-    uint32_t bspan[kL2Items], tied = 0, nothead = 0; // the pair's bin: first slot | pairs << 16
+    uint32_t bspan[kL2Items], tied = 0, nothead = 0, team = 0; // the pair's bin: first slot | pairs << 16
 #pragma unroll
     for (int k = 0; k < kL2Items; ++k) {
         bspan[k] = 0;
@@ -664,26 +694,82 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
             const uint32_t bin = f[k] >> bshift;
             const uint32_t end = (cw[bin >> 1] >> (16u * (bin & 1u))) & 0xFFFFu; // (the cursor has reached the bin's end)
             const uint32_t first = bin ? (cw[(bin - 1u) >> 1] >> (16u * ((bin - 1u) & 1u))) & 0xFFFFu : 0u;
-            bspan[k] = first | ((end - first) << 16);
-            sf[k] |= first << 16;
+            if (end - first > (uint32_t)kLsMaxBin) team |= 1u << k; // a crowded bin: placed by the waves' jobs below
+            else bspan[k] = first | ((end - first) << 16), sf[k] |= first << 16;
         }
     }
 #pragma unroll 1
-    for (uint32_t step = 0; step < (uint32_t)kLsMaxBin; ++step) {
+    for (uint32_t step = 0; step < (uint32_t)kLsMaxBin; step += (uint32_t)kL2Unroll) {
         bool more = false;
 #pragma unroll
         for (int k = 0; k < kL2Items; ++k) {
             const uint32_t len = bspan[k] >> 16;
             if (step < len) {
-                const uint32_t j = (bspan[k] & 0xFFFFu) + step, r2 = R[j], dropped = sf[k] & 0xFFFFu;
-                const bool eq = r2 == f[k];
-                sf[k] += (r2 < f[k] || (eq && j < dropped)) ? 0x10000u : 0u;
-                if (eq && j != dropped) tied |= 1u << k;
-                if (eq && j < dropped) nothead |= 1u << k;
-                more = more || step + 1u < len;
+                const uint32_t j0 = (bspan[k] & 0xFFFFu) + step, dropped = sf[k] & 0xFFFFu;
+                uint32_t r2[kL2Unroll];
+#pragma unroll
+                for (int u = 0; u < kL2Unroll; ++u) r2[u] = R[j0 + (uint32_t)u]; // (R is padded: what lies behind the bin is masked below)
+#pragma unroll
+                for (int u = 0; u < kL2Unroll; ++u) {
+                    const uint32_t j = j0 + (uint32_t)u;
+                    const bool in = step + (uint32_t)u < len, eq = in && r2[u] == f[k];
+                    sf[k] += ((in && r2[u] < f[k]) || (eq && j < dropped)) ? 0x10000u : 0u;
+                    if (eq && j != dropped) tied |= 1u << k;
+                    if (eq && j < dropped) nothead |= 1u << k;
+                }
+                more = more || step + (uint32_t)kL2Unroll < len;
             }
         }
         if (!__any(more ? 1 : 0)) break;
+    }
+    // Crowded bins (more than kLsMaxBin members: equal and nearly equal keys of a repeat family -- the genome-like 1 GiB text
+    // has one in 42 % of its workgroups, 68 000 bins of 33 ... 128 members mostly; a member stepping through its bin alone
+    // takes a step a member): a wave takes 64 members of the bin and, for every distinct value among them, counts over the whole
+    // bin -- 64 members a ballot -- the members below it, the equal ones and the equal ones in front of its piece; equal
+    // members keep the order of their slots.  (Every member against every member, passed from lane to lane: the same result,
+    // but 64 / (distinct values) times the work, and workgroups of nothing but crowded bins took ten times the usual.)
+    const uint32_t n_jobs = s_jobs < (uint32_t)kL2Jobs ? s_jobs : (uint32_t)kL2Jobs;
+    if (n_jobs) { // (uniform)
+        const uint32_t inbin = bshift >= 32 ? ~0u : ((1u << bshift) - 1u); // (a bin's members differ below bit bshift <= 19 only)
+        constexpr uint32_t kNoKey = 0xFFFFFFFFu;                           // (beyond the bin's end: above every key, equal to none)
+        for (uint32_t jb = (uint32_t)w; jb < n_jobs; jb += (uint32_t)kL2Waves) {
+            const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[jb]); // (uniform: the loops below stay scalar)
+            const uint32_t first = job & 0x1FFFu, len = (job >> 13) & 0x1FFFu, piece0 = (job >> 26) * kWave, mine = piece0 + (uint32_t)lane;
+            const bool act = mine < len;
+            const uint32_t ck = act ? R[first + mine] & inbin : 0u;
+            // (the bin's first 128 members stay in registers: few bins hold more)
+            const uint32_t c0 = (uint32_t)lane < len ? R[first + (uint32_t)lane] & inbin : kNoKey;
+            const uint32_t c1 = kWave + (uint32_t)lane < len ? R[first + kWave + (uint32_t)lane] & inbin : kNoKey;
+            uint64_t todo = __ballot(act ? 1 : 0);
+            while (todo) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)ck, __ffsll((unsigned long long)todo) - 1);
+                const uint64_t mym = __ballot(act && ck == v ? 1 : 0), e0 = __ballot(c0 == v ? 1 : 0), e1 = __ballot(c1 == v ? 1 : 0);
+                uint32_t below = (uint32_t)__popcll(__ballot(c0 < v ? 1 : 0)) + (uint32_t)__popcll(__ballot(c1 < v ? 1 : 0));
+                uint32_t equal = (uint32_t)__popcll(e0) + (uint32_t)__popcll(e1);
+                uint32_t front = (piece0 >= kWave ? (uint32_t)__popcll(e0) : 0u) + (piece0 >= 2u * kWave ? (uint32_t)__popcll(e1) : 0u);
+                for (uint32_t j0 = 2u * kWave; j0 < len; j0 += kWave) {
+                    const uint32_t c = j0 + (uint32_t)lane < len ? R[first + j0 + (uint32_t)lane] & inbin : kNoKey;
+                    const uint32_t e = (uint32_t)__popcll(__ballot(c == v ? 1 : 0));
+                    below += (uint32_t)__popcll(__ballot(c < v ? 1 : 0));
+                    equal += e;
+                    front += j0 < piece0 ? e : 0u;
+                }
+                if ((mym >> lane) & 1ull) {
+                    const uint32_t infront = front + (uint32_t)__popcll(mym & lanemask_lt());
+                    team_fin[first + mine] = (uint16_t)((first + below + infront) | (equal > 1u ? 0x2000u : 0u) | (infront ? 0x4000u : 0u));
+                }
+                todo &= ~mym;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kL2Items; ++k)
+            if ((team >> k) & 1u) {
+                const uint32_t r = team_fin[sf[k] & 0xFFFFu];
+                sf[k] |= (r & 0x1FFFu) << 16;
+                tied |= ((r >> 13) & 1u) << k;
+                nothead |= ((r >> 14) & 1u) << k;
+            }
     }
     LS_PROBE(5);
     // ---- out: positions and windows to their places --------------------------------------------------------------------------
@@ -737,6 +823,14 @@ __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
 #ifdef SX_LS_PROBE
     if (t == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&sx_ls_probe[i], (unsigned long long)probe_d[i]);
+    if (t == 0) { // the slowest workgroup, its insert phase, and how many took more than 3 times / 10 times 60 000 cycles
+        unsigned long long all = 0;
+        for (int i = 0; i < 8; ++i) all += probe_d[i];
+        atomicMax(&sx_ls_probe[16], all);
+        atomicMax(&sx_ls_probe[17], (unsigned long long)probe_d[5]);
+        if (all > 180000ull) atomicAdd(&sx_ls_probe[18], 1ull);
+        if (all > 600000ull) atomicAdd(&sx_ls_probe[19], 1ull);
+    }
 #endif
 }
 
@@ -921,8 +1015,12 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
     uint32_t res_local[3];
     if (!res) res = res_local;
     SX_CHECK(hipMemsetAsync(d_total_and_fail + 1, 0, 2 * sizeof(uint32_t), ctx->stream));
-    // (genome-like 1 GiB: the lean kernel + the workgroups it leaves 4.44 ms, the other kernel for all 4.11; uniform DNA 1.86 against 2.59)
-    if (ctx->local_sort_lean_off || crowded_expected) { // SX_FLAG_LOCAL_SORT_LEAN_OFF (tests, A/B), skewed symbol counts: rounds 3 and 4's kernel for every workgroup
+#ifndef SX_LS2_SKEWED
+#define SX_LS2_SKEWED 1 // texts with skewed symbol counts (repeat families crowd bins): 1 the lean kernel too, 0 the other one at once
+#endif
+    // (1 GiB of uniform DNA 1.75 - 1.8 ms against the other kernel's 2.59; the genome-like 1 GiB text, whose repeat family crowds a bin
+    //  in 42 % of the workgroups: 3.07 against 4.1 -- the lean kernel 2.2, the 2 % of the workgroups it leaves 0.2, the tied lists)
+    if (ctx->local_sort_lean_off || (crowded_expected && !SX_LS2_SKEWED)) { // SX_FLAG_LOCAL_SORT_LEAN_OFF (tests, A/B): rounds 3 and 4's kernel for every workgroup
         SX_CHECK(hipMemsetAsync(tile_start, 0xFF, (size_t)tiles * sizeof(uint32_t), ctx->stream));
         sx_launch(ctx, SX_KC_LOCAL_SORT, m * (12 + 4 + (seedw ? 4 : 0)), local_sort_redo_kernel, dim3(tiles), dim3(kLsThreads), kin, vin, m, L,
                   (uint32_t)kbits, vout, seedw, tile_start, tile_cnt, stage, stage_head, d_total_and_fail + 1, span, long_list,
@@ -934,11 +1032,16 @@ int sx_local_sort(sx_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_
     }
 #ifdef SX_LS_PROBE
     {
-        unsigned long long h[16];
+        unsigned long long h[24];
         SX_CHECK(hipStreamSynchronize(ctx->stream));
         SX_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(sx_ls_probe), sizeof h));
         fprintf(stderr, "local_sort phases (cycles a workgroup, %u workgroups): load+zero %llu starts %llu count %llu scan %llu drop %llu insert %llu stores %llu list %llu\n",
                 tiles, h[0] / tiles, h[1] / tiles, h[2] / tiles, h[3] / tiles, h[4] / tiles, h[5] / tiles, h[6] / tiles, h[7] / tiles);
+        fprintf(stderr, "local_sort crowded bins (bins / members): <=32 %llu / %llu, <=64 %llu / %llu, <=128 %llu / %llu, <=256 %llu / %llu, more %llu / %llu\n",
+                h[11] >> 40, h[11] & 0xFFFFFFFFFFull, h[12] >> 40, h[12] & 0xFFFFFFFFFFull, h[13] >> 40, h[13] & 0xFFFFFFFFFFull, h[14] >> 40,
+                h[14] & 0xFFFFFFFFFFull, h[15] >> 40, h[15] & 0xFFFFFFFFFFull);
+        fprintf(stderr, "local_sort slowest workgroup %llu cycles (insert phase at most %llu); %llu took > 180 000, %llu > 600 000\n", h[16], h[17], h[18], h[19]);
+        fprintf(stderr, "local_sort left to the other kernel: %llu workgroups with more sub-buckets than bins, %llu with a crowded bin (fullest %llu)\n", h[8], h[9], h[10]);
         memset(h, 0, sizeof h);
         SX_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sx_ls_probe), h, sizeof h));
     }

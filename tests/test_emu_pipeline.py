@@ -167,13 +167,46 @@ def test_hybrid_prefix_sort(emu_ctx):
             x[300 + 400 * i:360 + 400 * i] = x[100:160]
         emu_ctx.set_prefix_symbols(17)
         want = oracle.sa_is(x, 5)
-        # (round 5: the lean kernel leaves a workgroup with a crowded bin to the kernel of rounds 3 and 4, whose stable passes
-        #  set bit 1; SX_FLAG_LOCAL_SORT_LEAN_OFF: that kernel for every workgroup)
+        # (round 5: the lean kernel orders a crowded bin by its waves -- 64 members a wave, counted against all the bin's
+        #  members passed from lane to lane --; SX_FLAG_LOCAL_SORT_LEAN_OFF: the kernel of rounds 3 and 4 for every workgroup,
+        #  whose stable passes set bit 1)
         for lean in (True, False):
             emu_ctx.set_local_sort_lean(lean)
             sa = _sa(emu_ctx, x, 5)
-            assert emu_ctx.last_stats()["sort_local"] & 7 == 3, (lean, emu_ctx.last_stats())
+            assert emu_ctx.last_stats()["sort_local"] & 7 == (1 if lean else 3), (lean, emu_ctx.last_stats())
             assert (sa == want).all(), lean
+        # 90 and 200 copies (two and four pieces of 64 members a bin), some of them differing in the key's last symbols; and
+        # 700 copies: more than the waves take (SX_LS2_TEAM_MAX 512) -- that workgroup is left to the other kernel (bit 1)
+        for copies, variants, bit1 in ((90, 0, 0), (200, 7, 0), (130, 64, 0), (700, 0, 2), (700, 5, 2)):
+            n = 400 * copies + 5000
+            x = rng.integers(1, 5, size=n, dtype=np.uint8)
+            piece = x[100:160].copy()
+            for i in range(copies):
+                x[300 + 400 * i:360 + 400 * i] = piece
+                if variants and i % 3 == 0:
+                    x[300 + 400 * i + 14 + (i // 3) % 4] = 1 + (i // 3) % variants % 4
+            want = oracle.sa_is(x, 5)
+            for lean in (True, False):
+                emu_ctx.set_local_sort_lean(lean)
+                sa = _sa(emu_ctx, x, 5)
+                assert emu_ctx.last_stats()["sort_local"] & 7 == (1 | bit1 if lean else 3), (copies, variants, lean, emu_ctx.last_stats())
+                assert (sa == want).all(), (copies, variants, lean)
+        # skewed symbol counts (a genome's): long sub-buckets behind the frequent symbols' prefixes next to short ones, with ties
+        # beyond the key
+        for syms, n, p in ((17, 40000, (0.55, 0.25, 0.15, 0.05)), (14, 30000, (0.4, 0.4, 0.1, 0.1)), (18, 25000, (0.7, 0.1, 0.1, 0.1))):
+            x = rng.choice(np.arange(1, 5, dtype=np.uint8), size=n, p=p)
+            x[900:1000] = x[200:300]
+            x[n - 500:n - 420] = x[200:280]
+            emu_ctx.set_prefix_symbols(syms)
+            want = oracle.sa_is(x, 5)
+            for lean in (True, False):
+                emu_ctx.set_local_sort_lean(lean)
+                sa, bw = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint8)
+                emu_ctx.sa_bwt_build_dev(x, n, 5, sa, bw)
+                st = emu_ctx.last_stats()
+                assert st["lms_path"] == 1 and st["sort_local"] & 1, (syms, n, lean, st)
+                assert (sa == want).all() and (bw == oracle.bwt(x, want)).all(), (syms, n, lean)
+        emu_ctx.set_prefix_symbols(17)
         emu_ctx.set_local_sort_lean(True)
         # one 12-symbol prefix in front of thousands of LMS suffixes: a sub-bucket no workgroup can hold
         unit = np.array([1, 3, 2, 4, 4, 2, 3, 1, 1, 3, 2, 4, 2, 1], np.uint8)
@@ -220,6 +253,7 @@ def test_hybrid_prefix_sort(emu_ctx):
         emu_ctx.set_prefix_symbols(0)
         emu_ctx.set_text_keys(True)
         emu_ctx.set_long_subbuckets(True)
+        emu_ctx.set_local_sort_lean(True)
 
 
 def test_long_repeats_finish_by_comparison(emu_ctx):

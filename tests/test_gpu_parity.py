@@ -228,8 +228,23 @@ def test_hybrid_prefix_sort(gpu_ctx):
         for lean in (True, False):
             gpu_ctx.set_local_sort_lean(lean)
             sa = gpu_ctx.sa_build(x, 5)
-            assert gpu_ctx.last_stats()["sort_local"] & 7 == 3, (lean, gpu_ctx.last_stats())
+            assert gpu_ctx.last_stats()["sort_local"] & 7 == (1 if lean else 3), (lean, gpu_ctx.last_stats())
             assert (sa == want).all(), lean
+        # more copies: bins of two and four 64-member pieces for the lean kernel's waves, some copies differing in the key's last
+        # symbols; 700 copies: more than the waves take (SX_LS2_TEAM_MAX 512) -- that workgroup is left to the other kernel (bit 1)
+        for copies, variants, bit1 in ((90, 0, 0), (200, 7, 0), (130, 64, 0), (500, 3, 0), (700, 0, 2), (700, 5, 2)):
+            x = synth(1 << 20, 5, 35 + copies)
+            piece = x[100:160].copy()
+            for i in range(copies):
+                x[300 + 1400 * i:360 + 1400 * i] = piece
+                if variants and i % 3 == 0:
+                    x[300 + 1400 * i + 14 + (i // 3) % 4] = 1 + (i // 3) % variants % 4
+            want = oracle.sa_is(x, 5)
+            for lean in (True, False):
+                gpu_ctx.set_local_sort_lean(lean)
+                sa = gpu_ctx.sa_build(x, 5)
+                assert gpu_ctx.last_stats()["sort_local"] & 7 == (1 | bit1 if lean else 3), (copies, variants, lean, gpu_ctx.last_stats())
+                assert (sa == want).all(), (copies, variants, lean)
         gpu_ctx.set_local_sort_lean(True)
         # 60 variants of the piece that differ in the key's last three symbols, 30 copies each: crowded bins with many values
         x = synth(1 << 20, 5, 34)
