@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5's evidence, collected on a GPU box (three gpurun calls: parts a, b, c); the summaries are copied into profiles/
-# afterwards by tools/r05_collect.py.   bash tools/r05_final.sh a|b|c
+# Round 5's evidence, collected on a GPU box (gpurun calls: parts a, b, c, then d once the collected traffic is in the tree); the summaries are copied into profiles/
+# afterwards by tools/r05_collect.py.   bash tools/r05_final.sh a|b|c|d
 set -o pipefail
 part=$1
 out=gpurun_out/r05_final
@@ -31,4 +31,11 @@ case $part in
       "bench:--log2n 22 --steps 50 --warmup 5 $common" \
       "bench2n:--log2n 26 --steps 3 --warmup 1" "bench2:--log2n 26 --steps 3 --warmup 1" \
       "py:tools/bench_next.py" "prof:tools/bench_next.py";;
+  d) # after tools/r05_collect.py has stamped profiles/pmc_traffic.json: the lines that quote it, once more (traffic_stale false)
+    common2="--no-cpu --no-e2e --no-other-configs"
+    timeout -k 10 900 python bench.py --steps 20 --warmup 5 > $out/a/bench_1.json 2> $out/a/bench_1.err &&
+    timeout -k 10 600 python bench.py --workload bytes --steps 5 --warmup 2 $common2 > $out/c/bench_1.json 2> $out/c/bench_1.err &&
+    timeout -k 10 600 python bench.py --workload genome_like --steps 5 --warmup 2 $common2 > $out/c/bench_6.json 2> $out/c/bench_6.err &&
+    timeout -k 10 600 python bench.py --workload fasta --steps 5 --warmup 2 --no-cpu --no-e2e > $out/c/bench_11.json 2> $out/c/bench_11.err
+    echo "rc=$?";;
 esac
