@@ -466,6 +466,7 @@ constexpr int kL2Threads = SX_LS2_THREADS, kL2Waves = kL2Threads / kWave, kL2Ite
 #endif
 constexpr int kL2MinWaves = SX_LS2_MINWAVES; // (waves a SIMD the register budget is cut for)
 static_assert(kL2Threads * kL2Items == kL2Cap && kL2Bins / 2 % kL2Threads == 0 && kL2Cap <= kLsCap, "the lean kernel's shape");
+static_assert(kL2Cap < (1 << 13) && kL2TeamMax <= 64 * kWave, "a job word: 13 bits of first slot, 13 of members, 6 of piece");
 __global__ __launch_bounds__(kL2Threads, kL2MinWaves) void local_sort_kernel(
     const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t m, uint32_t L, uint32_t kbits,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ seedw /* or null */, uint32_t *__restrict__ tile_start,
