@@ -33,6 +33,7 @@ case $part in
       "py:tools/bench_next.py" "prof:tools/bench_next.py";;
   d) # after tools/r05_collect.py has stamped profiles/pmc_traffic.json: the lines that quote it, once more (traffic_stale false)
     common2="--no-cpu --no-e2e --no-other-configs"
+    mkdir -p $out/a $out/c
     timeout -k 10 900 python bench.py --steps 20 --warmup 5 > $out/a/bench_1.json 2> $out/a/bench_1.err &&
     timeout -k 10 600 python bench.py --workload bytes --steps 5 --warmup 2 $common2 > $out/c/bench_1.json 2> $out/c/bench_1.err &&
     timeout -k 10 600 python bench.py --workload genome_like --steps 5 --warmup 2 $common2 > $out/c/bench_6.json 2> $out/c/bench_6.err &&
