@@ -80,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-ro", action="store_true",
                     help="FASTA records: skip the reverse direction (build_complete_table's include_reverse: the RO table)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the probe of the box's memory ceiling before the timed region")
+    ap.add_argument("--roofline-every", type=int, default=4, metavar="M",
+                    help="the dominant kernel's launches carry HIP events in every M-th step of the timed region (1: every step; "
+                         "a timed launch costs the queue ~11 us)")
     ap.add_argument("--no-reference-scale", action="store_true",
                     help="skip the row at the reference's published size (n = 49 000 / 65 536 through the host C API)")
     ap.add_argument("--no-egress", action="store_true",
@@ -404,13 +407,26 @@ def run_rank(args):
     # one more untimed step, with events around every launch: the per-class table and the dominant class
     table = profiled_step()
     dom = max(table, key=lambda k: table[k]["ms"])  # the class with the largest summed time, whichever it is
-    # Timed region: events only around the dominant kernel's launches (the roofline figure is measured live, on
-    # the library's own stream); two event records around each of a step's ~300 launches would cost ~5 % of it.
+    # Timed region: events only on the dominant kernel's launches (the roofline figure is measured live, on the library's
+    # own stream), and only in every M-th of the timed steps: a launch that carries events leaves the queue idle for ~6 us
+    # in front of it and ~5 us behind it (rocprofv3 timeline; hipEventRecord pairs and hipExtLaunchKernelGGL's events alike),
+    # 0.39 ms of a 20 ms step for this class's 35 launches -- and two events on each of a step's ~300 launches ~5 % of it.
+    # Between the sampled steps the events are switched to a class no build launches (no synchronisation: the switch is a word).
+    every = max(1, args.roofline_every)
+    timed_steps = {"i": 0, "n": 0}
+
+    def timed_step():
+        sampled = timed_steps["i"] % every == 0
+        ctx.profile_only(dom if sampled else "search")
+        timed_steps["i"] += 1
+        timed_steps["n"] += 1 if sampled else 0
+        step()
+
     ctx.profile_reset()
-    ctx.profile_only(dom)
+    ctx.profile_only("search")
     ctx.profile_enable(True)
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps
-    elapsed_own = farm.timed(step, args.steps, 0, cuda=cuda)
+    elapsed_own = farm.timed(timed_step, args.steps, 0, cuda=cuda)
     ctx.profile_enable(False)
     prof = ctx.profile_read()
     ctx.profile_only(None)
@@ -565,6 +581,8 @@ def run_rank(args):
                                    "builder; not measured in this run") if traffic is not None else None,
                 "launches": d["launches"],
                 "avg_ms": round(d["ms"] / max(1, d["launches"]), 4),
+                "timed_steps": timed_steps["n"],  # the steps of the timed region whose launches of this class carried the events
+                "of_steps": args.steps,
                 # the same fraction against what THIS box streams (sx_membw_probe before the timed region): boxes of the pool
                 # differ by 12 - 14 % on unchanged kernels, a fraction of the data sheet's 8 TB/s cannot tell which moved
                 **({"peak_measured": ceiling["peak_measured"],

@@ -132,24 +132,22 @@ int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_ds
     return 0;
 }
 
-void sx_prof_begin(sx_ctx *ctx, int kclass)
+sx_event_pair *sx_prof_pair(sx_ctx *ctx, int kclass)
 {
     sx_event_pair ep;
     if (!ctx->ev_free.empty()) {
         ep = ctx->ev_free.back();
         ctx->ev_free.pop_back();
     } else {
-        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return nullptr;
     }
     ep.kclass = kclass;
-    (void)hipEventRecord(ep.a, ctx->stream);
     ctx->ev_used.push_back(ep);
+    return &ctx->ev_used.back();
 }
 
-void sx_prof_end(sx_ctx *ctx, int kclass, uint64_t alg_bytes)
+void sx_prof_count(sx_ctx *ctx, int kclass, uint64_t alg_bytes)
 {
-    if (ctx->ev_used.empty()) return;
-    (void)hipEventRecord(ctx->ev_used.back().b, ctx->stream);
     ctx->kstat[kclass].launches += 1;
     ctx->kstat[kclass].alg_bytes += alg_bytes;
 }

@@ -97,6 +97,15 @@ static void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size
     Pack pk{kernel, std::tuple<P...>(static_cast<P>(args)...)};
     emu_launch([](void *p) { Pack *q = (Pack *)p; emu_apply(q->k, q->a, std::index_sequence_for<P...>{}); }, &pk, grid, block);
 }
+/* hip_ext.h: the launch whose two events take the dispatch's own start and end times */
+template <class... P, class... A>
+static void hipExtLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t start,
+                                  hipEvent_t stop, unsigned /*flags*/, A... args)
+{
+    if (start) (void)hipEventRecord(start, st);
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+    if (stop) (void)hipEventRecord(stop, st);
+}
 
 static inline void __syncthreads() { emu_syncthreads(); }
 static inline void __threadfence() {}
