@@ -109,6 +109,8 @@ int sx_slab_ensure(sx_ctx *ctx, int which, size_t bytes);
 int sx_sync(sx_ctx *ctx);
 // device -> pinned host copy of `count` u32 followed by a stream sync
 int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst);
+// the same for one to four arrays (1024 words together), one behind the other in h_dst
+int sx_readback_ranges(sx_ctx *ctx, const uint32_t *const *d_src, const uint32_t *counts, int ranges, uint32_t *h_dst);
 // look-back status memory: a slab of (epoch-tagged) status words, zeroed whenever it is (re)allocated
 int sx_chain_slab(sx_ctx *ctx, int which, size_t bytes);
 // a fresh epoch for one chained launch (24 bits; every status slab is zeroed when they wrap)

@@ -104,15 +104,54 @@ __global__ void readback_kernel(const uint32_t *__restrict__ src, uint32_t count
         __hip_atomic_store(&page[1024], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// the same for up to four arrays, one behind the other on the page (the induced-sort passes read a pass's stop record, its
+// cursors and, at the end, two error words: one wake-up of the host instead of four)
+struct readback_ranges {
+    const uint32_t *src[4];
+    uint32_t count[4];
+};
+__global__ void readback_ranges_kernel(readback_ranges r, uint32_t *__restrict__ page, uint32_t seq)
+{
+    uint32_t at = 0;
+    for (int k = 0; k < 4; ++k) {
+        for (uint32_t i = threadIdx.x; i < r.count[k]; i += blockDim.x)
+            __hip_atomic_store(&page[at + i], r.src[k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        at += r.count[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&page[1024], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 } // namespace sx
 
 constexpr int kReadbackSpinUs = 150;
+static int readback_wait(sx_ctx *ctx, uint32_t seq, size_t count, uint32_t *h_dst);
 int sx_readback(sx_ctx *ctx, const uint32_t *d_src, size_t count, uint32_t *h_dst)
 {
     if (count > 1024) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
     const uint32_t seq = ++ctx->readback_seq ? ctx->readback_seq : ++ctx->readback_seq; // (never 0: the page starts zeroed)
     hipLaunchKernelGGL(sx::readback_kernel, dim3(1), dim3(256), 0, ctx->stream, d_src, (uint32_t)count, ctx->h_pin, seq);
     if (hipGetLastError() != hipSuccess) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback launch refused");
+    return readback_wait(ctx, seq, count, h_dst);
+}
+
+int sx_readback_ranges(sx_ctx *ctx, const uint32_t *const *d_src, const uint32_t *counts, int ranges, uint32_t *h_dst)
+{
+    sx::readback_ranges r = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
+    size_t total = 0;
+    if (ranges < 1 || ranges > 4) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback: one to four arrays");
+    for (int k = 0; k < ranges; ++k) r.src[k] = d_src[k], r.count[k] = counts[k], total += counts[k];
+    if (total > 1024) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback too large");
+    const uint32_t seq = ++ctx->readback_seq ? ctx->readback_seq : ++ctx->readback_seq;
+    hipLaunchKernelGGL(sx::readback_ranges_kernel, dim3(1), dim3(256), 0, ctx->stream, r, ctx->h_pin, seq);
+    if (hipGetLastError() != hipSuccess) return sx_fail_msg(ctx, SX_E_INTERNAL, "readback launch refused");
+    return readback_wait(ctx, seq, total, h_dst);
+}
+
+static int readback_wait(sx_ctx *ctx, uint32_t seq, size_t count, uint32_t *h_dst)
+{
     // The word usually arrives within tens of microseconds (the device is a launch or two behind the host), which is
     // what the poll is for: hipStreamSynchronize sleeps through that.  A wait that lasts longer -- milliseconds of queued
     // work in front of the read-back -- is left to the runtime: a farm runs several workers a device, all pinned to the

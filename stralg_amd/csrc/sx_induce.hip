@@ -553,15 +553,36 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         ctx->stats.induce_rounds++;
         return 0;
     };
-    auto cursors_as_counted = [&](bool &ok) -> int {
-        uint32_t cur[256];
-        SX_TRY(sx_readback(ctx, (const uint32_t *)st.cursor[st.par], nk, cur));
-        ok = true;
-        // both passes end with every cursor between its bucket's L and S suffixes (bucket 0 holds the sentinel's suffix
-        // alone, which no pass induces)
+    // what a pass leaves for the host, in one read-back: the unattended run's stop record (4 words), the cursors (nk), and
+    // behind the S pass the look-back time-out word and the hoisted rounds' error word
+    auto pass_end = [&](int pass, bool with_stop, uint32_t (&rec)[4], uint32_t (&cur)[256], uint32_t (&tail)[3]) -> int {
+        const uint32_t *src[4];
+        uint32_t cnt[4], page[4 + 256 + 3];
+        int k = 0;
+        if (with_stop) src[k] = (const uint32_t *)st.poison, cnt[k++] = 4;
+        src[k] = (const uint32_t *)st.cursor[st.par], cnt[k++] = nk;
+        if (pass == 1) {
+            src[k] = (const uint32_t *)st.status, cnt[k++] = 2;
+            if (st.hoist) src[k] = (const uint32_t *)st.hoist_err, cnt[k++] = 1;
+        }
+        SX_TRY(sx_readback_ranges(ctx, src, cnt, k, page));
+        const uint32_t *q = page;
+        if (with_stop) memcpy(rec, q, sizeof rec), q += 4;
+        memcpy(cur, q, nk * sizeof(uint32_t)), q += nk;
+        tail[0] = tail[1] = tail[2] = 0;
+        if (pass == 1) {
+            tail[0] = q[0], tail[1] = q[1];
+            if (st.hoist) tail[2] = q[2];
+        }
+        return 0;
+    };
+    // both passes end with every cursor between its bucket's L and S suffixes (bucket 0 holds the sentinel's suffix alone,
+    // which no pass induces)
+    auto cursors_as_counted = [&](const uint32_t (&cur)[256]) -> bool {
+        bool ok = true;
         for (uint32_t c = 1; c < nk; ++c)
             if (ti.h_all[c] && cur[c] != begin[c] + ti.h_l[c]) ok = false;
-        return 0;
+        return ok;
     };
     const bool unattended_ok = ctx->induce_attended != 1 && ti.open_tiles == 0;
     auto stopped = [&]() -> bool { return st.unattended && *(volatile uint32_t *)st.host_poison != 0; };
@@ -632,7 +653,7 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
         if (pass == 1) SX_CHECK(hipStreamSynchronize(ctx->stream)); // (`begin`, the L pass's upload source, may still be in use)
         SX_CHECK(hipMemcpyAsync(st.cursor[st.par], pass == 0 ? begin : begin + 1, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         if (st.hoist) SX_TRY(hoisted_rounds(pass));
-        uint32_t from = pass == 0 ? 0u : nk - 1u, rec[4] = {0, 0, 0, 0};
+        uint32_t from = pass == 0 ? 0u : nk - 1u, rec[4] = {0, 0, 0, 0}, cur[256], tail[3];
         const uint32_t *resume = nullptr;
         for (uint32_t attempt = 0;; ++attempt) {
             if (attempt > 2 * nk + 4) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a pass did not come to its end");
@@ -642,30 +663,20 @@ int induce_typed(sx_ctx *ctx, const sx_text_info &ti, uint32_t sigma, const uint
             }
             st.next_c = st.begun_c = -1;
             SX_TRY(pass == 0 ? pass_L(from, resume) : pass_S(from, resume));
-            if (!unattended_ok) break;
-            SX_TRY(sx_readback(ctx, (const uint32_t *)st.poison, 4, rec));
-            if (!rec[0]) break;
+            SX_TRY(pass_end(pass, unattended_ok, rec, cur, tail));
+            if (!unattended_ok || !rec[0]) break;
             // bucket rec[1] stopped with the range [rec[2], rec[3]) alive: carry it on attended, then the buckets behind it
             ctx->stats.induce_redo++;
             from = rec[1];
             resume = rec + 2;
         }
-        bool ok = false;
-        SX_TRY(cursors_as_counted(ok));
-        if (!ok) return sx_fail_msg(ctx, SX_E_INTERNAL, pass == 0 ? "induce L: a bucket did not receive its L-type count"
-                                                                    : "induce S: a bucket did not receive its S-type count");
+        if (!cursors_as_counted(cur))
+            return sx_fail_msg(ctx, SX_E_INTERNAL, pass == 0 ? "induce L: a bucket did not receive its L-type count"
+                                                             : "induce S: a bucket did not receive its S-type count");
+        if (pass == 1 && tail[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a look-back wait timed out");
+        if (pass == 1 && tail[2]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a bucket's cursor is not where the text's bigram counts put it");
     }
 
-    {
-        uint32_t timed_out[2] = {0, 0};
-        SX_TRY(sx_readback(ctx, (const uint32_t *)st.status, 2, timed_out));
-        if (timed_out[0]) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a look-back wait timed out");
-    }
-    if (st.hoist) {
-        uint32_t err = 0;
-        SX_TRY(sx_readback(ctx, (const uint32_t *)st.hoist_err, 1, &err));
-        if (err) return sx_fail_msg(ctx, SX_E_INTERNAL, "induce: a bucket's cursor is not where the text's bigram counts put it");
-    }
     if (ctx->prof_on) {
         // Algorithmic bytes of the two passes (the launches themselves were queued with bounds, not
         // sizes): the L pass scans every L-type entry and every LMS seed, the S pass every entry but
