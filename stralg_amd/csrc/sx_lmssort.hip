@@ -1341,6 +1341,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
     // LDS, the members of longer ones compacted and ordered by two radix sorts of (group, next key).
     // SX_FLAG_SORT_MODE 1 (plain passes only): every group of more than kSmallGroup members takes the radix sorts.
     const bool lds_tier = ctx->sort_mode != 1;
+    const bool trace_rounds = getenv("STRALG_AMD_TRACE_REFINE") != nullptr; // (diagnostic: members and time of every refinement round)
     auto refine_larger_groups = [&](uint64_t skip) -> int {
         const pkey_cfg kc_r = pkey_make(base, Cmax);
         SX_TRY((device_scan<OpMax>(ctx, A, InActHead{head}, OutGroupIds{head, (uint64_t)A, agid, gsize}, nullptr,
@@ -1362,10 +1363,16 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
         uint32_t *sub_num = gsize; // (the sizes are not needed any more)
         SX_TRY((device_scan<OpAdd>(ctx, A3, InSubHead{sub_t, sub_gid}, OutGroupNumber{sub_num}, d_scalar + 3, SX_KC_DOUBLING,
                                    (uint64_t)A3 * 12)));
-        uint32_t n_long = 0;
-        SX_TRY(sx_readback(ctx, d_scalar + 3, 1, &n_long));
-        const uint32_t gbits = n_long > 1 ? (uint32_t)sx_bitlen(n_long - 1) : 1u;
-        if (getenv("STRALG_AMD_TRACE_REFINE")) fprintf(stderr, "stralg_amd refine:   %u members of %u groups too long for the LDS tier\n", A3, n_long);
+        // (the groups' numbers are sort digits: how many there are is bounded by their least length -- no read-back of the count,
+        //  20 us of idle device a round; the bound is a bit too wide at most, and digits are taken eight bits at a time)
+        const uint32_t least = (uint32_t)(lds_tier ? kMidGroup : kSmallGroup) + 1u;
+        const uint32_t n_long_max = A3 / least > 1u ? A3 / least : 1u;
+        const uint32_t gbits = n_long_max > 1 ? (uint32_t)sx_bitlen(n_long_max - 1) : 1u;
+        if (trace_rounds) {
+            uint32_t n_long = 0;
+            SX_TRY(sx_readback(ctx, d_scalar + 3, 1, &n_long));
+            fprintf(stderr, "stralg_amd refine:   %u members of %u groups too long for the LDS tier\n", A3, n_long);
+        }
         // order by (group, next key), LSD: stable sort by next key, then stable sort by group
         int f = 0;
         SX_TRY(sx_sort_pairs(ctx, rk_a, ord_a, rk_b, ord_b, A3, 0, kbits_r, &f));
@@ -1380,7 +1387,7 @@ int sx_sort_lms_by_prefix(sx_ctx *ctx, const sx_text_info &ti, sx_arena &am, con
                   (const uint64_t *)key_keep, (uint64_t)A3, vs, ap_new, head_new, embed ? seedw : nullptr, ti.T, full_wcfg);
         return 0;
     };
-    const bool trace = getenv("STRALG_AMD_TRACE_REFINE") != nullptr; // (diagnostic: members and time of every refinement round)
+    const bool trace = trace_rounds;
     for (int round = 1; A > 0; ++round) {
         const auto trace_t0 = std::chrono::steady_clock::now();
         const uint32_t trace_A = A;
