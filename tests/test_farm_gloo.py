@@ -225,11 +225,15 @@ def test_bench_line_carries_round5_legs(emu_ctx):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["STRALG_BENCH_EMU"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2n", "12", "--steps", "1", "--warmup", "0",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2n", "12", "--steps", "6", "--warmup", "0",
                           "--e2e-log2n", "12", "--cpu-log2n", "12", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     doc = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert "peak_measured" in doc["roofline"] and doc["roofline"]["peak"] == 8000.0
+    # the dominant class carries its events in every fourth step of the timed region (steps 0 and 4 of six), and only there
+    rf = doc["roofline"]
+    assert (rf["timed_steps"], rf["of_steps"]) == (2, 6) and rf["launches"] > 0 and rf["launches"] % 2 == 0, rf  # (the harness's events carry no times)
+    assert rf["launches"] // 2 == doc["kernels"][rf["kernel"]]["launches_per_step"], (rf, doc["kernels"][rf["kernel"]])
     rs = doc["cpu_baseline"]["reference_scale"]
     assert [r["n"] for r in rs["rows"]] == [49000, 65536] and all(r["arrays_identical"] for r in rs["rows"]), rs
     assert rs["published"]["ms"] == 4.63 and all(r["gpu_call_ms"] > 0 and r["cpu_ms"] > 0 for r in rs["rows"])
