@@ -1,7 +1,7 @@
 """where the O table lands and how fast it is written: the same kernel (1 GiB of DNA: 20 GiB of rows) over buffers from
 successive allocations and at offsets inside one, beside a plain fill of the same buffer (sx_membw_probe) -- round 5's finding:
 the O-table kernel's time follows the allocation (4.0 ... 4.65 ms, host-timed), not the offset, the BWT's place or the time since
-the allocation, while the plain fill does not care (profiles/r05_otable_placement.txt)"""
+the allocation, while the plain fill does not care (profiles/r05_buffer_placement.txt)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
