@@ -84,6 +84,7 @@ for k in range(cases):
         assert (o.ravel() == want_o).all(), ("O", k, sigma, n, kind)
         sa2, c2, o2 = ctx.build_tables(x, sigma)  # the fused build: BWT from the induction windows / the sort payload
         assert (sa2 == want).all() and (c2 == want_c).all() and (o2.ravel() == want_o).all(), ("fused", k, sigma, n, kind, flag)
+    if k % 1000 == 999: print(f"{k + 1} cases, {time.time() - t0:.0f} s", flush=True)  # (a run that stays silent for minutes is taken for hung)
 ctx.force_general_path(False); ctx.set_no_direct_sort(False); ctx.set_chain_max_entries(-1); ctx.set_prefix_symbols(0)
 ctx.set_sort_mode(0); ctx.set_radix_digit_bits(0)
 ctx.set_induce_batch_min(-1); ctx.set_induce_batch(True); ctx.set_induce_attended(0); ctx.set_copy_text_first(False); ctx.set_recurse_min(-1); ctx.set_sample_min(-1)
