@@ -59,18 +59,69 @@ __device__ __forceinline__ void fasta_unpack16(const uint8_t *__restrict__ file,
 #endif
 constexpr int kFaSub = SX_FASTA_SUB;
 
-// (position + 1, kind) of the last '\n' (kind 1: a sequence follows) or '>' (kind 0: a header follows) among the bytes
-__device__ __forceinline__ uint32_t fasta_last_special(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end)
+// Which of a thread's 16 bytes are '\n', '>', white space (what a sequence drops: isspace()), ' ' or '\t' (what a header line
+// drops besides '>'), NUL: bit k for byte k.  Where the 16 bytes came as one load they are classified four at a time in their
+// words -- equality with a constant and "at least a constant" per byte without carries between the bytes, the four flag bits of
+// a word gathered by a dot product (sx_classify.hip does the same for the type bits) --, 170 instructions where a compare and
+// a shift for each byte and each class were 340 (round 5; the two kernels are bound by their instructions, 1.06 and 1.0 ms a GiB).
+struct fa_masks {
+    uint32_t nl, gt, sp, hdrop, zero;
+};
+__device__ __forceinline__ uint32_t fa_eq4(uint32_t w, uint32_t k4) // 0x80 in every byte of w that equals k4's
 {
-    uint32_t last = 0;
+    const uint32_t x = w ^ k4;
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t fa_ge4(uint32_t w, uint32_t k4) // 0x80 in every byte of w that is >= k4's (which are < 0x80)
+{
+    return (w | ((w | 0x80808080u) - k4)) & 0x80808080u;
+}
+__device__ __forceinline__ fa_masks fasta_masks16(const uint8_t *__restrict__ file, uint64_t i0, uint64_t end, bool fast, const uint4 &v)
+{
+    fa_masks m = {0, 0, 0, 0, 0};
+    if (fast) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t nl[4], gt[4], sp[4], hd[4], ze[4];
 #pragma unroll
-    for (int k = 0; k < kFaPer; ++k) {
-        if (i0 + k < end) {
-            if (b[k] == '\n') last = ((uint32_t)(i0 + k + 1) << 1) | 1u;
-            else if (b[k] == '>') last = (uint32_t)(i0 + k + 1) << 1;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t spc = fa_eq4(w[j], 0x20202020u), tab = fa_eq4(w[j], 0x09090909u);
+            nl[j] = fa_eq4(w[j], 0x0A0A0A0Au);
+            gt[j] = fa_eq4(w[j], 0x3E3E3E3Eu);
+            ze[j] = fa_eq4(w[j], 0u);
+            sp[j] = spc | (fa_ge4(w[j], 0x09090909u) & ~fa_ge4(w[j], 0x0E0E0E0Eu)); // ' ', or 9 ... 13
+            hd[j] = spc | tab;
+        }
+        m.nl = gather16(nl[0], nl[1], nl[2], nl[3], 7);
+        m.gt = gather16(gt[0], gt[1], gt[2], gt[3], 7);
+        m.sp = gather16(sp[0], sp[1], sp[2], sp[3], 7);
+        m.hdrop = gather16(hd[0], hd[1], hd[2], hd[3], 7);
+        m.zero = gather16(ze[0], ze[1], ze[2], ze[3], 7);
+    } else { // (the image's last bytes, or an image that does not start on a 16-byte boundary: zero beyond `end`)
+#pragma unroll
+        for (int k = 0; k < kFaPer; ++k) {
+            const uint32_t c = i0 + k < end ? (uint32_t)file[i0 + k] : 0u;
+            m.nl |= (c == '\n' ? 1u : 0u) << k;
+            m.gt |= (c == '>' ? 1u : 0u) << k;
+            m.sp |= ((c == ' ' || c - 9u < 5u) ? 1u : 0u) << k;
+            m.hdrop |= ((c == ' ' || c == '\t') ? 1u : 0u) << k;
+            m.zero |= (c == 0u ? 1u : 0u) << k;
         }
     }
-    return last;
+    return m;
+}
+// the thread's positions in front of `end`
+__device__ __forceinline__ uint32_t fasta_before(uint64_t i0, uint64_t end)
+{
+    return i0 >= end ? 0u : (end - i0 >= (uint64_t)kFaPer ? 0xFFFFu : (1u << (uint32_t)(end - i0)) - 1u);
+}
+
+// (position + 1, kind) of the last '\n' (kind 1: a sequence follows) or '>' (kind 0: a header follows) among the bytes
+__device__ __forceinline__ uint32_t fasta_last_special(const fa_masks &m, uint64_t i0, uint64_t end)
+{
+    const uint32_t ev = (m.nl | m.gt) & fasta_before(i0, end);
+    if (ev == 0) return 0;
+    const uint32_t k = 31u - (uint32_t)__clz(ev);
+    return ((uint32_t)(i0 + k + 1) << 1) | ((m.nl >> k) & 1u);
 }
 
 // What the packing loop of fasta.c:26-70 does with these bytes, entered in header or sequence state:
@@ -84,19 +135,11 @@ struct fa_chunk {
 // (a sequence follows, whatever the state was) or '>' (a header follows) before it, so the 16 bytes are classified
 // without branches into bit masks, the states are filled in from the events by doubling (4 steps for 16 bits), and
 // what is emitted follows from masks: a divergent 16-step walk per thread cost 1.2 - 1.4 ms per GiB and pass.
-__device__ __forceinline__ fa_chunk fasta_walk(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end, bool in_seq)
+__device__ __forceinline__ fa_chunk fasta_walk(const fa_masks &m, uint64_t i0, uint64_t end, bool in_seq)
 {
-    uint32_t nl = 0, gt = 0, sp = 0, hdrop = 0;
-#pragma unroll
-    for (int k = 0; k < kFaPer; ++k) {
-        const uint32_t c = b[k];
-        nl |= (c == '\n' ? 1u : 0u) << k;
-        gt |= (c == '>' ? 1u : 0u) << k;
-        sp |= ((c == ' ' || c - 9u < 5u) ? 1u : 0u) << k;        // isspace(): what a sequence drops
-        hdrop |= ((c == ' ' || c == '\t') ? 1u : 0u) << k;        // what a header line drops besides '>'
-    }
+    const uint32_t nl = m.nl, gt = m.gt, sp = m.sp, hdrop = m.hdrop;
     // positions before `end`, and the position `end` itself (the terminating NUL of the reference's buffer)
-    const uint32_t lt = i0 >= end ? 0u : (end - i0 >= (uint64_t)kFaPer ? 0xFFFFu : (1u << (uint32_t)(end - i0)) - 1u);
+    const uint32_t lt = fasta_before(i0, end);
     const uint32_t ate = (end >= i0 && end - i0 < (uint64_t)kFaPer) ? 1u << (uint32_t)(end - i0) : 0u;
     // state before every byte: events are "a sequence starts here" (after a newline) and "a header starts here"
     // (after a '>'); position 0 takes the entry state
@@ -143,14 +186,10 @@ __global__ __launch_bounds__(kBlock) void fasta_scan_kernel(const uint8_t *__res
     const uint32_t tile = blockIdx.x * (uint32_t)kFaSub + (uint32_t)sub;
     if (tile >= tiles) break; // uniform
     const uint64_t i0 = ((uint64_t)tile * kBlock + threadIdx.x) * kFaPer;
-    uint32_t b[kFaPer];
-    fasta_unpack16(file, i0, end, fast[sub], raw[sub], b);
-    uint32_t zero_at = kFaPer, nl_at = kFaPer;
-#pragma unroll
-    for (int k = kFaPer - 1; k >= 0; --k) {
-        if (b[k] == 0 && i0 + k < end) zero_at = (uint32_t)k;
-        if (b[k] == '\n' && i0 + k < end) nl_at = (uint32_t)k;
-    }
+    const fa_masks m = fasta_masks16(file, i0, end, fast[sub], raw[sub]);
+    const uint32_t in_image = fasta_before(i0, end);
+    const uint32_t zero_at = (m.zero & in_image) ? (uint32_t)__ffs(m.zero & in_image) - 1u : (uint32_t)kFaPer;
+    const uint32_t nl_at = (m.nl & in_image) ? (uint32_t)__ffs(m.nl & in_image) - 1u : (uint32_t)kFaPer;
     // the tile's first NUL ends the image for every thread of the tile (a NUL in an earlier tile: this tile is never used)
     const uint32_t my_nul = zero_at < (uint32_t)kFaPer ? (uint32_t)(i0 + zero_at) : 0xFFFFFFFFu;
     const uint32_t tile_nul = ~block_reduce<OpMax>(~my_nul, lds); // min as a max of complements
@@ -162,13 +201,13 @@ __global__ __launch_bounds__(kBlock) void fasta_scan_kernel(const uint8_t *__res
         (uint32_t)(i0 + nl_at) < __hip_atomic_load(&scal[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMin(&scal[2], (uint32_t)(i0 + nl_at));
     uint32_t tot_last;
-    const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(b, i0, end_l), lds, tot_last);
+    const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(m, i0, end_l), lds, tot_last);
     const bool known = before != 0;
-    const fa_chunk c = fasta_walk(b, i0, end_l, known ? (before & 1u) != 0 : true);
+    const fa_chunk c = fasta_walk(m, i0, end_l, known ? (before & 1u) != 0 : true);
     const uint32_t mine = (uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16);
     uint32_t other = 0;
     if (!known) { // (the first threads of the tile only)
-        const fa_chunk h = fasta_walk(b, i0, end_l, false);
+        const fa_chunk h = fasta_walk(m, i0, end_l, false);
         other = (uint32_t)__popc(h.emit) | ((uint32_t)__popc(h.term) << 16);
     }
     const uint32_t s_known = block_reduce<OpAdd>(known ? mine : 0u, lds);
@@ -197,11 +236,11 @@ struct InFaTileCount {
 };
 
 // state of every thread's first byte = kind of the last special byte before it (none: header)
-__device__ __forceinline__ bool fasta_enter_state(const uint32_t (&b)[kFaPer], uint64_t i0, uint64_t end, uint32_t tile_carry,
+__device__ __forceinline__ bool fasta_enter_state(const fa_masks &m, uint64_t i0, uint64_t end, uint32_t tile_carry,
                                                   uint32_t *lds)
 {
     uint32_t tot;
-    const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(b, i0, end), lds, tot);
+    const uint32_t before = block_exclusive_scan<OpMax>(fasta_last_special(m, i0, end), lds, tot);
     const uint32_t last = before > tile_carry ? before : tile_carry;
     return last != 0 && (last & 1u);
 }
@@ -234,8 +273,9 @@ __global__ __launch_bounds__(kBlock) void fasta_write_kernel(const uint8_t *__re
     const uint64_t i0 = ((uint64_t)tile * kBlock + threadIdx.x) * kFaPer;
     uint32_t b[kFaPer];
     fasta_unpack16(file, i0, end, fast[sub], raw[sub], b);
-    const bool in_seq = fasta_enter_state(b, i0, end, tile_carry[tile], lds);
-    const fa_chunk c = fasta_walk(b, i0, end, in_seq);
+    const fa_masks m = fasta_masks16(file, i0, end, fast[sub], raw[sub]);
+    const bool in_seq = fasta_enter_state(m, i0, end, tile_carry[tile], lds);
+    const fa_chunk c = fasta_walk(m, i0, end, in_seq);
     if (c.eof_in_name) atomicOr(&scal[1], 1u);
     uint32_t tot;
     const uint32_t ex = block_exclusive_scan<OpAdd>((uint32_t)__popc(c.emit) | ((uint32_t)__popc(c.term) << 16), lds, tot);

@@ -261,6 +261,44 @@ def check_fasta(records_of, cases):
             assert c["err"] == 2 and "-4" in str(e), (name, e)
 
 
+def fasta_soup_cases(rng, cases, sizes):
+    """files of '>' / newline / white space / letters / bytes above 0x7f in any order, of well-formed lines with stray '>', of
+    random bytes, and with a NUL inside (the image ends there: io.c:15-18); most end in a sequence line"""
+    soup = np.array(list(b">\n \t\r\x0b\x0cACGTNacgt>>\n\n\n") + [0x80, 0xFF, 0x0E, 0x08, 0x1F, 0x21, 0x3D, 0x3F], dtype=np.uint8)
+    for k in range(cases):
+        n = int(rng.choice(sizes)) + int(rng.integers(0, 3))
+        kind = int(rng.integers(0, 4))
+        if kind == 1:
+            data = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n)
+            data[59::61] = 10
+            if n:
+                data[rng.integers(0, n, size=max(1, n // 500))] = ord(">")
+        elif kind == 2:
+            data = rng.integers(1, 256, size=n, dtype=np.uint8)
+        else:
+            data = rng.choice(soup, size=n)
+            if kind == 3 and n:
+                data[int(rng.integers(0, n))] = 0
+        if kind != 3 and n > 8 and rng.integers(0, 4):
+            data[-6:] = np.frombuffer(b"\nACGT\n", np.uint8)
+        if n and rng.integers(0, 2):
+            data[0] = ord(">")
+        yield k, kind, np.ascontiguousarray(data, np.uint8)
+
+
+def check_fasta_soup(ctx, rng, cases, sizes):
+    from oracle import pyoracle
+    for k, kind, data in fasta_soup_cases(rng, cases, sizes):
+        w_bad, _, w_recs = pyoracle.fasta_pack(data)
+        try:
+            got = ctx.fasta_records(data.tobytes())
+        except Exception as e:  # noqa: BLE001 -- the binding's own error type
+            assert w_bad and "-4" in str(e), (k, data.size, kind, e)
+            continue
+        assert not w_bad, (k, data.size, kind, "should be malformed")
+        assert got == w_recs, (k, data.size, kind)
+
+
 @pytest.fixture(scope="session")
 def emu_ctx():
     """Context on the CPU execution harness build of the kernel sources (tests/emu).

@@ -550,6 +550,13 @@ def test_fasta_ingest_and_remap(emu_routed, golden_fasta):
         emu_routed.remap_dev(x, x.size, np.zeros(x.size + 1, np.uint8))
 
 
+def test_fasta_pack_byte_soup(emu_ctx):
+    """the packing kernels classify a thread's 16 bytes four at a time in their words (round 5): any bytes in any order, around
+    the 16-byte and 4096-byte boundaries, against the C restatement of bioinf/fasta.c:26-135"""
+    from conftest import check_fasta_soup
+    check_fasta_soup(emu_ctx, np.random.default_rng(17), 250, [0, 1, 2, 15, 16, 17, 31, 33, 4095, 4096, 4097, 8191, 8193, 12288, 20000])
+
+
 def test_wide_alphabets_direct_sort_and_induction(emu_ctx):
     """alphabets of 16+ symbols: the direct prefix sort of all suffixes (lms_path 3) and, with it switched off, the
     LMS sort + induction over many buckets; suffix array and BWT from both"""

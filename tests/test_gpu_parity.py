@@ -1122,6 +1122,14 @@ def test_fasta_golden(gpu_ctx, golden_fasta):
     check_fasta(gpu_ctx.fasta_records, golden_fasta)
 
 
+def test_fasta_pack_byte_soup(gpu_ctx):
+    """the packing kernels classify a thread's 16 bytes four at a time in their words (round 5): any bytes in any order, around
+    the 16-byte and 4096-byte boundaries and up to a megabyte, against the C restatement of bioinf/fasta.c:26-135"""
+    from conftest import check_fasta_soup
+    check_fasta_soup(gpu_ctx, np.random.default_rng(19), 500,
+                     [0, 1, 2, 15, 16, 17, 31, 33, 4095, 4096, 4097, 8191, 8193, 12288, 20000, 65536, 262145, 1 << 20])
+
+
 def test_fasta_reference_named_c_api(gpu_ctx, golden_fasta, tmp_path):
     """load_fasta_records and friends (bioinf/fasta.h) as the reference's fasta_test.c drives them"""
     class Rec(C.Structure):
